@@ -1,0 +1,118 @@
+"""Seeded synthetic frames and descriptor sets for parity tests and bench.py.
+
+Follows SURVEY.md section 8(d): corner-rich u8 images (low-pass noise, a few
+thousand rectangles / rotated rectangles / discs with +-30..+-120 contrast,
++-3 pixel noise, plus a flat band so that some FAST cells hit the min-threshold
+fallback and some stay empty).  numpy only, so the same seed gives the same
+bytes here and on the GPU box.
+"""
+import numpy as np
+
+DEFAULT_SEED = 20261004
+
+
+def _box_blur(a, r):
+    """Separable running-mean blur (float64), edge-replicated."""
+    if r <= 0:
+        return a
+    k = 2 * r + 1
+    for axis in (0, 1):
+        pad = [(0, 0), (0, 0)]
+        pad[axis] = (r + 1, r)
+        p = np.pad(a, pad, mode="edge")
+        c = np.cumsum(p, axis=axis)
+        if axis == 0:
+            a = (c[k:, :] - c[:-k, :]) / k
+        else:
+            a = (c[:, k:] - c[:, :-k]) / k
+    return a
+
+
+def make_canvas(width, height, seed=DEFAULT_SEED, n_shapes=None):
+    """One corner-rich u8 canvas of size height x width."""
+    rng = np.random.RandomState(seed)
+    base = rng.uniform(0.0, 1.0, size=(height, width))
+    base = _box_blur(_box_blur(base, 3), 3)
+    lo, hi = base.min(), base.max()
+    img = 40.0 + (base - lo) / max(hi - lo, 1e-9) * 175.0
+    if n_shapes is None:
+        n_shapes = int(6000 * (width * height) / (1242.0 * 375.0))
+    yy, xx = np.mgrid[0:height, 0:width]
+    del yy, xx
+    for _ in range(n_shapes):
+        kind = rng.randint(0, 3)
+        cx = rng.randint(0, width)
+        cy = rng.randint(0, height)
+        r = rng.randint(3, 22)
+        amp = rng.randint(30, 121) * (1 if rng.randint(0, 2) else -1)
+        x0, x1 = max(cx - r, 0), min(cx + r + 1, width)
+        y0, y1 = max(cy - r, 0), min(cy + r + 1, height)
+        if x1 <= x0 or y1 <= y0:
+            continue
+        if kind == 0:  # axis-aligned rectangle with random aspect
+            ry = rng.randint(2, r + 1)
+            y0b, y1b = max(cy - ry, 0), min(cy + ry + 1, height)
+            img[y0b:y1b, x0:x1] += amp
+        else:
+            ly, lx = np.mgrid[y0 - cy:y1 - cy, x0 - cx:x1 - cx]
+            if kind == 1:  # disc
+                m = lx * lx + ly * ly <= r * r
+            else:  # rotated rectangle
+                th = rng.uniform(0, np.pi)
+                c, s = np.cos(th), np.sin(th)
+                u = lx * c + ly * s
+                v = -lx * s + ly * c
+                m = (np.abs(u) <= r * 0.8) & (np.abs(v) <= r * rng.uniform(0.2, 0.7))
+            img[y0:y1, x0:x1] += amp * m
+    img += rng.randint(-3, 4, size=(height, width))
+    # flat band (fallback / empty cells) across ~8% of the height, with faint texture
+    b0 = int(height * 0.55)
+    b1 = b0 + max(int(height * 0.08), 8)
+    img[b0:b1, :] = 128.0 + rng.randint(-1, 2, size=(b1 - b0, width))
+    # a low-contrast strip: corners only at the min threshold
+    s0 = int(height * 0.30)
+    s1 = s0 + max(int(height * 0.06), 8)
+    strip = img[s0:s1, :]
+    img[s0:s1, :] = 128.0 + (strip - strip.mean()) * 0.12
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def make_frames(n, width, height, seed=DEFAULT_SEED):
+    """n distinct frames (n, height, width) u8: shifted crops of one larger canvas
+    plus per-frame +-2 noise, cheap enough for batches of hundreds."""
+    rng = np.random.RandomState(seed + 7)
+    mx, my = 64, 48
+    canvas = make_canvas(width + mx, height + my, seed)
+    out = np.empty((n, height, width), dtype=np.uint8)
+    for i in range(n):
+        ox = rng.randint(0, mx + 1)
+        oy = rng.randint(0, my + 1)
+        f = canvas[oy:oy + height, ox:ox + width].astype(np.int16)
+        if i > 0:
+            f = f + rng.randint(-2, 3, size=f.shape).astype(np.int16)
+        out[i] = np.clip(f, 0, 255).astype(np.uint8)
+    return out
+
+
+def make_descriptor_pair(n, seed=DEFAULT_SEED, flip_p=0.1):
+    """Set A: n x 32 i.i.d. bytes.  Set B: A with each bit flipped w.p. flip_p,
+    then row-permuted.  Returns (A, B, perm) with B[i] derived from A[perm[i]]."""
+    rng = np.random.RandomState(seed + 13)
+    a = rng.randint(0, 256, size=(n, 32)).astype(np.uint8)
+    flips = (rng.uniform(size=(n, 256)) < flip_p)
+    fb = np.packbits(flips, axis=1, bitorder="little")
+    perm = rng.permutation(n)
+    b = (a ^ fb)[perm]
+    return a, np.ascontiguousarray(b), perm
+
+
+def feature_vector_by_prefix(desc, bits):
+    """Synthetic DBoW2 FeatureVector: bucket descriptors by their first `bits`
+    bits (little-endian in byte 0/1).  Returns CSR (node_ids, offsets, indices)
+    with indices ascending inside a node (FeatureVector.cpp:31-45 order)."""
+    key = (desc[:, 0].astype(np.uint32) | (desc[:, 1].astype(np.uint32) << 8)) & ((1 << bits) - 1)
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    node_ids, starts = np.unique(ks, return_index=True)
+    offsets = np.concatenate([starts, [len(ks)]]).astype(np.int32)
+    return node_ids.astype(np.uint32), offsets, order.astype(np.uint32)

@@ -1,0 +1,268 @@
+"""ctypes loader for the CPU oracle (oracle/liborb_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (monoorbslam3_amd/) never
+imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liborb_ref.so")
+MAX_LEVELS = 16
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("n_features", C.c_int), ("n_levels", C.c_int), ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int),
+        ("scale_factor", C.c_float), ("log_scale_factor", C.c_float),
+        ("scale_factors", C.c_float * MAX_LEVELS), ("inv_scale_factors", C.c_float * MAX_LEVELS),
+        ("square_sigmas", C.c_float * MAX_LEVELS), ("inv_square_sigmas", C.c_float * MAX_LEVELS),
+        ("n_features_per_level", C.c_int * MAX_LEVELS), ("u_max", C.c_int * 16), ("blur_taps", C.c_int * 7),
+    ]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4")])
+
+
+class Fv(C.Structure):
+    _fields_ = [("n_nodes", C.c_int), ("node_ids", C.c_void_p), ("offsets", C.c_void_p), ("indices", C.c_void_p)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
+            for f in ("orb_ref.c", "orb_ref.h", "orb_pattern.inc")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.orbref_fast_atan2.restype = C.c_float
+        L.orbref_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orbref_ic_angle.restype = C.c_float
+        L.orbref_round_f.argtypes = [C.c_float]
+        L.orbref_floor_f.argtypes = [C.c_float]
+        L.orbref_ceil_f.argtypes = [C.c_float]
+        L.orbref_round_d.argtypes = [C.c_double]
+        L.orbref_pattern.restype = C.POINTER(C.c_int8)
+        L.orbref_cfg_init.argtypes = [C.POINTER(Cfg), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orbref_sincos_deg.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orbref_ic_angle.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orbref_brief.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.orbref_grid_build.restype = C.c_void_p
+        L.orbref_grid_free.argtypes = [C.c_void_p]
+        L.orbref_features_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int,
+                                              C.c_int, C.c_void_p, C.c_int]
+        L.orbref_search_by_bow.argtypes = [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.POINTER(Fv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Fv)]
+        L.orbref_search_for_triangulation.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                      C.POINTER(Fv), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                      C.POINTER(Fv), C.c_void_p]
+        L.orbref_search_for_initialization.argtypes = [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                       C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                       C.c_void_p, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Thin object wrapper: one orbref_cfg + stage functions on numpy arrays."""
+
+    def __init__(self, n_features=1000, scale_factor=1.2, n_levels=8, ini_th_fast=20, min_th_fast=10,
+                 blur_variant=0):
+        self.L = lib()
+        self.cfg = Cfg()
+        self.L.orbref_cfg_init(C.byref(self.cfg), n_features, scale_factor, n_levels, ini_th_fast, min_th_fast)
+        self.L.orbref_set_blur_taps(C.byref(self.cfg), blur_variant)
+
+    # -- tables -----------------------------------------------------------
+    @property
+    def n_levels(self):
+        return self.cfg.n_levels
+
+    def quotas(self):
+        return list(self.cfg.n_features_per_level[: self.cfg.n_levels])
+
+    def requota(self, n_features):
+        self.L.orbref_cfg_requota(C.byref(self.cfg), n_features)
+
+    def u_max(self):
+        return list(self.cfg.u_max)
+
+    def scale_factors(self):
+        return np.array(self.cfg.scale_factors[: self.cfg.n_levels], dtype=np.float32)
+
+    def level_size(self, w, h, level):
+        lw, lh = C.c_int(), C.c_int()
+        self.L.orbref_level_size(C.byref(self.cfg), w, h, level, C.byref(lw), C.byref(lh))
+        return lw.value, lh.value
+
+    # -- stages -----------------------------------------------------------
+    def resize(self, src, dw, dh):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.empty((dh, dw), dtype=np.uint8)
+        self.L.orbref_resize_linear(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), dw, dh, dw)
+        return dst
+
+    def pyramid(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        levels = [np.empty(self.level_size(w, h, l)[::-1], dtype=np.uint8) for l in range(self.n_levels)]
+        ptrs = (C.c_void_p * self.n_levels)(*[l.ctypes.data for l in levels])
+        self.L.orbref_pyramid(C.byref(self.cfg), _p(img), w, h, w, ptrs)
+        return levels
+
+    def fast_box(self, img, x0, y0, x1, y1, threshold):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        cap = max((x1 - x0) * (y1 - y0), 1)
+        out = np.zeros(cap, dtype=CAND_DTYPE)
+        n = self.L.orbref_fast_box(_p(img), img.shape[1], x0, y0, x1, y1, threshold, _p(out), cap)
+        return out[:n]
+
+    def fast_strength(self, img, x, y):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        return self.L.orbref_fast_strength(_p(img), img.shape[1], x, y)
+
+    def level_candidates(self, level_img):
+        img = np.ascontiguousarray(level_img, dtype=np.uint8)
+        h, w = img.shape
+        cap = max((w - 38) * (h - 38), 1)
+        out = np.zeros(cap, dtype=CAND_DTYPE)
+        n = self.L.orbref_level_candidates(C.byref(self.cfg), _p(img), w, h, w, _p(out), cap)
+        return out[:n]
+
+    def distribute(self, cands, min_x, max_x, min_y, max_y, n_features):
+        cands = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+        out = np.zeros(max(len(cands), 1), dtype=CAND_DTYPE)
+        n = self.L.orbref_distribute_octree(_p(cands), len(cands), min_x, max_x, min_y, max_y, n_features,
+                                            _p(out), len(out))
+        return out[:n]
+
+    def ic_angle(self, img, x, y):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        return float(self.L.orbref_ic_angle(C.byref(self.cfg), _p(img), img.shape[1], x, y))
+
+    def blur(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        out = np.empty_like(img)
+        self.L.orbref_gaussian_blur7(C.byref(self.cfg), _p(img), img.shape[1], img.shape[0], img.shape[1],
+                                     _p(out), img.shape[1])
+        return out
+
+    def brief(self, blur, x, y, angle):
+        blur = np.ascontiguousarray(blur, dtype=np.uint8)
+        d = np.zeros(32, dtype=np.uint8)
+        self.L.orbref_brief(_p(blur), blur.shape[1], x, y, angle, _p(d))
+        return d
+
+    def sincos_deg(self, angle):
+        c, s = C.c_float(), C.c_float()
+        self.L.orbref_sincos_deg(angle, C.byref(c), C.byref(s))
+        return c.value, s.value
+
+    def extract(self, img, cap=None):
+        """operator(): returns (keypoints[KP_DTYPE], descriptors[n,32], per-level counts)."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        if cap is None:
+            cap = 4 * self.cfg.n_features + 64
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        counts = (C.c_int * MAX_LEVELS)()
+        n = self.L.orbref_extract(C.byref(self.cfg), _p(img), w, h, w, _p(kps), _p(desc), cap, counts)
+        if n < 0:
+            raise RuntimeError("oracle: capacity too small")
+        return kps[:n].copy(), desc[:n].copy(), list(counts[: self.n_levels])
+
+
+# -- matcher helpers ---------------------------------------------------------
+def hamming(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    return lib().orbref_hamming(_p(a), _p(b))
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+    i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    lib().orbref_three_maxima(_p(sizes), len(sizes), C.byref(i1), C.byref(i2), C.byref(i3))
+    return i1.value, i2.value, i3.value
+
+
+def _fv(csr):
+    node_ids, offsets, indices = csr
+    node_ids = np.ascontiguousarray(node_ids, dtype=np.uint32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    f = Fv(len(node_ids), node_ids.ctypes.data, offsets.ctypes.data, indices.ctypes.data)
+    f._keep = (node_ids, offsets, indices)
+    return f
+
+
+def search_by_bow(nn_ratio, check_orientation, desc1, angle1, kf_mp_ok, fv1, desc2, angle2, frame_mp, fv2):
+    desc1 = np.ascontiguousarray(desc1, dtype=np.uint8)
+    desc2 = np.ascontiguousarray(desc2, dtype=np.uint8)
+    angle1 = np.ascontiguousarray(angle1, dtype=np.float32)
+    angle2 = np.ascontiguousarray(angle2, dtype=np.float32)
+    kf_mp_ok = np.ascontiguousarray(kf_mp_ok, dtype=np.uint8)
+    frame_mp = np.ascontiguousarray(frame_mp, dtype=np.int32).copy()
+    f1, f2 = _fv(fv1), _fv(fv2)
+    n = lib().orbref_search_by_bow(nn_ratio, int(check_orientation), _p(desc1), _p(angle1), _p(kf_mp_ok),
+                                   len(desc1), C.byref(f1), _p(desc2), _p(angle2), _p(frame_mp), len(desc2),
+                                   C.byref(f2))
+    return n, frame_mp
+
+
+def search_for_triangulation(check_orientation, desc1, angle1, has_mp1, fv1, desc2, angle2, has_mp2, fv2):
+    desc1 = np.ascontiguousarray(desc1, dtype=np.uint8)
+    desc2 = np.ascontiguousarray(desc2, dtype=np.uint8)
+    angle1 = np.ascontiguousarray(angle1, dtype=np.float32)
+    angle2 = np.ascontiguousarray(angle2, dtype=np.float32)
+    has_mp1 = np.ascontiguousarray(has_mp1, dtype=np.uint8)
+    has_mp2 = np.ascontiguousarray(has_mp2, dtype=np.uint8)
+    m12 = np.full(len(desc1), -1, dtype=np.int32)
+    f1, f2 = _fv(fv1), _fv(fv2)
+    n = lib().orbref_search_for_triangulation(int(check_orientation), _p(desc1), _p(angle1), _p(has_mp1),
+                                              len(desc1), C.byref(f1), _p(desc2), _p(angle2), _p(has_mp2),
+                                              len(desc2), C.byref(f2), _p(m12))
+    return n, m12
+
+
+def search_for_initialization(nn_ratio, check_orientation, kps1, desc1, kps2, desc2, img_w, img_h, prematched,
+                              window_size=100):
+    kps1 = np.ascontiguousarray(kps1, dtype=KP_DTYPE)
+    kps2 = np.ascontiguousarray(kps2, dtype=KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, dtype=np.uint8)
+    desc2 = np.ascontiguousarray(desc2, dtype=np.uint8)
+    pre = np.ascontiguousarray(prematched, dtype=np.float32).copy()
+    m12 = np.full(len(kps1), -1, dtype=np.int32)
+    n = lib().orbref_search_for_initialization(nn_ratio, int(check_orientation), _p(kps1), _p(desc1), len(kps1),
+                                               _p(kps2), _p(desc2), len(kps2), img_w, img_h, _p(pre), _p(m12),
+                                               window_size)
+    return n, m12, pre
+
+
+def features_in_area(kps, img_w, img_h, x, y, r, min_level, max_level):
+    kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+    g = lib().orbref_grid_build(_p(kps), len(kps), img_w, img_h)
+    out = np.zeros(max(len(kps), 1), dtype=np.int32)
+    n = lib().orbref_features_in_area(g, _p(kps), x, y, r, min_level, max_level, _p(out), len(out))
+    lib().orbref_grid_free(g)
+    return out[:n]
