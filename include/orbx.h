@@ -1,0 +1,133 @@
+/*
+ * orbx.h -- C ABI of the MI355X ORB extractor (liborbx.so).
+ *
+ * Drop-in boundary for the reference's ORBExtractor
+ * (modules/ORB/ORBExtractor.h:27-122, modules/ORB/ORBExtractor.cpp:424-638):
+ * plain pointers and sizes only, no C++ or torch types.  The header-only shim
+ * monoorbslam3_amd/compat/ORBExtractor.h re-creates the reference class on top
+ * of these entry points.
+ *
+ * Every entry point returns 0 on success or a negative ORBX_E_* code; the text
+ * of the last failure on the calling thread is in orbx_last_error().
+ * There is no CPU fallback: without a HIP device the calls fail with
+ * ORBX_E_NO_DEVICE.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_OK 0
+#define ORBX_E_ARG (-1)       /* bad argument / image larger than the handle was created for */
+#define ORBX_E_NO_DEVICE (-2) /* no HIP device, or a HIP runtime error */
+#define ORBX_E_CAPACITY (-3)  /* caller's output capacity too small (n_out still reports the need) */
+#define ORBX_E_UNSUPPORTED (-4)
+
+#define ORBX_MAX_LEVELS 16
+
+/* Same layout as cv::KeyPoint (28 bytes): the shim memcpy's between the two.
+ * Replaces the std::vector<cv::KeyPoint>& out-parameter of
+ * ORBExtractor::operator() (modules/ORB/ORBExtractor.h:38-39). */
+typedef struct orbx_kp {
+    float x, y;      /* pt, level-0 pixel coordinates (ORBExtractor.cpp:537-542) */
+    float size;      /* scale_factors[octave]            (ORBExtractor.cpp:631)   */
+    float angle;     /* degrees in [0,360]               (ORBExtractor.cpp:41)    */
+    float response;  /* FAST score                                                */
+    int32_t octave;  /* pyramid level                    (ORBExtractor.cpp:630)   */
+    int32_t class_id;/* always -1                                                  */
+} orbx_kp;
+
+/* Constructor arguments of ORBExtractor(int nFeatures, float scaleFactor,
+ * int nLevels, int iniThFast, int minThFast) (modules/ORB/ORBExtractor.h:29-30)
+ * plus the device-side sizing the CPU class does not need. */
+typedef struct orbx_cfg {
+    int32_t n_features;
+    float scale_factor;
+    int32_t n_levels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t max_width;    /* largest level-0 image the handle must accept */
+    int32_t max_height;
+    int32_t max_batch;    /* frames resident per call (>= 1) */
+    int32_t blur_variant; /* 0: 7-tap set summing to 256 (default), 1: plain-rounded set (sum 257) */
+    int32_t device;       /* HIP device ordinal, -1 = current device */
+} orbx_cfg;
+
+typedef struct orbx_ctx orbx_t;
+
+/* ORBExtractor::ORBExtractor(...)  (modules/ORB/ORBExtractor.cpp:424-475) */
+int orbx_create(const orbx_cfg *cfg, orbx_t **out);
+/* ORBExtractor::ORBExtractor(int nFeatures, const ORBExtractor&) (ORBExtractor.cpp:477-493):
+ * same pyramid, new per-level quotas (the 2N "initial" extractor, Tracking.cpp:24). */
+int orbx_create_requota(const orbx_t *other, int n_features, orbx_t **out);
+void orbx_destroy(orbx_t *h);
+
+/* Static scale tables and per-instance quotas
+ * (modules/ORB/ORBExtractor.h:44-86, :109-118).  Any pointer may be NULL. */
+int orbx_tables(const orbx_t *h, int *n_levels, float *scale_factors, float *inv_scale_factors,
+                float *square_sigmas, float *inv_square_sigmas, float *log_scale_factor,
+                int32_t *n_features_per_level, int32_t *u_max16);
+/* Pyramid level size for a level-0 size (ORBExtractor.cpp:563-564) */
+int orbx_level_size(const orbx_t *h, int w0, int h0, int level, int *w, int *ht);
+/* Upper bound on keypoints one frame can yield (sum over levels of max(quota+3, 4*nIni)) */
+int orbx_max_keypoints(const orbx_t *h, int w0, int h0);
+
+/* ORBExtractor::operator()(image, keyPoints, descriptors)
+ * (modules/ORB/ORBExtractor.cpp:495-547).  Host pointers.  img is 8UC1 with
+ * `stride` bytes per row.  On success *n_out keypoints and n_out*32 descriptor
+ * bytes are written, level-major, in the reference's order.  Empty image or
+ * zero keypoints: *n_out = 0 and the outputs are untouched (ORBExtractor.cpp:497,:512). */
+int orbx_extract(orbx_t *h, const uint8_t *img, int width, int height, int stride,
+                 orbx_kp *out_kp, uint8_t *out_desc, int cap, int *n_out);
+
+/* Batch of equally sized frames, host pointers.  Frame f starts at
+ * imgs + f*frame_stride.  Outputs: frame f owns out_kp[f*cap .. ], out_desc[f*cap*32 .. ],
+ * n_out[f]. */
+int orbx_extract_batch(orbx_t *h, const uint8_t *imgs, int n_frames, int width, int height,
+                       int stride, size_t frame_stride, orbx_kp *out_kp, uint8_t *out_desc, int cap,
+                       int32_t *n_out);
+
+/* Same, but every pointer is DEVICE memory (inputs already resident in HBM, the
+ * bench path) and the work is enqueued on `stream` (a hipStream_t, NULL = the
+ * handle's own stream) without a host synchronisation.  d_n_out[f] may exceed
+ * cap; only min(n,cap) records are written. */
+int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_imgs, int n_frames, int width, int height,
+                              int stride, size_t frame_stride, orbx_kp *d_out_kp, uint8_t *d_out_desc,
+                              int cap, int32_t *d_n_out, void *stream);
+/* Block until everything enqueued on the handle's stream has finished. */
+int orbx_synchronize(orbx_t *h);
+
+/* ---- stage taps: copy intermediate results of the LAST extract call to host
+ * memory (parity tests compare every stage with the oracle). ---- */
+/* pyramid level (blurred = 0) or its 7x7 Gaussian-blurred copy (blurred = 1), tightly packed w*h */
+int orbx_tap_level(orbx_t *h, int frame, int level, int blurred, uint8_t *out, size_t out_bytes);
+/* FAST candidates of one level, unordered: x,y relative to (19,19), response.  Returns count via n_out. */
+int orbx_tap_candidates(orbx_t *h, int frame, int level, uint16_t *xs, uint16_t *ys, uint8_t *resp,
+                        int cap, int *n_out);
+/* per-level keypoint counts after the quadtree */
+int orbx_tap_level_counts(orbx_t *h, int frame, int32_t *counts);
+
+/* ---- per-kernel timing (HIP events on the handle's stream) ---- */
+#define ORBX_STAGE_RESIZE 0
+#define ORBX_STAGE_FAST 1
+#define ORBX_STAGE_BLUR 2
+#define ORBX_STAGE_OCTREE 3
+#define ORBX_STAGE_DESC 4
+#define ORBX_N_STAGES 5
+/* enable = 1: every later extract call records HIP events around each stage */
+int orbx_set_stage_timing(orbx_t *h, int enable);
+/* milliseconds each stage took in the last extract call (synchronises) */
+int orbx_stage_times_ms(orbx_t *h, float *ms /* ORBX_N_STAGES */);
+
+const char *orbx_last_error(void);
+const char *orbx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,589 @@
+// C-ABI host side of the MI355X ORB extractor (see include/orbx.h).
+//
+// Mirrors the reference's ORBExtractor (modules/ORB/ORBExtractor.{h,cpp}): construction builds the
+// scale tables, per-level quotas and the circular-patch row table exactly as the constructor at
+// ORBExtractor.cpp:424-475 does; extract enqueues the HIP kernels of orbx_kernels.hip.  There is no
+// CPU implementation of the pixel path in this library: without a HIP device every call fails.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "orb_math.h"
+#include "orbx_internal.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ORBX_E_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct orbx_ctx {
+    orbx_cfg cfg;
+    int device;
+    // reference tables (ORBExtractor.h:109-121)
+    float scale_factors[ORBX_MAX_LEVELS], inv_scale_factors[ORBX_MAX_LEVELS];
+    float square_sigmas[ORBX_MAX_LEVELS], inv_square_sigmas[ORBX_MAX_LEVELS];
+    float log_scale_factor;
+    int quotas[ORBX_MAX_LEVELS];
+    int u_max[ORBX_HALF_PATCH + 1];
+    int taps[7];
+    // geometry of the current frame size
+    int cur_w, cur_h;
+    OrbxLevels levels;
+    size_t l0_stage_pitch; // staging copy of level 0 for the host-pointer API
+    // device state
+    hipStream_t stream;
+    OrbxBuffers buf;
+    OrbxLevels *d_levels;
+    OrbxTap *d_xtap[ORBX_MAX_LEVELS], *d_ytap[ORBX_MAX_LEVELS];
+    int *d_umax, *d_taps;
+    uint8_t *d_l0_stage; size_t l0_stage_fs;
+    orbx_kp *d_out_kp; uint8_t *d_out_desc; int32_t *d_out_n; int out_cap;
+    // capacities actually allocated
+    int alloc_batch;
+    size_t alloc_img_fs, alloc_cand_fs, alloc_node_fs, alloc_l0_fs;
+    int alloc_kcap_total, alloc_out_cap;
+    size_t sort_lds_bytes;
+    // last call (for the taps)
+    const uint8_t *last_l0; size_t last_l0_fs; int last_l0_pitch; int last_frames;
+    // stage timing
+    int timing;
+    hipEvent_t ev[ORBX_N_STAGES + 1];
+    bool ev_valid;
+};
+
+// ------------------------------------------------------------------------------------------------
+// tables -- reference ORBExtractor.cpp:424-475
+// ------------------------------------------------------------------------------------------------
+static void compute_quotas(orbx_ctx *c, int n_features)
+{
+    // :443-452.  pow(float,int) is the double overload; the quotient is rounded once to float.
+    const float sf = c->cfg.scale_factor;
+    float inv2 = 1.0f / (sf * sf);
+    float num = (float)n_features * (1 - inv2);
+    float nd = (float)((double)num / (1.0 - pow((double)inv2, (double)c->cfg.n_levels)));
+    int sum = 0;
+    for (int l = 0; l < c->cfg.n_levels - 1; ++l) {
+        c->quotas[l] = orb_round_f(nd);
+        sum += c->quotas[l];
+        nd *= inv2;
+    }
+    c->quotas[c->cfg.n_levels - 1] = std::max(n_features - sum, 1);
+}
+
+static void compute_tables(orbx_ctx *c)
+{
+    const int L = c->cfg.n_levels;
+    const float sf = c->cfg.scale_factor;
+    c->log_scale_factor = logf(sf);
+    c->scale_factors[0] = c->inv_scale_factors[0] = c->square_sigmas[0] = c->inv_square_sigmas[0] = 1.f;
+    for (int i = 1; i < L; ++i) {
+        c->scale_factors[i] = c->scale_factors[i - 1] * sf;
+        c->inv_scale_factors[i] = 1.f / c->scale_factors[i];
+        c->square_sigmas[i] = c->scale_factors[i] * c->scale_factors[i];
+        c->inv_square_sigmas[i] = 1.f / c->square_sigmas[i];
+    }
+    compute_quotas(c, c->cfg.n_features);
+    // :460-474
+    const int HP = ORBX_HALF_PATCH;
+    int v, v0;
+    const int vmax = orb_floor_f((float)HP * sqrtf(2.f) / 2 + 1);
+    const int vmin = orb_ceil_f((float)HP * sqrtf(2.f) / 2);
+    const double hp2 = HP * HP;
+    for (v = 0; v <= vmax; ++v) c->u_max[v] = (int)lrint(sqrt(hp2 - v * v));
+    for (v = HP, v0 = 0; v >= vmin; --v) {
+        while (c->u_max[v0] == c->u_max[v0 + 1]) ++v0;
+        c->u_max[v] = v0;
+        ++v0;
+    }
+    static const int t0[7] = {18, 34, 48, 56, 48, 34, 18}, t1[7] = {18, 34, 49, 55, 49, 34, 18};
+    memcpy(c->taps, c->cfg.blur_variant == 1 ? t1 : t0, sizeof t0);
+}
+
+static void level_size(const orbx_ctx *c, int w0, int h0, int l, int *w, int *h)
+{
+    if (l == 0) { *w = w0; *h = h0; return; }
+    const float s = c->inv_scale_factors[l]; // :563-564
+    *w = orb_round_f((float)w0 * s);
+    *h = orb_round_f((float)h0 * s);
+}
+
+// cv::resize INTER_LINEAR tap table for one axis
+static void linear_taps(int dn, int sn, bool clamp_ofs, std::vector<OrbxTap> &out)
+{
+    out.resize(dn);
+    const double inv_scale = (double)dn / sn;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dn; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = orb_floor_f(f);
+        f -= (float)s;
+        if (clamp_ofs) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= sn - 1) { f = 0; s = sn - 1; }
+        }
+        auto sat = [](int v) { return (int16_t)std::min(std::max(v, -32768), 32767); };
+        out[d].ofs = s;
+        out[d].c0 = sat(orb_round_f((1.f - f) * 2048.f));
+        out[d].c1 = sat(orb_round_f(f * 2048.f));
+    }
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Geometry {
+    OrbxLevels levels;
+    size_t img_fs, cand_fs, node_fs, l0_fs;
+    int l0_pitch;
+    size_t sort_lds;
+};
+
+static int compute_geometry(const orbx_ctx *c, int w0, int h0, Geometry *g)
+{
+    memset(g, 0, sizeof *g);
+    OrbxLevels &LV = g->levels;
+    LV.n_levels = c->cfg.n_levels;
+    LV.ini_th = c->cfg.ini_th_fast;
+    LV.min_th = c->cfg.min_th_fast;
+    size_t img = 0, cand = 0, node = 0;
+    int kp = 0, max_quota = 1;
+    for (int l = 0; l < LV.n_levels; ++l) {
+        OrbxLevel &v = LV.lv[l];
+        level_size(c, w0, h0, l, &v.w, &v.h);
+        if (v.w < 1 || v.h < 1) return fail(ORBX_E_ARG, "pyramid level collapses to zero size");
+        if (v.w > 32000 || v.h > 32000) return fail(ORBX_E_UNSUPPORTED, "image side above 32000 px");
+        v.pitch = (int)align_up(v.w, 64);
+        v.region_w = v.w - 2 * ORBX_EDGE;
+        v.region_h = v.h - 2 * ORBX_EDGE;
+        v.quota = c->quotas[l];
+        v.scale = c->scale_factors[l];
+        max_quota = std::max(max_quota, v.quota);
+        if (v.region_w > 0 && v.region_h > 0) {
+            v.n_cols = (v.region_w + ORBX_CELL - 1) / ORBX_CELL;
+            v.n_rows = (v.region_h + ORBX_CELL - 1) / ORBX_CELL;
+            // reference :645-646
+            v.n_ini = orb_ceil_f((float)v.region_w / (float)v.region_h);
+            v.h_x = orb_ceil_f((float)v.region_w / (float)v.n_ini);
+            // at most one strict 3x3 maximum per 2x2 block inside a cell
+            const int fullc = v.region_w / ORBX_CELL, remc = v.region_w % ORBX_CELL;
+            const int fullr = v.region_h / ORBX_CELL, remr = v.region_h % ORBX_CELL;
+            const int colsum = fullc * 15 + (remc + 1) / 2, rowsum = fullr * 15 + (remr + 1) / 2;
+            v.cand_cap = colsum * rowsum;
+            v.kcap = std::max(v.quota + 3, 4 * v.n_ini);
+            v.node_cap = std::max(4 * v.quota, 4 * v.n_ini) + 8;
+        } else { // level too small for the 19-px border: yields nothing (the reference misbehaves here)
+            v.n_cols = v.n_rows = 0; v.n_ini = 1; v.h_x = 1; v.cand_cap = 0; v.kcap = 1; v.node_cap = 8;
+        }
+        v.kp_off = kp; kp += v.kcap;
+        v.cand_off = cand; cand += (size_t)align_up(std::max(v.cand_cap, 1), 2);
+        v.node_off = node; node += (size_t)align_up(v.node_cap, 4);
+        const size_t bytes = (size_t)v.pitch * v.h;
+        if (l > 0) { v.raw_off = img; img += align_up(bytes, 256); }
+        v.blur_off = img; img += align_up(bytes, 256);
+    }
+    LV.kcap_total = kp;
+    g->img_fs = img;
+    g->cand_fs = cand;
+    g->node_fs = node;
+    g->l0_pitch = LV.lv[0].pitch;
+    g->l0_fs = align_up((size_t)g->l0_pitch * h0, 256);
+    size_t p = 1;
+    while (p < (size_t)max_quota) p <<= 1;
+    g->sort_lds = p * sizeof(unsigned long long);
+    if (g->sort_lds > 60 * 1024) return fail(ORBX_E_UNSUPPORTED, "per-level quota above 7680 features");
+    return ORBX_OK;
+}
+
+template <typename T> static hipError_t dev_alloc(T **p, size_t n)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    return hipMalloc((void **)p, std::max(n, (size_t)1) * sizeof(T));
+}
+
+static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
+{
+    Geometry g;
+    const bool same = (w0 == c->cur_w && h0 == c->cur_h);
+    if (!same) {
+        int rc = compute_geometry(c, w0, h0, &g);
+        if (rc) return rc;
+    } else {
+        g.levels = c->levels;
+        g.img_fs = c->alloc_img_fs; g.cand_fs = c->alloc_cand_fs; g.node_fs = c->alloc_node_fs; g.l0_fs = c->alloc_l0_fs;
+        g.l0_pitch = (int)c->l0_stage_pitch; g.sort_lds = c->sort_lds_bytes;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const bool grow = batch > c->alloc_batch || g.img_fs > c->alloc_img_fs || g.cand_fs > c->alloc_cand_fs ||
+                      g.node_fs > c->alloc_node_fs || g.l0_fs > c->alloc_l0_fs ||
+                      g.levels.kcap_total > c->alloc_kcap_total;
+    if (grow) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const int B = std::max(batch, c->alloc_batch);
+        const size_t img_fs = std::max(g.img_fs, c->alloc_img_fs), cand_fs = std::max(g.cand_fs, c->alloc_cand_fs);
+        const size_t node_fs = std::max(g.node_fs, c->alloc_node_fs), l0_fs = std::max(g.l0_fs, c->alloc_l0_fs);
+        const int kcap = std::max(g.levels.kcap_total, c->alloc_kcap_total);
+        OrbxBuffers &b = c->buf;
+        HIP_TRY(dev_alloc(&b.img_arena, img_fs * B));
+        HIP_TRY(dev_alloc(&b.cand, cand_fs * B));
+        HIP_TRY(dev_alloc(&b.pnode, cand_fs * B));
+        HIP_TRY(dev_alloc(&b.cand_count, (size_t)ORBX_MAX_LEVELS * B));
+        HIP_TRY(dev_alloc(&b.bnd0, node_fs * B));
+        HIP_TRY(dev_alloc(&b.bnd1, node_fs * B));
+        HIP_TRY(dev_alloc(&b.cnt0, node_fs * B));
+        HIP_TRY(dev_alloc(&b.cnt1, node_fs * B));
+        HIP_TRY(dev_alloc(&b.rank, node_fs * B));
+        HIP_TRY(dev_alloc(&b.node_of_rank, node_fs * B));
+        HIP_TRY(dev_alloc(&b.newpos, node_fs * B));
+        HIP_TRY(dev_alloc(&b.childcnt, 4 * node_fs * B));
+        HIP_TRY(dev_alloc(&b.childpos, 4 * node_fs * B));
+        HIP_TRY(dev_alloc(&b.best, node_fs * B));
+        HIP_TRY(dev_alloc(&b.sel, (size_t)kcap * B));
+        HIP_TRY(dev_alloc(&b.sel_count, (size_t)ORBX_MAX_LEVELS * B));
+        HIP_TRY(dev_alloc(&c->d_l0_stage, l0_fs * B));
+        c->alloc_batch = B; c->alloc_img_fs = img_fs; c->alloc_cand_fs = cand_fs; c->alloc_node_fs = node_fs;
+        c->alloc_l0_fs = l0_fs; c->alloc_kcap_total = kcap;
+        c->alloc_out_cap = 0; // host-API output staging is per (batch, cap)
+    }
+    if (out_cap > 0 && (out_cap > c->alloc_out_cap || grow)) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const int cap = std::max(out_cap, c->alloc_out_cap);
+        HIP_TRY(dev_alloc(&c->d_out_kp, (size_t)cap * c->alloc_batch));
+        HIP_TRY(dev_alloc(&c->d_out_desc, (size_t)cap * 32 * c->alloc_batch));
+        HIP_TRY(dev_alloc(&c->d_out_n, (size_t)c->alloc_batch));
+        c->alloc_out_cap = cap;
+    }
+    if (!same) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->levels = g.levels;
+        c->cur_w = w0; c->cur_h = h0;
+        c->l0_stage_pitch = g.l0_pitch;
+        c->sort_lds_bytes = g.sort_lds;
+        HIP_TRY(hipMemcpy(c->d_levels, &c->levels, sizeof(OrbxLevels), hipMemcpyHostToDevice));
+        std::vector<OrbxTap> taps;
+        for (int l = 1; l < c->levels.n_levels; ++l) {
+            const OrbxLevel &d = c->levels.lv[l], &s = c->levels.lv[l - 1];
+            linear_taps(d.w, s.w, true, taps);
+            HIP_TRY(dev_alloc(&c->d_xtap[l], taps.size()));
+            HIP_TRY(hipMemcpy(c->d_xtap[l], taps.data(), taps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice));
+            linear_taps(d.h, s.h, false, taps);
+            HIP_TRY(dev_alloc(&c->d_ytap[l], taps.size()));
+            HIP_TRY(hipMemcpy(c->d_ytap[l], taps.data(), taps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice));
+        }
+    }
+    // frame strides of the arenas are the allocated ones
+    c->buf.img_frame_stride = c->alloc_img_fs;
+    c->buf.cand_frame_stride = c->alloc_cand_fs;
+    c->buf.node_frame_stride = c->alloc_node_fs;
+    c->l0_stage_fs = c->alloc_l0_fs;
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// construction
+// ------------------------------------------------------------------------------------------------
+static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t **out)
+{
+    if (!cfg || !out) return fail(ORBX_E_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->n_levels < 1 || cfg->n_levels > ORBX_MAX_LEVELS) return fail(ORBX_E_ARG, "n_levels out of range");
+    if (cfg->n_features < 1) return fail(ORBX_E_ARG, "n_features must be >= 1");
+    if (!(cfg->scale_factor > 1.0f)) return fail(ORBX_E_ARG, "scale_factor must be > 1");
+    if (fabs((double)cfg->scale_factor - 2.0) < 1e-6)
+        return fail(ORBX_E_UNSUPPORTED, "scale_factor 2.0 takes cv::resize's INTER_AREA shortcut, not implemented");
+    if (cfg->ini_th_fast < 1 || cfg->min_th_fast < 1 || cfg->ini_th_fast > 254 || cfg->min_th_fast > 254)
+        return fail(ORBX_E_ARG, "FAST thresholds must be in [1,254]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(ORBX_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    orbx_ctx *c = new orbx_ctx();
+    memset(c, 0, sizeof *c);
+    c->cfg = *cfg;
+    if (c->cfg.max_batch < 1) c->cfg.max_batch = 1;
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) { delete c; return fail(ORBX_E_ARG, "device ordinal out of range"); }
+    c->device = dev;
+    compute_tables(c);
+    if (quotas_override) memcpy(c->quotas, quotas_override, sizeof(int) * cfg->n_levels);
+    c->cur_w = c->cur_h = -1;
+    auto cleanup = [&](int code) { orbx_destroy(c); return code; };
+    if (hipSetDevice(dev) != hipSuccess) return cleanup(fail(ORBX_E_NO_DEVICE, "hipSetDevice failed"));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        return cleanup(fail(ORBX_E_NO_DEVICE, "hipStreamCreate failed"));
+    for (int i = 0; i <= ORBX_N_STAGES; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) return cleanup(fail(ORBX_E_NO_DEVICE, "hipEventCreate failed"));
+    if (hipMalloc((void **)&c->d_levels, sizeof(OrbxLevels)) != hipSuccess ||
+        hipMalloc((void **)&c->d_umax, sizeof(int) * 16) != hipSuccess ||
+        hipMalloc((void **)&c->d_taps, sizeof(int) * 8) != hipSuccess)
+        return cleanup(fail(ORBX_E_NO_DEVICE, "hipMalloc failed"));
+    if (hipMemcpy(c->d_umax, c->u_max, sizeof(int) * 16, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_taps, c->taps, sizeof(int) * 7, hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup(fail(ORBX_E_NO_DEVICE, "hipMemcpy failed"));
+    if (cfg->max_width > 0 && cfg->max_height > 0) {
+        int rc = ensure_geometry(c, cfg->max_width, cfg->max_height, c->cfg.max_batch, 0);
+        if (rc) return cleanup(rc);
+    }
+    *out = c;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_create(const orbx_cfg *cfg, orbx_t **out) { return create_common(cfg, nullptr, out); }
+
+extern "C" int orbx_create_requota(const orbx_t *other, int n_features, orbx_t **out)
+{
+    // reference ORBExtractor.cpp:477-493: same pyramid and thresholds, new quotas
+    if (!other) return fail(ORBX_E_ARG, "null argument");
+    orbx_cfg cfg = other->cfg;
+    cfg.n_features = n_features;
+    return create_common(&cfg, nullptr, out);
+}
+
+extern "C" void orbx_destroy(orbx_t *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    OrbxBuffers &b = c->buf;
+    void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
+                    b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.sel_count, c->d_levels, c->d_umax, c->d_taps,
+                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
+        if (c->d_xtap[l]) (void)hipFree(c->d_xtap[l]);
+        if (c->d_ytap[l]) (void)hipFree(c->d_ytap[l]);
+    }
+    for (int i = 0; i <= ORBX_N_STAGES; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int orbx_tables(const orbx_t *c, int *n_levels, float *sf, float *isf, float *ss, float *iss, float *lsf,
+                           int32_t *quotas, int32_t *u_max16)
+{
+    if (!c) return fail(ORBX_E_ARG, "null handle");
+    const int L = c->cfg.n_levels;
+    if (n_levels) *n_levels = L;
+    if (sf) memcpy(sf, c->scale_factors, sizeof(float) * L);
+    if (isf) memcpy(isf, c->inv_scale_factors, sizeof(float) * L);
+    if (ss) memcpy(ss, c->square_sigmas, sizeof(float) * L);
+    if (iss) memcpy(iss, c->inv_square_sigmas, sizeof(float) * L);
+    if (lsf) *lsf = c->log_scale_factor;
+    if (quotas) memcpy(quotas, c->quotas, sizeof(int) * L);
+    if (u_max16) memcpy(u_max16, c->u_max, sizeof(int) * 16);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_level_size(const orbx_t *c, int w0, int h0, int level, int *w, int *h)
+{
+    if (!c || level < 0 || level >= c->cfg.n_levels || !w || !h) return fail(ORBX_E_ARG, "bad argument");
+    level_size(c, w0, h0, level, w, h);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_max_keypoints(const orbx_t *c, int w0, int h0)
+{
+    if (!c) return fail(ORBX_E_ARG, "null handle");
+    Geometry g;
+    int rc = compute_geometry(c, w0, h0, &g);
+    if (rc) return rc;
+    return g.levels.kcap_total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the pipeline
+// ------------------------------------------------------------------------------------------------
+static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs, int l0_pitch, int n_frames,
+                   orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n)
+{
+    const OrbxLevels &LV = c->levels;
+    const int L = LV.n_levels;
+    OrbxBuffers &b = c->buf;
+    const bool t = c->timing != 0;
+    if (t) HIP_TRY(hipEventRecord(c->ev[0], s));
+    HIP_TRY(hipMemsetAsync(b.cand_count, 0, sizeof(int) * ORBX_MAX_LEVELS * n_frames, s));
+    auto raw = [&](int l, const uint8_t **p, size_t *fs, int *pitch) {
+        if (l == 0) { *p = d_l0; *fs = l0_fs; *pitch = l0_pitch; }
+        else { *p = b.img_arena + LV.lv[l].raw_off; *fs = b.img_frame_stride; *pitch = LV.lv[l].pitch; }
+    };
+    for (int l = 1; l < L; ++l) {
+        const uint8_t *sp; size_t sfs; int spitch;
+        raw(l - 1, &sp, &sfs, &spitch);
+        orbx_launch_resize(s, sp, sfs, spitch, LV.lv[l - 1].w, LV.lv[l - 1].h, b.img_arena + LV.lv[l].raw_off,
+                           b.img_frame_stride, LV.lv[l].pitch, LV.lv[l].w, LV.lv[l].h, c->d_xtap[l], c->d_ytap[l],
+                           n_frames);
+    }
+    if (t) HIP_TRY(hipEventRecord(c->ev[1], s));
+    for (int l = 0; l < L; ++l) {
+        const uint8_t *sp; size_t sfs; int spitch;
+        raw(l, &sp, &sfs, &spitch);
+        orbx_launch_fast(s, sp, sfs, spitch, LV.lv[l], l, ORBX_MAX_LEVELS, b, LV.ini_th, LV.min_th, n_frames);
+    }
+    if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
+    for (int l = 0; l < L; ++l) {
+        const uint8_t *sp; size_t sfs; int spitch;
+        raw(l, &sp, &sfs, &spitch);
+        orbx_launch_blur(s, sp, sfs, spitch, b.img_arena + LV.lv[l].blur_off, b.img_frame_stride, LV.lv[l].pitch,
+                         LV.lv[l].w, LV.lv[l].h, c->d_taps, n_frames);
+    }
+    if (t) HIP_TRY(hipEventRecord(c->ev[3], s));
+    orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes);
+    if (t) HIP_TRY(hipEventRecord(c->ev[4], s));
+    orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames);
+    if (t) { HIP_TRY(hipEventRecord(c->ev[5], s)); c->ev_valid = true; }
+    HIP_TRY(hipGetLastError());
+    c->last_l0 = d_l0; c->last_l0_fs = l0_fs; c->last_l0_pitch = l0_pitch; c->last_frames = n_frames;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch_device(orbx_t *c, const uint8_t *d_imgs, int n_frames, int width, int height,
+                                         int stride, size_t frame_stride, orbx_kp *d_kp, uint8_t *d_desc, int cap,
+                                         int32_t *d_n, void *stream)
+{
+    if (!c || !d_imgs || !d_kp || !d_desc || !d_n) return fail(ORBX_E_ARG, "null argument");
+    if (n_frames < 1 || width < 1 || height < 1 || stride < width || cap < 1) return fail(ORBX_E_ARG, "bad size");
+    int rc = ensure_geometry(c, width, height, n_frames, 0);
+    if (rc) return rc;
+    return enqueue(c, stream ? (hipStream_t)stream : c->stream, d_imgs, frame_stride, stride, n_frames, d_kp, d_desc,
+                   cap, d_n);
+}
+
+extern "C" int orbx_synchronize(orbx_t *c)
+{
+    if (!c) return fail(ORBX_E_ARG, "null handle");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch(orbx_t *c, const uint8_t *imgs, int n_frames, int width, int height, int stride,
+                                  size_t frame_stride, orbx_kp *out_kp, uint8_t *out_desc, int cap, int32_t *n_out)
+{
+    if (!c || !n_out) return fail(ORBX_E_ARG, "null argument");
+    for (int f = 0; f < n_frames; ++f) n_out[f] = 0;
+    if (!imgs || width <= 0 || height <= 0) return ORBX_OK; // reference :497 -- empty image: silent no-op
+    if (n_frames < 1 || stride < width || cap < 1 || !out_kp || !out_desc) return fail(ORBX_E_ARG, "bad argument");
+    Geometry g;
+    int rc = compute_geometry(c, width, height, &g);
+    if (rc) return rc;
+    const int dcap = g.levels.kcap_total; // device-side staging holds every possible keypoint
+    rc = ensure_geometry(c, width, height, n_frames, dcap);
+    if (rc) return rc;
+    const int scap = c->alloc_out_cap;
+    hipStream_t s = c->stream;
+    for (int f = 0; f < n_frames; ++f)
+        HIP_TRY(hipMemcpy2DAsync(c->d_l0_stage + (size_t)f * c->l0_stage_fs, c->l0_stage_pitch,
+                                 imgs + (size_t)f * frame_stride, stride, width, height, hipMemcpyHostToDevice, s));
+    rc = enqueue(c, s, c->d_l0_stage, c->l0_stage_fs, (int)c->l0_stage_pitch, n_frames, c->d_out_kp, c->d_out_desc,
+                 scap, c->d_out_n);
+    if (rc) return rc;
+    std::vector<int32_t> counts(n_frames);
+    HIP_TRY(hipMemcpyAsync(counts.data(), c->d_out_n, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int status = ORBX_OK;
+    for (int f = 0; f < n_frames; ++f) {
+        const int n = counts[f];
+        n_out[f] = n;
+        if (n == 0) continue; // reference :512 -- outputs untouched
+        if (n > cap) { status = ORBX_E_CAPACITY; continue; }
+        HIP_TRY(hipMemcpyAsync(out_kp + (size_t)f * cap, c->d_out_kp + (size_t)f * scap, sizeof(orbx_kp) * n,
+                               hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out_desc + (size_t)f * cap * 32, c->d_out_desc + (size_t)f * scap * 32, (size_t)n * 32,
+                               hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (status == ORBX_E_CAPACITY) return fail(status, "output capacity too small");
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract(orbx_t *c, const uint8_t *img, int width, int height, int stride, orbx_kp *out_kp,
+                            uint8_t *out_desc, int cap, int *n_out)
+{
+    int32_t n = 0;
+    int rc = orbx_extract_batch(c, img, 1, width, height, stride, (size_t)stride * (height > 0 ? height : 0), out_kp,
+                                out_desc, cap, &n);
+    if (n_out) *n_out = n;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage taps
+// ------------------------------------------------------------------------------------------------
+extern "C" int orbx_tap_level(orbx_t *c, int frame, int level, int blurred, uint8_t *out, size_t out_bytes)
+{
+    if (!c || !out || c->cur_w < 0 || !c->last_l0) return fail(ORBX_E_ARG, "no extract call yet");
+    if (frame < 0 || frame >= c->last_frames || level < 0 || level >= c->levels.n_levels)
+        return fail(ORBX_E_ARG, "frame/level out of range");
+    const OrbxLevel &v = c->levels.lv[level];
+    if (out_bytes < (size_t)v.w * v.h) return fail(ORBX_E_CAPACITY, "buffer too small");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint8_t *src; size_t pitch;
+    if (blurred) { src = c->buf.img_arena + (size_t)frame * c->buf.img_frame_stride + v.blur_off; pitch = v.pitch; }
+    else if (level == 0) { src = c->last_l0 + (size_t)frame * c->last_l0_fs; pitch = c->last_l0_pitch; }
+    else { src = c->buf.img_arena + (size_t)frame * c->buf.img_frame_stride + v.raw_off; pitch = v.pitch; }
+    HIP_TRY(hipMemcpy2D(out, v.w, src, pitch, v.w, v.h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_tap_candidates(orbx_t *c, int frame, int level, uint16_t *xs, uint16_t *ys, uint8_t *resp, int cap,
+                                   int *n_out)
+{
+    if (!c || !n_out || c->cur_w < 0 || !c->last_l0) return fail(ORBX_E_ARG, "no extract call yet");
+    if (frame < 0 || frame >= c->last_frames || level < 0 || level >= c->levels.n_levels)
+        return fail(ORBX_E_ARG, "frame/level out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int n = 0;
+    HIP_TRY(hipMemcpy(&n, c->buf.cand_count + frame * ORBX_MAX_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n > cap) return fail(ORBX_E_CAPACITY, "buffer too small");
+    std::vector<unsigned long long> tmp(std::max(n, 1));
+    HIP_TRY(hipMemcpy(tmp.data(), c->buf.cand + (size_t)frame * c->buf.cand_frame_stride + c->levels.lv[level].cand_off,
+                      sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        if (xs) xs[i] = (uint16_t)(tmp[i] & 0xFFFF);
+        if (ys) ys[i] = (uint16_t)((tmp[i] >> 16) & 0xFFFF);
+        if (resp) resp[i] = (uint8_t)(tmp[i] >> 32);
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_tap_level_counts(orbx_t *c, int frame, int32_t *counts)
+{
+    if (!c || !counts || c->cur_w < 0 || !c->last_l0) return fail(ORBX_E_ARG, "no extract call yet");
+    if (frame < 0 || frame >= c->last_frames) return fail(ORBX_E_ARG, "frame out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(counts, c->buf.sel_count + frame * ORBX_MAX_LEVELS, sizeof(int) * c->levels.n_levels,
+                      hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_set_stage_timing(orbx_t *c, int enable)
+{
+    if (!c) return fail(ORBX_E_ARG, "null handle");
+    c->timing = enable;
+    c->ev_valid = false;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_stage_times_ms(orbx_t *c, float *ms)
+{
+    if (!c || !ms) return fail(ORBX_E_ARG, "null argument");
+    if (!c->ev_valid) return fail(ORBX_E_ARG, "no timed extract call yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[ORBX_N_STAGES]));
+    for (int i = 0; i < ORBX_N_STAGES; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    return ORBX_OK;
+}
+
+extern "C" const char *orbx_last_error(void) { return g_err.c_str(); }
+extern "C" const char *orbx_version(void) { return "orbx 0.1 (gfx950)"; }

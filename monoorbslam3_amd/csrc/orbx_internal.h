@@ -1,0 +1,74 @@
+// Internal declarations shared by the extractor's kernels and its C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/orbx.h"
+
+#define ORBX_EDGE 19        // EDGE_THRESHOLD (reference modules/ORB/ORBExtractor.cpp:15)
+#define ORBX_CELL 30        // W              (reference modules/ORB/ORBExtractor.cpp:575)
+#define ORBX_HALF_PATCH 15  // HALF_PATCH_SIZE(reference modules/ORB/ORBExtractor.cpp:14)
+#define ORBX_OCT_THREADS 512
+
+// Geometry of one pyramid level and where its buffers live inside the per-frame arenas.
+struct OrbxLevel {
+    int w, h;           // level size
+    int pitch;          // bytes per row in the arena (multiple of 64)
+    int n_cols, n_rows; // FAST cells (30x30) over [19,w-19) x [19,h-19)
+    int region_w, region_h;
+    int quota;          // n_features_per_level
+    int n_ini, h_x;     // DistributeOctree initial nodes (reference :645-646)
+    int kcap;           // upper bound on keypoints after the quadtree
+    int kp_off;         // prefix sum of kcap (slot offset in the per-frame selected array)
+    int node_cap;       // quadtree list capacity
+    int cand_cap;       // candidate capacity (sum over cells of ceil(cw/2)*ceil(ch/2))
+    float scale;        // scale_factors[level]
+    size_t raw_off;     // byte offset of the raw level inside a frame's image arena (level 0: unused)
+    size_t blur_off;    // byte offset of the blurred level
+    size_t cand_off;    // record offset inside a frame's candidate arena
+    size_t node_off;    // node-slot offset inside a frame's quadtree scratch
+};
+
+// Per-dst-column / per-dst-row bilinear tap (cv::resize INTER_LINEAR fixed point)
+struct OrbxTap {
+    int32_t ofs;
+    int16_t c0, c1;
+};
+
+struct OrbxLevels {
+    int n_levels;
+    int ini_th, min_th;
+    int kcap_total;
+    OrbxLevel lv[ORBX_MAX_LEVELS];
+};
+
+// Device pointers of one extractor handle (all per-frame arenas are frame-major).
+struct OrbxBuffers {
+    uint8_t *img_arena;        size_t img_frame_stride;   // raw levels 1.. + blurred levels 0..
+    unsigned long long *cand;  size_t cand_frame_stride;  // packed candidates
+    int *cand_count;                                      // [frame][level]
+    uint32_t *pnode;                                      // [frame][cand slot] quadtree node of each candidate
+    // quadtree scratch, per frame `node_frame_stride` node slots
+    size_t node_frame_stride;
+    short4 *bnd0, *bnd1;
+    int *cnt0, *cnt1;
+    int *rank, *node_of_rank, *newpos;
+    int *childcnt, *childpos;                             // 4 per node slot
+    unsigned long long *best;
+    uint2 *sel;                                           // [frame][kcap_total] selected keypoints (x | y<<16, response)
+    int *sel_count;                                       // [frame][level]
+};
+
+void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh,
+                        uint8_t *dst, size_t dst_fs, int dst_pitch, int dw, int dh,
+                        const OrbxTap *xtap, const OrbxTap *ytap, int n_frames);
+void orbx_launch_fast(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, const OrbxLevel &lv, int level,
+                      int n_levels, const OrbxBuffers &b, int ini_th, int min_th, int n_frames);
+void orbx_launch_blur(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, uint8_t *dst, size_t dst_fs,
+                      int dst_pitch, int w, int h, const int *taps7, int n_frames);
+void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLevels &levels, const OrbxBuffers &b,
+                        int n_frames, size_t sort_lds_bytes);
+void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
+                             const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
+                             uint8_t *out_desc, int cap, int32_t *out_n, int n_frames);

@@ -1,0 +1,107 @@
+"""GPU parity: every stage of the HIP extractor against the CPU oracle, through the C ABI.
+
+Bar: bit-exact pyramid / blurred levels, identical FAST candidate sets, identical
+keypoint (u, v, octave, response) lists in the reference's order, identical 32-byte
+descriptors; orientation bit-identical (shared arithmetic), checked with tolerance
+1e-4 degrees as the stated fallback bound.
+"""
+import numpy as np
+import pytest
+
+from monoorbslam3_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(oracle_mod, n_features, w, h, ini=20, mn=7, n_levels=8, sf=1.2, batch=1):
+    from monoorbslam3_amd.extractor import ORBExtractor
+    ex = ORBExtractor(n_features, sf, n_levels, ini, mn, max_width=w, max_height=h, max_batch=batch)
+    orc = oracle_mod.Oracle(n_features, sf, n_levels, ini, mn)
+    return ex, orc
+
+
+def _check_frame(ex, orc, img, kps, desc, frame=0, stages=True):
+    h, w = img.shape
+    okps, odesc, ocounts = orc.extract(img)
+    if stages:
+        pyr = orc.pyramid(img)
+        for l in range(orc.n_levels):
+            got = ex.tap_level(frame, l, w, h, blurred=False)
+            assert np.array_equal(got, pyr[l]), "pyramid level %d differs" % l
+            gotb = ex.tap_level(frame, l, w, h, blurred=True)
+            assert np.array_equal(gotb, orc.blur(pyr[l])), "blurred level %d differs" % l
+            xs, ys, rs = ex.tap_candidates(frame, l)
+            oc = orc.level_candidates(pyr[l])
+            got_set = sorted(zip(ys.tolist(), xs.tolist(), rs.tolist()))
+            ref_set = sorted(zip(oc["y"].astype(int).tolist(), oc["x"].astype(int).tolist(),
+                                 oc["response"].astype(int).tolist()))
+            assert got_set == ref_set, "FAST candidates differ at level %d" % l
+        assert ex.tap_level_counts(frame).tolist() == ocounts
+    assert len(kps) == len(okps)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(kps[f], okps[f]), f
+    assert np.max(np.abs(kps["angle"] - okps["angle"]), initial=0) <= 1e-4
+    assert np.array_equal(kps["angle"], okps["angle"])
+    assert np.array_equal(desc, odesc)
+
+
+@pytest.mark.parametrize("w,h,nf", [(1242, 375, 2000), (752, 480, 1000), (640, 200, 500)])
+def test_single_frame_all_stages(oracle_mod, w, h, nf):
+    ex, orc = _mk(oracle_mod, nf, w, h)
+    img = synth.make_frames(1, w, h, seed=synth.DEFAULT_SEED + w)[0]
+    kps, desc = ex(img)
+    assert len(kps) > nf // 2
+    _check_frame(ex, orc, img, kps, desc)
+
+
+def test_batch_host(oracle_mod):
+    w, h, nf = 1242, 375, 2000
+    ex, orc = _mk(oracle_mod, nf, w, h, batch=4)
+    imgs = synth.make_frames(4, w, h)
+    res = ex.extract_batch(imgs)
+    for f in range(4):
+        _check_frame(ex, orc, imgs[f], res[f][0], res[f][1], frame=f, stages=(f in (0, 3)))
+
+
+def test_requota_initial_extractor(oracle_mod):
+    """the 2N 'initial' extractor (reference Tracking.cpp:24, ORBExtractor.cpp:477-493)"""
+    from monoorbslam3_amd.extractor import ORBExtractor
+    w, h = 752, 480
+    ex = ORBExtractor(1000, 1.2, 8, 20, 7)
+    ex2 = ORBExtractor.requota(2000, ex)
+    orc = oracle_mod.Oracle(1000, 1.2, 8, 20, 7)
+    orc.requota(2000)
+    assert ex2.features_per_level().tolist() == orc.quotas()
+    img = synth.make_frames(1, w, h, seed=5)[0]
+    kps, desc = ex2(img)
+    _check_frame(ex2, orc, img, kps, desc, stages=False)
+
+
+def test_edge_cases(oracle_mod):
+    from monoorbslam3_amd.extractor import ORBExtractor
+    ex = ORBExtractor(500, 1.2, 8, 20, 7)
+    orc = oracle_mod.Oracle(500, 1.2, 8, 20, 7)
+    # empty image: silent no-op (reference ORBExtractor.cpp:497)
+    k, d = ex(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    # flat image: zero keypoints (reference :512)
+    k, d = ex(np.full((240, 320), 90, np.uint8))
+    assert len(k) == 0
+    # tiny quota levels / few corners: a handful of isolated squares
+    img = np.full((240, 320), 60, np.uint8)
+    img[100:120, 100:130] = 200
+    img[40:60, 200:230] = 10
+    k, d = ex(img)
+    ok, od, _ = orc.extract(img)
+    assert len(k) == len(ok) and len(k) > 0
+    assert np.array_equal(k["x"], ok["x"]) and np.array_equal(k["y"], ok["y"]) and np.array_equal(d, od)
+    # random noise: every cell saturated with candidates, quadtree final phase exercised hard
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 256, size=(300, 500)).astype(np.uint8)
+    k, d = ex(img)
+    _check_frame(ex, orc, img, k, d)
+    # non-contiguous rows (stride > width)
+    big = synth.make_frames(1, 700, 300, seed=11)[0]
+    view = big[:, 20:660]
+    k, d = ex(view)
+    _check_frame(ex, orc, np.ascontiguousarray(view), k, d, stages=False)
