@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- ORB extract+match frames/s at 1242x375 / 2000 features on N MI355X.
+
+One "step" = one pass of the hot path over one resident batch of synthetic frames per GPU:
+pyramid -> FAST cells -> blur -> quadtree -> orientation + rBRIEF for every frame, then the
+256-bit Hamming best-2 brute force (the SearchByBow inner loop) of every frame's descriptors
+against its neighbour's.  Inputs live in HBM before the timed region.  With N > 1 each rank
+processes its own batch (weak scaling) and the step ends with one RCCL all-gather of the
+fixed-capacity keypoint/descriptor records (monoorbslam3_amd/dist.py).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
+dominant kernel (HIP-event timing on the launch stream) and `cpu_baseline` (the C oracle
+timed on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def level_bytes(ex, w, h):
+    sizes = [ex.level_size(w, h, l) for l in range(ex.n_levels)]
+    return [a * b for a, b in sizes]
+
+
+def algorithmic_bytes(ex, w, h, kp_per_frame):
+    """Per-frame compulsory HBM bytes of each stage."""
+    lb = level_bytes(ex, w, h)
+    P, L0, Llast = sum(lb), lb[0], lb[-1]
+    return {
+        "resize": (P - Llast) + (P - L0),
+        "fast": P,
+        "blur": 2 * P,
+        "octree": 0,
+        "orient_desc": min(kp_per_frame * 961, P) + min(kp_per_frame * 1369, P) + kp_per_frame * 60,
+    }, P
+
+
+def cpu_baseline(frames, n_features, threads):
+    """The C oracle (restatement of the reference's CPU extractor) on the host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import orb_ref_py
+    orb_ref_py.build()
+    orc = [orb_ref_py.Oracle(n_features, 1.2, 8, 20, 7) for _ in range(threads)]
+    orc[0].extract(frames[0])  # warm-up
+
+    def work(t):
+        n = 0
+        for i in range(t, len(frames), threads):
+            orc[t].extract(frames[i])
+            n += 1
+        return n
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as pool:  # ctypes releases the GIL during the C call
+        done = sum(pool.map(work, range(threads)))
+    dt = time.perf_counter() - t0
+    return done / dt, done, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="resident frames per GPU per step")
+    ap.add_argument("--width", type=int, default=1242)
+    ap.add_argument("--height", type=int, default=375)
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-match", action="store_true", help="time extraction only")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from monoorbslam3_amd import synth
+    from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
+    from monoorbslam3_amd.matcher import MatcherHandle, _mlib
+    from monoorbslam3_amd import _lib
+    from monoorbslam3_amd.dist import gather_records
+
+    W, H, B, NF = args.width, args.height, args.batch, args.features
+    # ---- synthetic resident batch: a few dozen distinct frames, replicated with per-copy noise
+    n_distinct = min(B, 32)
+    base = synth.make_frames(n_distinct, W, H, seed=synth.DEFAULT_SEED + 101 * rank)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    frames = torch.from_numpy(base).to(dev)
+    if B > n_distinct:
+        reps = (B + n_distinct - 1) // n_distinct
+        frames = frames.repeat(reps, 1, 1)[:B].contiguous()
+        noise = torch.randint(-2, 3, frames.shape, generator=g, dtype=torch.int16).to(dev)
+        noise[:n_distinct] = 0
+        frames = (frames.to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8).contiguous()
+    ex = ORBExtractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
+    cap = ex.max_keypoints(W, H)
+    d_kp = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    d_bidx = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    d_bd = torch.zeros((B, cap), dtype=torch.int16, device=dev)
+    d_sd = torch.zeros((B, cap), dtype=torch.int16, device=dev)
+    mh = MatcherHandle(device=local_rank)
+    ML = _mlib()
+    # a dedicated non-default stream: the C ABI treats a NULL stream as "the handle's own stream", and the
+    # RCCL gather below must be ordered behind the extraction kernels on the same stream
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    assert stream != 0
+
+    def match():
+        # frame f against frame f+1 (B-1 problems), and the last frame against frame 0
+        if B > 1:
+            _lib.check(ML.orbm_best2_device(mh._h, B - 1, d_desc.data_ptr(), cap, d_n.data_ptr(), cap,
+                                            d_desc.data_ptr() + cap * 32, cap, d_n.data_ptr() + 4, cap, None, None,
+                                            d_bidx.data_ptr(), d_bd.data_ptr(), d_sd.data_ptr(), stream))
+        _lib.check(ML.orbm_best2_device(mh._h, 1, d_desc.data_ptr() + (B - 1) * cap * 32, cap,
+                                        d_n.data_ptr() + 4 * (B - 1), cap, d_desc.data_ptr(), cap, d_n.data_ptr(), cap,
+                                        None, None, d_bidx.data_ptr() + 4 * (B - 1) * cap,
+                                        d_bd.data_ptr() + 2 * (B - 1) * cap, d_sd.data_ptr() + 2 * (B - 1) * cap,
+                                        stream))
+
+    def step():
+        ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, d_kp.data_ptr(), d_desc.data_ptr(), cap,
+                                d_n.data_ptr(), stream)
+        if not args.no_match:
+            match()
+        if world > 1:
+            gather_records(d_n, d_kp, d_desc)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fps = world * B * args.steps / dt
+
+    # ---- per-stage HIP-event timing on the launch stream (untimed extra steps)
+    ex.set_stage_timing(True)
+    acc = {}
+    n_prof = 5
+    ev_m0, ev_m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    match_ms = 0.0
+    for _ in range(n_prof):
+        ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, d_kp.data_ptr(), d_desc.data_ptr(), cap,
+                                d_n.data_ptr(), stream)
+        for k, v in ex.stage_times_ms().items():
+            acc[k] = acc.get(k, 0.0) + v / n_prof
+        ev_m0.record()
+        match()
+        ev_m1.record()
+        torch.cuda.synchronize()
+        match_ms += ev_m0.elapsed_time(ev_m1) / n_prof
+    ex.set_stage_timing(False)
+    counts = d_n.cpu().numpy()
+    kp_mean = float(counts.mean())
+    alg, P = algorithmic_bytes(ex, W, H, int(round(kp_mean)))
+    stage_gbs = {k: (alg[k] * B / (acc[k] * 1e-3) / 1e9 if acc[k] > 0 and alg[k] > 0 else None) for k in acc}
+    dominant = max(acc, key=lambda k: acc[k])
+    fb_ms = acc["fast"] + acc["orient_desc"]
+    fast_brief_gbs = 2 * P * B / (fb_ms * 1e-3) / 1e9
+    pairs = float((counts.astype(np.float64) * np.roll(counts, -1)).sum())
+
+    out = {
+        "metric": "ORB extract+match frames/s @1242x375, 2000 feat",
+        "value": round(fps, 2),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "KITTI 1242x375, 2000 feat, 8-level pyramid scale 1.2, FAST 20/7; extract + "
+                               "2000x2000 Hamming best-2 per frame" if (W, H, NF) == (1242, 375, 2000) else
+                               "%dx%d, %d feat" % (W, H, NF),
+                   "frames_per_gpu_per_step": B, "width": W, "height": H, "n_features": NF,
+                   "match": not args.no_match, "parallelism": "frames sharded 1 batch/GPU, all-gather of records"},
+        "keypoints_per_frame": round(kp_mean, 1),
+        "stages_ms": {k: round(v, 4) for k, v in acc.items()},
+        "match_ms": round(match_ms, 4),
+        "match_gpairs_per_s": round(pairs / (match_ms * 1e-3) / 1e9, 2) if match_ms > 0 else None,
+        "stage_algorithmic_GBps": {k: (round(v, 1) if v else None) for k, v in stage_gbs.items()},
+        "roofline": {
+            "kernel": dominant, "bound": "hbm",
+            "achieved": round(stage_gbs[dominant], 1) if stage_gbs[dominant] else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(stage_gbs[dominant] / HBM_PEAK_GBS, 4) if stage_gbs[dominant] else None,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg[dominant] * B,
+            "launch_ms": round(acc[dominant], 4),
+        },
+        "roofline_fast_plus_brief": {"bound": "hbm", "achieved": round(fast_brief_gbs, 1), "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": round(fast_brief_gbs / HBM_PEAK_GBS, 4),
+                                     "algorithmic_bytes_per_frame": 2 * P},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = min(16, os.cpu_count() or 1)
+        n_cpu = max(threads * 8, 64)
+        cf = base[np.arange(n_cpu) % n_distinct]
+        v, done, cdt = cpu_baseline(cf, NF, threads)
+        out["cpu_baseline"] = {"value": round(v, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+                               "sample": "%d frames of the same synthetic workload, extraction only, C oracle "
+                                         "(restatement of the reference's CPU ORBextractor, -O2), %.1f s wall" % (done, cdt)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+/*
+ * orbm.h -- C ABI of the MI355X ORB matcher cores (liborbx.so).
+ *
+ * Drop-in boundary for the reference's ORBMatcher
+ * (modules/ORB/ORBMatcher.h:12-52, modules/ORB/ORBMatcher.cpp).  The 256-bit
+ * Hamming brute force of every Search* routine runs as HIP kernels; the greedy,
+ * order-dependent resolution (which mutates Frame/KeyFrame/MapPoint objects in
+ * the reference) consumes the device-computed distances on the host so that the
+ * results are identical to the reference's sequential loops.
+ * The header-only shim monoorbslam3_amd/compat/ORBMatcher.h maps the
+ * reference's Frame/KeyFrame types onto these plain-array entry points.
+ *
+ * Returns 0 or a negative ORBX_E_* code (orbx.h); text in orbx_last_error().
+ * All entry points are re-entrant: a handle owns its stream and scratch, and the
+ * reference calls SearchForTriangulation from the LocalMapping thread while
+ * Tracking calls SearchByBow (LocalMapping.cpp:168, Tracking.cpp:262) -- use one
+ * handle per thread.
+ */
+#ifndef ORBM_H
+#define ORBM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBM_TH_LOW 50        /* modules/ORB/ORBMatcher.cpp:13 */
+#define ORBM_TH_HIGH 100      /* modules/ORB/ORBMatcher.cpp:14 */
+#define ORBM_HISTO_LENGTH 30  /* modules/ORB/ORBMatcher.cpp:15 */
+
+typedef struct orbm_ctx orbm_t;
+
+int orbm_create(int device, orbm_t **out);
+void orbm_destroy(orbm_t *h);
+
+/* DBoW2::FeatureVector (thirdParty/DBoW2/DBoW2/FeatureVector.h) flattened to CSR:
+ * node ids ascending, indices of a node in insertion (ascending feature) order. */
+typedef struct orbm_fv {
+    int32_t n_nodes;
+    const uint32_t *node_ids;
+    const int32_t *offsets; /* n_nodes + 1 */
+    const uint32_t *indices;
+} orbm_fv;
+
+/* ORBMatcher::DescriptorDistance (modules/ORB/ORBMatcher.cpp:17-31) for all pairs:
+ * out[i*nb + j] = popcount(a[i] ^ b[j]), 0..256.  Host pointers. */
+int orbm_hamming_matrix(orbm_t *h, const uint8_t *a, int na, const uint8_t *b, int nb, uint16_t *out);
+/* same with device pointers, enqueued on `stream` (hipStream_t, NULL = handle's stream) */
+int orbm_hamming_matrix_device(orbm_t *h, const uint8_t *d_a, int na, const uint8_t *d_b, int nb, uint16_t *d_out,
+                               void *stream);
+
+/* Best / second-best of every query row among the candidate rows, the inner loop of
+ * SearchByBow (ORBMatcher.cpp:148-162): strict '<' updates in ascending candidate order,
+ * both distances start at 256, best index -1 when no candidate.  row_ok / col_ok
+ * (may be NULL) are byte masks: skipped queries return (-1,256,256); masked candidates
+ * are not considered.  `n_pairs` independent (A,B) problems are processed in one launch:
+ * problem p uses a + p*a_stride ... (strides in descriptors/elements).  Device pointers. */
+int orbm_best2_device(orbm_t *h, int n_pairs, const uint8_t *d_a, size_t a_stride, const int32_t *d_na, int na_max,
+                      const uint8_t *d_b, size_t b_stride, const int32_t *d_nb, int nb_max,
+                      const uint8_t *d_row_ok, const uint8_t *d_col_ok, int32_t *d_best_idx, uint16_t *d_best,
+                      uint16_t *d_second, void *stream);
+/* host-pointer convenience wrapper for one problem */
+int orbm_best2(orbm_t *h, const uint8_t *a, int na, const uint8_t *b, int nb, const uint8_t *row_ok,
+               const uint8_t *col_ok, int32_t *best_idx, uint16_t *best, uint16_t *second);
+
+/* Distances for explicit candidate lists (CSR): for query q (descriptor a[q_idx[q]]) and
+ * t in [off[q], off[q+1]): out[t] = hamming(a[q_idx[q]], b[c_idx[t]]).  Host pointers.
+ * This is the device primitive under every window / BoW-node search. */
+int orbm_hamming_csr(orbm_t *h, const uint8_t *a, int na, const uint8_t *b, int nb, const int32_t *q_idx,
+                     const int32_t *off, int n_queries, const int32_t *c_idx, uint16_t *out);
+
+/* ORBMatcher::SearchByBow(keyFrame, frame) (modules/ORB/ORBMatcher.cpp:118-201).
+ * kf_mp_ok[i] != 0 <=> keyFrame->getMapPoints()[i] is non-null and not bad (:143).
+ * frame_mp[j] (in/out): -1 where frame->map_points[j] is null; on return matched
+ * entries hold the key-frame feature index whose MapPoint the reference would assign (:165).
+ * Returns the match count through n_matches. */
+int orbm_search_by_bow(orbm_t *h, float nn_ratio, int check_orientation,
+                       const uint8_t *desc1, const float *angle1, const uint8_t *kf_mp_ok, int n1, const orbm_fv *fv1,
+                       const uint8_t *desc2, const float *angle2, int32_t *frame_mp, int n2, const orbm_fv *fv2,
+                       int *n_matches);
+
+/* ORBMatcher::SearchForTriangulation(kf1, kf2, matches12) (modules/ORB/ORBMatcher.cpp:417-522),
+ * including its `bestIdx2 > 0` acceptance rule (:484).  has_mp1/2[i] != 0 <=> hasMapPoint(i). */
+int orbm_search_for_triangulation(orbm_t *h, int check_orientation,
+                                  const uint8_t *desc1, const float *angle1, const uint8_t *has_mp1, int n1,
+                                  const orbm_fv *fv1,
+                                  const uint8_t *desc2, const float *angle2, const uint8_t *has_mp2, int n2,
+                                  const orbm_fv *fv2, int32_t *matches12, int *n_matches);
+
+/* ORBMatcher::SearchForInitialization(frame1, frame2, vecPreMatched, matches12, windowSize)
+ * (modules/ORB/ORBMatcher.cpp:33-116) with Frame::getFeaturesInArea (Frame.cpp:97-127) over
+ * plain arrays.  kps are orbx_kp-layout records (28 bytes).  prematched: n1 (x,y) pairs, in/out. */
+int orbm_search_for_initialization(orbm_t *h, float nn_ratio, int check_orientation,
+                                   const void *kps1, const uint8_t *desc1, int n1,
+                                   const void *kps2, const uint8_t *desc2, int n2,
+                                   int img_w, int img_h, float *prematched_xy, int32_t *matches12,
+                                   int window_size, int *n_matches);
+
+/* ORBMatcher::ComputeThreeMaxima (modules/ORB/ORBMatcher.cpp:594-622) on bin sizes */
+void orbm_three_maxima(const int32_t *hist_sizes, int n_bins, int *ind1, int *ind2, int *ind3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,590 @@
+// Matcher cores for gfx950: 256-bit Hamming brute force as HIP kernels (xor + 64-bit popcount,
+// wave64 reductions), plus the host-side greedy passes that turn device-computed distances into
+// exactly the matches of the reference's sequential loops.
+//
+// Reference code replaced (paths relative to the reference root):
+//   DescriptorDistance                 modules/ORB/ORBMatcher.cpp:17-31
+//   SearchByBow inner loop + accept    modules/ORB/ORBMatcher.cpp:136-198
+//   SearchForTriangulation             modules/ORB/ORBMatcher.cpp:448-519
+//   SearchForInitialization            modules/ORB/ORBMatcher.cpp:33-116 (+ Frame.cpp:97-127 window query)
+//   ComputeThreeMaxima                 modules/ORB/ORBMatcher.cpp:594-622
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/orbm.h"
+#include "../../include/orbx.h"
+#include "orb_math.h"
+
+typedef unsigned long long u64;
+
+extern "C" const char *orbx_last_error(void);
+// error text is shared with the extractor (orbx_api.hip owns the thread-local string)
+int orbx_set_error(int code, const std::string &msg);
+#define M_TRY(expr)                                                                                    \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return orbx_set_error(ORBX_E_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+struct Desc256 { u64 w[4]; };
+
+__device__ __forceinline__ Desc256 load_desc(const uint8_t *p)
+{
+    const uint4 lo = *reinterpret_cast<const uint4 *>(p), hi = *reinterpret_cast<const uint4 *>(p + 16);
+    Desc256 d;
+    d.w[0] = (u64)lo.x | ((u64)lo.y << 32); d.w[1] = (u64)lo.z | ((u64)lo.w << 32);
+    d.w[2] = (u64)hi.x | ((u64)hi.y << 32); d.w[3] = (u64)hi.z | ((u64)hi.w << 32);
+    return d;
+}
+__device__ __forceinline__ int ham256(const Desc256 &a, const Desc256 &b)
+{
+    return __popcll(a.w[0] ^ b.w[0]) + __popcll(a.w[1] ^ b.w[1]) + __popcll(a.w[2] ^ b.w[2]) + __popcll(a.w[3] ^ b.w[3]);
+}
+
+// dense na x nb distance matrix; 64x64 tile per 256-thread workgroup, B tile staged in LDS
+__global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t *__restrict__ a, int na,
+                                                        const uint8_t *__restrict__ b, int nb,
+                                                        uint16_t *__restrict__ out)
+{
+    __shared__ u64 sb[64 * 4];
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    {
+        const int col = tid >> 2, part = tid & 3; // 8 bytes each
+        u64 v = 0;
+        if (j0 + col < nb) v = *reinterpret_cast<const u64 *>(b + (size_t)(j0 + col) * 32 + part * 8);
+        sb[col * 4 + part] = v;
+    }
+    __syncthreads();
+    const int r = i0 + (tid >> 2), g = tid & 3;
+    if (r >= na) return;
+    const Desc256 da = load_desc(a + (size_t)r * 32);
+    uint16_t *o = out + (size_t)r * nb + j0 + g * 16;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int col = g * 16 + c;
+        if (j0 + col < nb) {
+            const u64 *pb = &sb[col * 4];
+            o[c] = (uint16_t)(__popcll(da.w[0] ^ pb[0]) + __popcll(da.w[1] ^ pb[1]) + __popcll(da.w[2] ^ pb[2]) +
+                              __popcll(da.w[3] ^ pb[3]));
+        }
+    }
+}
+
+// best / second-best per query row, one wave per row.  Partial results merge exactly like the
+// sequential strict-'<' scan: best = smallest (distance, index), second = 2nd smallest distance.
+__global__ __launch_bounds__(256) void k_best2(const uint8_t *__restrict__ a, size_t a_stride,
+                                               const int32_t *__restrict__ na_p, int na_max,
+                                               const uint8_t *__restrict__ b, size_t b_stride,
+                                               const int32_t *__restrict__ nb_p, int nb_max,
+                                               const uint8_t *__restrict__ row_ok, const uint8_t *__restrict__ col_ok,
+                                               int32_t *__restrict__ best_idx, uint16_t *__restrict__ best,
+                                               uint16_t *__restrict__ second)
+{
+    const int p = blockIdx.y;
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int na = na_p ? min(na_p[p], na_max) : na_max, nb = nb_p ? min(nb_p[p], nb_max) : nb_max;
+    if (i >= na_max) return;
+    const size_t orow = (size_t)p * a_stride + i;
+    if (i >= na || (row_ok && !row_ok[orow])) {
+        if (lane == 0) { best_idx[orow] = -1; best[orow] = 256; second[orow] = 256; }
+        return;
+    }
+    const Desc256 da = load_desc(a + orow * 32);
+    const uint8_t *B = b + (size_t)p * b_stride * 32;
+    const uint8_t *ok = col_ok ? col_ok + (size_t)p * b_stride : nullptr;
+    uint32_t k1 = (256u << 23) | 0x7FFFFFu; // (distance << 23) | index
+    uint32_t s2 = 256;
+    for (int j = lane; j < nb; j += 64) {
+        if (ok && !ok[j]) continue;
+        const uint32_t d = (uint32_t)ham256(da, load_desc(B + (size_t)j * 32));
+        const uint32_t k = (d << 23) | (uint32_t)j;
+        if (k < k1) { s2 = min(s2, k1 >> 23); k1 = k; }
+        else s2 = min(s2, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t ok1 = __shfl_xor(k1, o), os2 = __shfl_xor(s2, o);
+        const uint32_t lo = min(k1, ok1), hi = max(k1, ok1);
+        s2 = min(min(s2, os2), hi >> 23);
+        k1 = lo;
+    }
+    if (lane == 0) {
+        const uint32_t d1 = k1 >> 23;
+        best_idx[orow] = d1 < 256 ? (int32_t)(k1 & 0x7FFFFFu) : -1; // a 256-distance candidate never beats the initial 256
+        best[orow] = (uint16_t)min(d1, 256u);
+        second[orow] = (uint16_t)min(s2, 256u);
+    }
+}
+
+// distances for explicit candidate lists; one wave per query
+__global__ __launch_bounds__(256) void k_hamming_lists(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                                                       const int32_t *__restrict__ q_idx,
+                                                       const int32_t *__restrict__ c_begin,
+                                                       const int32_t *__restrict__ c_len,
+                                                       const int32_t *__restrict__ out_begin, int n_queries,
+                                                       const int32_t *__restrict__ c_idx, uint16_t *__restrict__ out)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= n_queries) return;
+    const Desc256 da = load_desc(a + (size_t)q_idx[q] * 32);
+    const int cb = c_begin[q], n = c_len[q], ob = out_begin[q];
+    for (int t = lane; t < n; t += 64) out[ob + t] = (uint16_t)ham256(da, load_desc(b + (size_t)c_idx[cb + t] * 32));
+}
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = std::max(bytes, (size_t)4096);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct orbm_ctx {
+    int device;
+    hipStream_t stream;
+    DevBuf a, b, out, q_idx, c_begin, c_len, out_begin, c_idx, row_ok, col_ok, bidx, bbest, bsecond;
+};
+
+extern "C" int orbm_create(int device, orbm_t **out)
+{
+    if (!out) return orbx_set_error(ORBX_E_ARG, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return orbx_set_error(ORBX_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= ndev) return orbx_set_error(ORBX_E_ARG, "device ordinal out of range");
+    orbm_ctx *c = new orbm_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return orbx_set_error(ORBX_E_NO_DEVICE, "stream creation failed");
+    }
+    *out = c;
+    return ORBX_OK;
+}
+
+extern "C" void orbm_destroy(orbm_t *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->a, &c->b, &c->out, &c->q_idx, &c->c_begin, &c->c_len, &c->out_begin, &c->c_idx,
+                      &c->row_ok, &c->col_ok, &c->bidx, &c->bbest, &c->bsecond};
+    for (DevBuf *d : bufs) d->release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int orbm_hamming_matrix_device(orbm_t *c, const uint8_t *d_a, int na, const uint8_t *d_b, int nb,
+                                          uint16_t *d_out, void *stream)
+{
+    if (!c || !d_a || !d_b || !d_out || na < 0 || nb < 0) return orbx_set_error(ORBX_E_ARG, "bad argument");
+    if (na == 0 || nb == 0) return ORBX_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    dim3 grid((nb + 63) / 64, (na + 63) / 64);
+    hipLaunchKernelGGL(k_hamming_matrix, grid, dim3(256), 0, s, d_a, na, d_b, nb, d_out);
+    M_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+
+extern "C" int orbm_hamming_matrix(orbm_t *c, const uint8_t *a, int na, const uint8_t *b, int nb, uint16_t *out)
+{
+    if (!c || !a || !b || !out || na < 0 || nb < 0) return orbx_set_error(ORBX_E_ARG, "bad argument");
+    if (na == 0 || nb == 0) return ORBX_OK;
+    M_TRY(hipSetDevice(c->device));
+    M_TRY(c->a.need((size_t)na * 32));
+    M_TRY(c->b.need((size_t)nb * 32));
+    M_TRY(c->out.need((size_t)na * nb * 2));
+    M_TRY(hipMemcpyAsync(c->a.p, a, (size_t)na * 32, hipMemcpyHostToDevice, c->stream));
+    M_TRY(hipMemcpyAsync(c->b.p, b, (size_t)nb * 32, hipMemcpyHostToDevice, c->stream));
+    int rc = orbm_hamming_matrix_device(c, (const uint8_t *)c->a.p, na, (const uint8_t *)c->b.p, nb, (uint16_t *)c->out.p,
+                                        nullptr);
+    if (rc) return rc;
+    M_TRY(hipMemcpyAsync(out, c->out.p, (size_t)na * nb * 2, hipMemcpyDeviceToHost, c->stream));
+    M_TRY(hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbm_best2_device(orbm_t *c, int n_pairs, const uint8_t *d_a, size_t a_stride, const int32_t *d_na,
+                                 int na_max, const uint8_t *d_b, size_t b_stride, const int32_t *d_nb, int nb_max,
+                                 const uint8_t *d_row_ok, const uint8_t *d_col_ok, int32_t *d_best_idx, uint16_t *d_best,
+                                 uint16_t *d_second, void *stream)
+{
+    if (!c || !d_a || !d_b || !d_best_idx || !d_best || !d_second || n_pairs < 1 || na_max < 0 || nb_max < 0)
+        return orbx_set_error(ORBX_E_ARG, "bad argument");
+    if (nb_max >= (1 << 23)) return orbx_set_error(ORBX_E_UNSUPPORTED, "more than 2^23 candidates per problem");
+    if (na_max == 0) return ORBX_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    dim3 grid((na_max + 3) / 4, n_pairs);
+    hipLaunchKernelGGL(k_best2, grid, dim3(256), 0, s, d_a, a_stride, d_na, na_max, d_b, b_stride, d_nb, nb_max,
+                       d_row_ok, d_col_ok, d_best_idx, d_best, d_second);
+    M_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+
+extern "C" int orbm_best2(orbm_t *c, const uint8_t *a, int na, const uint8_t *b, int nb, const uint8_t *row_ok,
+                          const uint8_t *col_ok, int32_t *best_idx, uint16_t *best, uint16_t *second)
+{
+    if (!c || !a || !best_idx || !best || !second || na < 0 || nb < 0 || (nb > 0 && !b))
+        return orbx_set_error(ORBX_E_ARG, "bad argument");
+    if (na == 0) return ORBX_OK;
+    M_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    M_TRY(c->a.need((size_t)na * 32));
+    M_TRY(c->b.need((size_t)std::max(nb, 1) * 32));
+    M_TRY(c->bidx.need((size_t)na * 4));
+    M_TRY(c->bbest.need((size_t)na * 2));
+    M_TRY(c->bsecond.need((size_t)na * 2));
+    M_TRY(hipMemcpyAsync(c->a.p, a, (size_t)na * 32, hipMemcpyHostToDevice, s));
+    if (nb) M_TRY(hipMemcpyAsync(c->b.p, b, (size_t)nb * 32, hipMemcpyHostToDevice, s));
+    const uint8_t *d_row = nullptr, *d_col = nullptr;
+    if (row_ok) { M_TRY(c->row_ok.need(na)); M_TRY(hipMemcpyAsync(c->row_ok.p, row_ok, na, hipMemcpyHostToDevice, s)); d_row = (const uint8_t *)c->row_ok.p; }
+    if (col_ok && nb) { M_TRY(c->col_ok.need(nb)); M_TRY(hipMemcpyAsync(c->col_ok.p, col_ok, nb, hipMemcpyHostToDevice, s)); d_col = (const uint8_t *)c->col_ok.p; }
+    int rc = orbm_best2_device(c, 1, (const uint8_t *)c->a.p, na, nullptr, na, (const uint8_t *)c->b.p, std::max(nb, 1),
+                               nullptr, nb, d_row, d_col, (int32_t *)c->bidx.p, (uint16_t *)c->bbest.p,
+                               (uint16_t *)c->bsecond.p, nullptr);
+    if (rc) return rc;
+    M_TRY(hipMemcpyAsync(best_idx, c->bidx.p, (size_t)na * 4, hipMemcpyDeviceToHost, s));
+    M_TRY(hipMemcpyAsync(best, c->bbest.p, (size_t)na * 2, hipMemcpyDeviceToHost, s));
+    M_TRY(hipMemcpyAsync(second, c->bsecond.p, (size_t)na * 2, hipMemcpyDeviceToHost, s));
+    M_TRY(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+// distances for per-query candidate lists; the lists may alias each other (queries of one BoW
+// node share the node's candidate list), outputs are disjoint
+static int hamming_lists(orbm_ctx *c, const uint8_t *a, int na, const uint8_t *b, int nb,
+                         const std::vector<int32_t> &q_idx, const std::vector<int32_t> &c_begin,
+                         const std::vector<int32_t> &c_len, const std::vector<int32_t> &out_begin,
+                         const int32_t *c_idx, size_t n_cidx, size_t n_out, std::vector<uint16_t> &out)
+{
+    out.resize(n_out);
+    const int nq = (int)q_idx.size();
+    if (nq == 0 || n_out == 0) return ORBX_OK;
+    M_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    M_TRY(c->a.need((size_t)na * 32));
+    M_TRY(c->b.need((size_t)nb * 32));
+    M_TRY(c->q_idx.need((size_t)nq * 4));
+    M_TRY(c->c_begin.need((size_t)nq * 4));
+    M_TRY(c->c_len.need((size_t)nq * 4));
+    M_TRY(c->out_begin.need((size_t)nq * 4));
+    M_TRY(c->c_idx.need(n_cidx * 4));
+    M_TRY(c->out.need(n_out * 2));
+    M_TRY(hipMemcpyAsync(c->a.p, a, (size_t)na * 32, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->b.p, b, (size_t)nb * 32, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->q_idx.p, q_idx.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->c_begin.p, c_begin.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->c_len.p, c_len.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->out_begin.p, out_begin.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->c_idx.p, c_idx, n_cidx * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_hamming_lists, dim3((nq + 3) / 4), dim3(256), 0, s, (const uint8_t *)c->a.p,
+                       (const uint8_t *)c->b.p, (const int32_t *)c->q_idx.p, (const int32_t *)c->c_begin.p,
+                       (const int32_t *)c->c_len.p, (const int32_t *)c->out_begin.p, nq, (const int32_t *)c->c_idx.p,
+                       (uint16_t *)c->out.p);
+    M_TRY(hipGetLastError());
+    M_TRY(hipMemcpyAsync(out.data(), c->out.p, n_out * 2, hipMemcpyDeviceToHost, s));
+    M_TRY(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+extern "C" int orbm_hamming_csr(orbm_t *c, const uint8_t *a, int na, const uint8_t *b, int nb, const int32_t *q_idx,
+                                const int32_t *off, int n_queries, const int32_t *c_idx, uint16_t *out)
+{
+    if (!c || !a || !b || !q_idx || !off || !out || n_queries < 0) return orbx_set_error(ORBX_E_ARG, "bad argument");
+    if (n_queries == 0) return ORBX_OK;
+    std::vector<int32_t> q(q_idx, q_idx + n_queries), cb(off, off + n_queries), cl(n_queries);
+    for (int i = 0; i < n_queries; ++i) cl[i] = off[i + 1] - off[i];
+    std::vector<uint16_t> tmp;
+    const size_t n_out = (size_t)off[n_queries];
+    if (n_out && !c_idx) return orbx_set_error(ORBX_E_ARG, "null candidate list");
+    int rc = hamming_lists(c, a, na, b, nb, q, cb, cl, cb, c_idx, n_out, n_out, tmp);
+    if (rc) return rc;
+    if (n_out) memcpy(out, tmp.data(), n_out * 2);
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side greedy passes over device-computed distances
+// ---------------------------------------------------------------------------------------------
+extern "C" void orbm_three_maxima(const int32_t *h, int n_bins, int *ind1, int *ind2, int *ind3)
+{
+    // ORBMatcher.cpp:594-622 (callers initialise the three indices to -1)
+    int max1 = 0, max2 = -1, max3 = -2;
+    for (int i = 0; i < n_bins; ++i) {
+        const int n = h[i];
+        if (n > max1) { max3 = max2; max2 = max1; max1 = n; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (n > max2) { max3 = max2; max2 = n; *ind3 = *ind2; *ind2 = i; }
+        else if (n > max3) { max3 = n; *ind3 = i; }
+    }
+    if (max2 < max1 / 10) { *ind2 = -1; *ind3 = -1; }
+    else if (max3 < max1 / 10) *ind3 = -1;
+}
+
+namespace {
+struct RotHist {
+    std::vector<int> bins[ORBM_HISTO_LENGTH];
+    void add(float a1, float a2, int v)
+    {
+        // `factor = 1.f / HISTO_LENGTH` as in the reference (:128), so only bins 0..12 fill up
+        const float factor = 1.f / ORBM_HISTO_LENGTH;
+        float rot = a1 - a2;
+        if (rot < 0) rot += 360.f;
+        int bin = orb_round_f(rot * factor);
+        if (bin == ORBM_HISTO_LENGTH) bin = 0;
+        bins[bin].push_back(v);
+    }
+    void keep3(int *i1, int *i2, int *i3) const
+    {
+        int32_t sizes[ORBM_HISTO_LENGTH];
+        for (int i = 0; i < ORBM_HISTO_LENGTH; ++i) sizes[i] = (int32_t)bins[i].size();
+        *i1 = *i2 = *i3 = -1;
+        orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, i1, i2, i3);
+    }
+};
+
+// merge-walk of two FeatureVectors (:136-185): pairs of positions with equal node id
+struct NodePair { int i1, i2; };
+void shared_nodes(const orbm_fv *f1, const orbm_fv *f2, std::vector<NodePair> &out)
+{
+    int i1 = 0, i2 = 0;
+    while (i1 < f1->n_nodes && i2 < f2->n_nodes) {
+        const uint32_t a = f1->node_ids[i1], b = f2->node_ids[i2];
+        if (a == b) { out.push_back({i1, i2}); ++i1; ++i2; }
+        else if (a < b) i1 = (int)(std::lower_bound(f1->node_ids + i1, f1->node_ids + f1->n_nodes, b) - f1->node_ids);
+        else i2 = (int)(std::lower_bound(f2->node_ids + i2, f2->node_ids + f2->n_nodes, a) - f2->node_ids);
+    }
+}
+
+// one query per (shared node, usable feature of side 1); candidates = the node's features on side 2
+struct NodeQueries {
+    std::vector<int32_t> q_idx, c_begin, c_len, out_begin;
+    size_t n_out = 0;
+};
+void build_node_queries(const orbm_fv *f1, const orbm_fv *f2, const std::vector<NodePair> &nodes,
+                        const uint8_t *skip1_if_zero, const uint8_t *skip1_if_nonzero, NodeQueries &q)
+{
+    for (const NodePair &np : nodes) {
+        const int cb = f2->offsets[np.i2], cl = f2->offsets[np.i2 + 1] - cb;
+        for (int a = f1->offsets[np.i1]; a < f1->offsets[np.i1 + 1]; ++a) {
+            const int idx1 = (int)f1->indices[a];
+            if (skip1_if_zero && !skip1_if_zero[idx1]) continue;
+            if (skip1_if_nonzero && skip1_if_nonzero[idx1]) continue;
+            q.q_idx.push_back(idx1); q.c_begin.push_back(cb); q.c_len.push_back(cl);
+            q.out_begin.push_back((int32_t)q.n_out);
+            q.n_out += (size_t)cl;
+        }
+    }
+}
+} // namespace
+
+extern "C" int orbm_search_by_bow(orbm_t *c, float nn_ratio, int check_orientation, const uint8_t *desc1,
+                                  const float *angle1, const uint8_t *kf_mp_ok, int n1, const orbm_fv *fv1,
+                                  const uint8_t *desc2, const float *angle2, int32_t *frame_mp, int n2,
+                                  const orbm_fv *fv2, int *n_matches)
+{
+    if (!c || !desc1 || !desc2 || !kf_mp_ok || !frame_mp || !fv1 || !fv2 || !n_matches || !angle1 || !angle2)
+        return orbx_set_error(ORBX_E_ARG, "null argument");
+    *n_matches = 0;
+    if (n1 <= 0 || n2 <= 0) return ORBX_OK;
+    std::vector<NodePair> nodes;
+    shared_nodes(fv1, fv2, nodes);
+    NodeQueries q;
+    build_node_queries(fv1, fv2, nodes, kf_mp_ok, nullptr, q);
+    std::vector<uint16_t> dist;
+    int rc = hamming_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.out_begin,
+                           reinterpret_cast<const int32_t *>(fv2->indices), (size_t)fv2->offsets[fv2->n_nodes], q.n_out,
+                           dist);
+    if (rc) return rc;
+    RotHist rh;
+    int num = 0;
+    for (size_t k = 0; k < q.q_idx.size(); ++k) {
+        const int idx1 = q.q_idx[k];
+        const uint32_t *cand = fv2->indices + q.c_begin[k];
+        const uint16_t *d = dist.data() + q.out_begin[k];
+        int bestDist = 256, secondDist = 256, bestIdx2 = -1;
+        for (int t = 0; t < q.c_len[k]; ++t) {
+            const int idx2 = (int)cand[t];
+            if (frame_mp[idx2] != -1) continue; // :150 -- includes features matched earlier in this call
+            const int dd = d[t];
+            if (dd < bestDist) { secondDist = bestDist; bestDist = dd; bestIdx2 = idx2; }
+            else if (dd < secondDist) secondDist = dd;
+        }
+        if (bestDist <= ORBM_TH_LOW && (float)bestDist < nn_ratio * (float)secondDist) { // :164
+            frame_mp[bestIdx2] = idx1;
+            ++num;
+            if (check_orientation) rh.add(angle1[idx1], angle2[bestIdx2], bestIdx2);
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        rh.keep3(&i1, &i2, &i3);
+        for (int i = 0; i < ORBM_HISTO_LENGTH; ++i) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int idx2 : rh.bins[i]) { frame_mp[idx2] = -1; --num; }
+        }
+    }
+    *n_matches = num;
+    return ORBX_OK;
+}
+
+extern "C" int orbm_search_for_triangulation(orbm_t *c, int check_orientation, const uint8_t *desc1,
+                                             const float *angle1, const uint8_t *has_mp1, int n1, const orbm_fv *fv1,
+                                             const uint8_t *desc2, const float *angle2, const uint8_t *has_mp2, int n2,
+                                             const orbm_fv *fv2, int32_t *matches12, int *n_matches)
+{
+    if (!c || !desc1 || !desc2 || !has_mp1 || !has_mp2 || !fv1 || !fv2 || !matches12 || !n_matches || !angle1 || !angle2)
+        return orbx_set_error(ORBX_E_ARG, "null argument");
+    *n_matches = 0;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    if (n1 <= 0 || n2 <= 0) return ORBX_OK;
+    std::vector<NodePair> nodes;
+    shared_nodes(fv1, fv2, nodes);
+    NodeQueries q;
+    build_node_queries(fv1, fv2, nodes, nullptr, has_mp1, q); // :452
+    std::vector<uint16_t> dist;
+    int rc = hamming_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.out_begin,
+                           reinterpret_cast<const int32_t *>(fv2->indices), (size_t)fv2->offsets[fv2->n_nodes], q.n_out,
+                           dist);
+    if (rc) return rc;
+    std::vector<uint8_t> matched2(n2, 0);
+    RotHist rh;
+    int num = 0;
+    for (size_t k = 0; k < q.q_idx.size(); ++k) {
+        const int idx1 = q.q_idx[k];
+        const uint32_t *cand = fv2->indices + q.c_begin[k];
+        const uint16_t *d = dist.data() + q.out_begin[k];
+        int bestDist = ORBM_TH_LOW, bestIdx2 = -1;
+        for (int t = 0; t < q.c_len[k]; ++t) {
+            const int idx2 = (int)cand[t];
+            if (matched2[idx2] || has_mp2[idx2]) continue; // :466
+            if (d[t] < bestDist) { bestIdx2 = idx2; bestDist = d[t]; }
+        }
+        if (bestIdx2 > 0) { // :484 -- feature 0 of key frame 2 is never accepted
+            matches12[idx1] = bestIdx2;
+            matched2[bestIdx2] = 1;
+            ++num;
+            if (check_orientation) rh.add(angle1[idx1], angle2[bestIdx2], idx1);
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        rh.keep3(&i1, &i2, &i3);
+        for (int i = 0; i < ORBM_HISTO_LENGTH; ++i) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int idx1 : rh.bins[i]) { matches12[idx1] = -1; --num; }
+        }
+    }
+    *n_matches = num;
+    return ORBX_OK;
+}
+
+extern "C" int orbm_search_for_initialization(orbm_t *c, float nn_ratio, int check_orientation, const void *kps1v,
+                                              const uint8_t *desc1, int n1, const void *kps2v, const uint8_t *desc2,
+                                              int n2, int img_w, int img_h, float *pre, int32_t *matches12,
+                                              int window_size, int *n_matches)
+{
+    if (!c || !kps1v || !kps2v || !desc1 || !desc2 || !pre || !matches12 || !n_matches)
+        return orbx_set_error(ORBX_E_ARG, "null argument");
+    const orbx_kp *kps1 = (const orbx_kp *)kps1v, *kps2 = (const orbx_kp *)kps2v;
+    *n_matches = 0;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    if (n1 <= 0 || n2 <= 0) return ORBX_OK;
+    // Frame grid of frame2 (Frame.cpp:33-51): 40-px cells, column-major vector of vectors
+    const int G = 40;
+    const int gcols = img_w % G == 0 ? img_w / G : img_w / G + 1, grows = img_h % G == 0 ? img_h / G : img_h / G + 1;
+    std::vector<std::vector<int>> grid((size_t)gcols * grows);
+    for (int i = 0; i < n2; ++i) {
+        const int x = orb_floor_f(kps2[i].x), y = orb_floor_f(kps2[i].y);
+        if (x < 0 || x >= img_w || y < 0 || y >= img_h) continue;
+        grid[(size_t)(x / G) * grows + y / G].push_back(i);
+    }
+    // window candidates per level-0 feature of frame1 (:46-54, Frame.cpp:97-127)
+    std::vector<int32_t> q_idx, c_begin, c_len, out_begin, c_idx;
+    const float r = (float)window_size;
+    for (int idx1 = 0; idx1 < n1; ++idx1) {
+        const int level1 = kps1[idx1].octave;
+        if (level1 > 0) continue;
+        const float x = pre[2 * idx1], y = pre[2 * idx1 + 1];
+        const int minCX = std::max(0, orb_floor_f(x - r) / G), maxCX = std::min(gcols - 1, orb_floor_f(x + r) / G);
+        if (minCX > maxCX) continue;
+        const int minCY = std::max(0, orb_floor_f(y - r) / G), maxCY = std::min(grows - 1, orb_floor_f(y + r) / G);
+        if (minCY > maxCY) continue;
+        const bool check = level1 > 0 || level1 >= 0; // beCheckLevel with minLevel = maxLevel = level1
+        const size_t begin = c_idx.size();
+        for (int cx = minCX; cx <= maxCX; ++cx)
+            for (int cy = minCY; cy <= maxCY; ++cy)
+                for (int j : grid[(size_t)cx * grows + cy]) {
+                    if (check) {
+                        if (kps2[j].octave < level1) continue;
+                        if (level1 >= 0 && kps2[j].octave > level1) continue;
+                    }
+                    if (fabsf(kps2[j].x - x) <= r && fabsf(kps2[j].y - y) <= r) c_idx.push_back(j);
+                }
+        if (c_idx.size() == begin) continue;
+        q_idx.push_back(idx1); c_begin.push_back((int32_t)begin); c_len.push_back((int32_t)(c_idx.size() - begin));
+        out_begin.push_back((int32_t)begin);
+    }
+    std::vector<uint16_t> dist;
+    int rc = hamming_lists(c, desc1, n1, desc2, n2, q_idx, c_begin, c_len, out_begin, c_idx.data(), c_idx.size(),
+                           c_idx.size(), dist);
+    if (rc) return rc;
+    std::vector<int> matches21(n2, -1), matchedDist(n2, INT_MAX);
+    RotHist rh;
+    int num = 0;
+    for (size_t k = 0; k < q_idx.size(); ++k) {
+        const int idx1 = q_idx[k];
+        int bestDist = INT_MAX - 1, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int t = 0; t < c_len[k]; ++t) {
+            const int idx2 = c_idx[c_begin[k] + t];
+            const int d = dist[out_begin[k] + t];
+            if (matchedDist[idx2] <= d) continue; // :63
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = idx2; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        if (bestDist <= ORBM_TH_LOW && bestDist < orb_round_f((float)bestDist2 * nn_ratio)) { // :74
+            if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; --num; }
+            matches12[idx1] = bestIdx2;
+            matches21[bestIdx2] = idx1;
+            matchedDist[bestIdx2] = bestDist;
+            ++num;
+            if (check_orientation) rh.add(kps1[idx1].angle, kps2[bestIdx2].angle, idx1);
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        rh.keep3(&i1, &i2, &i3);
+        for (int i = 0; i < ORBM_HISTO_LENGTH; ++i) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int idx1 : rh.bins[i])
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; --num; }
+        }
+    }
+    for (int idx1 = 0; idx1 < n1; ++idx1)
+        if (matches12[idx1] >= 0) { pre[2 * idx1] = kps2[matches12[idx1]].x; pre[2 * idx1 + 1] = kps2[matches12[idx1]].y; }
+    *n_matches = num;
+    return ORBX_OK;
+}

@@ -18,6 +18,8 @@
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+// shared with the matcher translation unit (orbm_matcher.hip)
+int orbx_set_error(int code, const std::string &msg) { return fail(code, msg); }
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \

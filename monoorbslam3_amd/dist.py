@@ -1,0 +1,75 @@
+"""Batch-of-frames mode: independent frames sharded across ranks, one gather of the results.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm,
+"gloo" on CPU for tests).  Frame i of a global batch goes to rank i % world
+(SURVEY.md section 8e).  Extraction has no cross-frame state, so the only
+communication is ONE all-gather per batch of fixed-capacity records
+(count:int32, keypoints cap x 28 B, descriptors cap x 32 B): ~120 KB per frame,
+latency-bound on the xGMI mesh, no reduction, no ring-sized tuning needed.
+The reference has no counterpart (single process, CPU).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+KP_BYTES = 28
+DESC_BYTES = 32
+
+
+def shard_indices(n_frames, rank, world):
+    """Global frame indices owned by `rank` (round-robin)."""
+    return list(range(rank, n_frames, world))
+
+
+def unshard_order(n_frames, world):
+    """Position of global frame i inside the rank-major gathered layout: (rank, local index)."""
+    return [(i % world, i // world) for i in range(n_frames)]
+
+
+def gather_records(counts, kps, desc, group=None):
+    """All-gather fixed-capacity per-frame records.
+
+    counts: int32 [b]; kps: uint8 [b, cap, 28]; desc: uint8 [b, cap, 32] (same b, cap on every rank).
+    Returns (counts [world, b], kps [world, b, cap, 28], desc [world, b, cap, 32]).
+    """
+    world = dist.get_world_size(group)
+    b, cap = kps.shape[0], kps.shape[1]
+    assert kps.dtype == torch.uint8 and desc.dtype == torch.uint8 and counts.dtype == torch.int32
+    # one fused payload per rank -> a single collective per batch
+    payload = torch.cat([counts.view(torch.uint8).reshape(-1), kps.reshape(-1), desc.reshape(-1)])
+    flat = torch.empty(world * payload.numel(), dtype=torch.uint8, device=payload.device)
+    dist.all_gather_into_tensor(flat, payload, group=group)
+    out = flat.view(world, payload.numel())
+    n0 = b * 4
+    n1 = n0 + b * cap * KP_BYTES
+    g_counts = out[:, :n0].contiguous().view(torch.int32).reshape(world, b)
+    g_kps = out[:, n0:n1].reshape(world, b, cap, KP_BYTES)
+    g_desc = out[:, n1:].reshape(world, b, cap, DESC_BYTES)
+    return g_counts, g_kps, g_desc
+
+
+def extract_sharded(frames, extract_fn, cap, group=None, device="cpu"):
+    """Shard a global batch, run `extract_fn` on the local frames, gather everything everywhere.
+
+    frames: uint8 array [n, h, w] (identical on every rank).
+    extract_fn(local_frames[b, h, w]) -> (counts int32 [b], kps uint8 [b, cap, 28], desc uint8 [b, cap, 32])
+    as torch tensors on `device`.  Returns per-global-frame lists (count, kps[count], desc[count]) as numpy.
+    """
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = len(frames)
+    per = (n + world - 1) // world
+    mine = shard_indices(n, rank, world)
+    local = np.zeros((per,) + tuple(frames.shape[1:]), dtype=np.uint8)
+    for k, i in enumerate(mine):
+        local[k] = frames[i]
+    counts, kps, desc = extract_fn(local)
+    if len(mine) < per:  # padding frames contribute nothing
+        counts = counts.clone()
+        counts[len(mine):] = 0
+    g_counts, g_kps, g_desc = gather_records(counts.to(device), kps.to(device), desc.to(device), group)
+    g_counts, g_kps, g_desc = g_counts.cpu().numpy(), g_kps.cpu().numpy(), g_desc.cpu().numpy()
+    out = []
+    for r, k in unshard_order(n, world):
+        c = int(g_counts[r, k])
+        out.append((c, g_kps[r, k, :c].copy(), g_desc[r, k, :c].copy()))
+    return out

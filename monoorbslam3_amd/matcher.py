@@ -1,0 +1,203 @@
+"""Python mirror of the reference's ORBMatcher over the C ABI (include/orbm.h).
+
+Same constructor as modules/ORB/ORBMatcher.h:14 (nnRatio, checkOrientation) and the
+Search* entry points of the north-star path, expressed over plain arrays instead of
+Frame / KeyFrame objects: a "frame" here is (descriptors[n,32], angles[n] or
+keypoints, FeatureVector CSR, map-point mask).  Distances are computed by the HIP
+kernels; the library's host code performs the reference's greedy resolution.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .extractor import KP_DTYPE
+
+TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
+
+
+class _Fv(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_ids", C.c_void_p), ("offsets", C.c_void_p), ("indices", C.c_void_p)]
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_sigs_done = False
+
+
+def _mlib():
+    global _sigs_done
+    L = _lib.lib()
+    if not _sigs_done:
+        vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+        sigs = {
+            "orbm_create": (i32, [i32, C.POINTER(vp)]),
+            "orbm_destroy": (None, [vp]),
+            "orbm_hamming_matrix": (i32, [vp, vp, i32, vp, i32, vp]),
+            "orbm_hamming_matrix_device": (i32, [vp, vp, i32, vp, i32, vp, vp]),
+            "orbm_best2_device": (i32, [vp, i32, vp, sz, vp, i32, vp, sz, vp, i32, vp, vp, vp, vp, vp, vp]),
+            "orbm_best2": (i32, [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
+            "orbm_hamming_csr": (i32, [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp]),
+            "orbm_search_by_bow": (i32, [vp, f32, i32, vp, vp, vp, i32, C.POINTER(_Fv), vp, vp, vp, i32,
+                                         C.POINTER(_Fv), C.POINTER(i32)]),
+            "orbm_search_for_triangulation": (i32, [vp, i32, vp, vp, vp, i32, C.POINTER(_Fv), vp, vp, vp, i32,
+                                                    C.POINTER(_Fv), vp, C.POINTER(i32)]),
+            "orbm_search_for_initialization": (i32, [vp, f32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32,
+                                                     C.POINTER(i32)]),
+            "orbm_three_maxima": (None, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        }
+        for name, (res, args) in sigs.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _sigs_done = True
+    return L
+
+
+def _fv(csr):
+    node_ids, offsets, indices = csr
+    node_ids = np.ascontiguousarray(node_ids, dtype=np.uint32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    f = _Fv(len(node_ids), node_ids.ctypes.data, offsets.ctypes.data, indices.ctypes.data)
+    f._keep = (node_ids, offsets, indices)
+    return f
+
+
+_default = None
+
+
+def _handle():
+    global _default
+    if _default is None:
+        _default = MatcherHandle()
+    return _default
+
+
+class MatcherHandle:
+    """One orbm_t: a HIP stream plus scratch.  Use one per host thread."""
+
+    def __init__(self, device=-1):
+        self._L = _mlib()
+        self._h = C.c_void_p()
+        _lib.check(self._L.orbm_create(device, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.orbm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ORBMatcher:
+    """ORBMatcher(nnRatio=0.6, checkOrientation=True) (reference modules/ORB/ORBMatcher.h:14)."""
+
+    def __init__(self, nnRatio=0.6, checkOrientation=True, handle=None):
+        self.nn_ratio = float(nnRatio)
+        self.be_check_orientation = bool(checkOrientation)
+        self._hd = handle or _handle()
+        self._L = self._hd._L
+
+    # -- DescriptorDistance (ORBMatcher.cpp:17-31) --------------------------------
+    @staticmethod
+    def DescriptorDistance(a, b):
+        return int(ORBMatcher.hamming_matrix(np.asarray(a, np.uint8).reshape(1, 32),
+                                             np.asarray(b, np.uint8).reshape(1, 32))[0, 0])
+
+    @staticmethod
+    def hamming_matrix(a, b, handle=None):
+        hd = handle or _handle()
+        a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 32)
+        out = np.zeros((len(a), len(b)), np.uint16)
+        _lib.check(hd._L.orbm_hamming_matrix(hd._h, _vp(a), len(a), _vp(b), len(b), _vp(out)))
+        return out
+
+    @staticmethod
+    def best2(a, b, row_ok=None, col_ok=None, handle=None):
+        """(best index, best distance, second distance) per row of `a` among rows of `b`."""
+        hd = handle or _handle()
+        a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 32)
+        bi = np.zeros(len(a), np.int32)
+        bd = np.zeros(len(a), np.uint16)
+        sd = np.zeros(len(a), np.uint16)
+        ro = None if row_ok is None else np.ascontiguousarray(row_ok, dtype=np.uint8)
+        co = None if col_ok is None else np.ascontiguousarray(col_ok, dtype=np.uint8)
+        _lib.check(hd._L.orbm_best2(hd._h, _vp(a), len(a), _vp(b), len(b), None if ro is None else _vp(ro),
+                                    None if co is None else _vp(co), _vp(bi), _vp(bd), _vp(sd)))
+        return bi, bd, sd
+
+    @staticmethod
+    def hamming_csr(a, b, q_idx, off, c_idx, handle=None):
+        hd = handle or _handle()
+        a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 32)
+        q_idx = np.ascontiguousarray(q_idx, dtype=np.int32)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        c_idx = np.ascontiguousarray(c_idx, dtype=np.int32)
+        out = np.zeros(int(off[-1]) if len(off) else 0, np.uint16)
+        _lib.check(hd._L.orbm_hamming_csr(hd._h, _vp(a), len(a), _vp(b), len(b), _vp(q_idx), _vp(off), len(q_idx),
+                                          _vp(c_idx), _vp(out)))
+        return out
+
+    @staticmethod
+    def ComputeThreeMaxima(hist_sizes):
+        L = _mlib()
+        s = np.ascontiguousarray(hist_sizes, dtype=np.int32)
+        i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        L.orbm_three_maxima(_vp(s), len(s), C.byref(i1), C.byref(i2), C.byref(i3))
+        return i1.value, i2.value, i3.value
+
+    # -- SearchByBow (ORBMatcher.cpp:118-201) --------------------------------------
+    def SearchByBow(self, kf_desc, kf_angles, kf_mp_ok, kf_fv, fr_desc, fr_angles, frame_mp, fr_fv):
+        """Returns (numMatch, frame_mp'): frame_mp'[j] = key-frame feature whose MapPoint is assigned, -1 = null."""
+        d1 = np.ascontiguousarray(kf_desc, dtype=np.uint8)
+        d2 = np.ascontiguousarray(fr_desc, dtype=np.uint8)
+        a1 = np.ascontiguousarray(kf_angles, dtype=np.float32)
+        a2 = np.ascontiguousarray(fr_angles, dtype=np.float32)
+        ok = np.ascontiguousarray(kf_mp_ok, dtype=np.uint8)
+        mp = np.ascontiguousarray(frame_mp, dtype=np.int32).copy()
+        f1, f2 = _fv(kf_fv), _fv(fr_fv)
+        n = C.c_int()
+        _lib.check(self._L.orbm_search_by_bow(self._hd._h, self.nn_ratio, int(self.be_check_orientation), _vp(d1),
+                                              _vp(a1), _vp(ok), len(d1), C.byref(f1), _vp(d2), _vp(a2), _vp(mp),
+                                              len(d2), C.byref(f2), C.byref(n)))
+        return n.value, mp
+
+    # -- SearchForTriangulation (ORBMatcher.cpp:417-522) -----------------------------
+    def SearchForTriangulation(self, desc1, angles1, has_mp1, fv1, desc2, angles2, has_mp2, fv2):
+        d1 = np.ascontiguousarray(desc1, dtype=np.uint8)
+        d2 = np.ascontiguousarray(desc2, dtype=np.uint8)
+        a1 = np.ascontiguousarray(angles1, dtype=np.float32)
+        a2 = np.ascontiguousarray(angles2, dtype=np.float32)
+        h1 = np.ascontiguousarray(has_mp1, dtype=np.uint8)
+        h2 = np.ascontiguousarray(has_mp2, dtype=np.uint8)
+        m12 = np.full(len(d1), -1, np.int32)
+        f1, f2 = _fv(fv1), _fv(fv2)
+        n = C.c_int()
+        _lib.check(self._L.orbm_search_for_triangulation(self._hd._h, int(self.be_check_orientation), _vp(d1), _vp(a1),
+                                                         _vp(h1), len(d1), C.byref(f1), _vp(d2), _vp(a2), _vp(h2),
+                                                         len(d2), C.byref(f2), _vp(m12), C.byref(n)))
+        return n.value, m12
+
+    # -- SearchForInitialization (ORBMatcher.cpp:33-116) -----------------------------
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, img_w, img_h, vecPreMatched, windowSize=100):
+        k1 = np.ascontiguousarray(kps1, dtype=KP_DTYPE)
+        k2 = np.ascontiguousarray(kps2, dtype=KP_DTYPE)
+        d1 = np.ascontiguousarray(desc1, dtype=np.uint8)
+        d2 = np.ascontiguousarray(desc2, dtype=np.uint8)
+        pre = np.ascontiguousarray(vecPreMatched, dtype=np.float32).copy()
+        m12 = np.full(len(k1), -1, np.int32)
+        n = C.c_int()
+        _lib.check(self._L.orbm_search_for_initialization(self._hd._h, self.nn_ratio, int(self.be_check_orientation),
+                                                          _vp(k1), _vp(d1), len(k1), _vp(k2), _vp(d2), len(k2), img_w,
+                                                          img_h, _vp(pre), _vp(m12), windowSize, C.byref(n)))
+        return n.value, m12, pre

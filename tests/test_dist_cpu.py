@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: world_size-2 gloo, frames sharded round-robin, one all-gather of padded records."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from monoorbslam3_amd import dist as D
+
+CAP = 16
+
+
+def _fake_extract(frames):
+    """deterministic stand-in for the GPU extractor: records derived from the frame bytes"""
+    b = len(frames)
+    counts = torch.zeros(b, dtype=torch.int32)
+    kps = torch.zeros((b, CAP, 28), dtype=torch.uint8)
+    desc = torch.zeros((b, CAP, 32), dtype=torch.uint8)
+    for i, f in enumerate(frames):
+        n = int(f[0, 0]) % CAP
+        counts[i] = n
+        for k in range(n):
+            kps[i, k] = torch.from_numpy(np.full(28, (int(f[0, 1]) + k) % 256, np.uint8))
+            desc[i, k] = torch.from_numpy(np.full(32, (int(f[1, 0]) * 3 + k) % 256, np.uint8))
+    return counts, kps, desc
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.RandomState(0)
+    frames = rng.randint(0, 256, (n_frames, 4, 6)).astype(np.uint8)
+    res = D.extract_sharded(frames, _fake_extract, CAP)
+    q.put((rank, [(c, k.tobytes(), d.tobytes()) for c, k, d in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n_frames", [8, 5])
+def test_sharded_extract_world2(n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.RandomState(0)
+    frames = rng.randint(0, 256, (n_frames, 4, 6)).astype(np.uint8)
+    counts, kps, desc = _fake_extract(frames)
+    ref = [(int(counts[i]), kps[i, :counts[i]].numpy().tobytes(), desc[i, :counts[i]].numpy().tobytes())
+           for i in range(n_frames)]
+    assert got[0] == ref and got[1] == ref  # every rank ends with every frame's records, in global order
+
+
+def test_shard_indices():
+    assert D.shard_indices(10, 1, 4) == [1, 5, 9]
+    assert D.unshard_order(5, 2) == [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2)]

@@ -1,0 +1,144 @@
+"""GPU parity of the matcher cores against the CPU oracle, through the C ABI (bit-exact integers)."""
+import numpy as np
+import pytest
+
+from monoorbslam3_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _popcount_ref(a, b):
+    return np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(axis=2).astype(np.uint16)
+
+
+def test_descriptor_distance_kats():
+    from monoorbslam3_amd.matcher import ORBMatcher
+    x = np.arange(32, dtype=np.uint8)
+    assert ORBMatcher.DescriptorDistance(x, x) == 0
+    assert ORBMatcher.DescriptorDistance(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+    y = x.copy()
+    y[5] ^= 0b10110000
+    assert ORBMatcher.DescriptorDistance(x, y) == 3
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (63, 65), (500, 777), (2000, 2000)])
+def test_hamming_matrix(na, nb):
+    from monoorbslam3_amd.matcher import ORBMatcher
+    rng = np.random.RandomState(na * 7 + nb)
+    a = rng.randint(0, 256, (na, 32)).astype(np.uint8)
+    b = rng.randint(0, 256, (nb, 32)).astype(np.uint8)
+    d = ORBMatcher.hamming_matrix(a, b)
+    assert np.array_equal(d, _popcount_ref(a, b))
+
+
+def _best2_ref(d, row_ok, col_ok):
+    na, nb = d.shape
+    bi = np.full(na, -1, np.int32)
+    bd = np.full(na, 256, np.uint16)
+    sd = np.full(na, 256, np.uint16)
+    for i in range(na):
+        if row_ok is not None and not row_ok[i]:
+            continue
+        best, second, idx = 256, 256, -1
+        for j in range(nb):
+            if col_ok is not None and not col_ok[j]:
+                continue
+            v = int(d[i, j])
+            if v < best:
+                second, best, idx = best, v, j
+            elif v < second:
+                second = v
+        bi[i], bd[i], sd[i] = idx, best, second
+    return bi, bd, sd
+
+
+def test_best2_masked_and_ties():
+    from monoorbslam3_amd.matcher import ORBMatcher
+    a, b, _ = synth.make_descriptor_pair(300, seed=3)
+    b[17] = b[5]            # exact duplicate candidate: first index must win
+    b[40] = a[40] ^ 255     # a 256-distance candidate
+    rng = np.random.RandomState(1)
+    row_ok = (rng.uniform(size=300) > 0.2).astype(np.uint8)
+    col_ok = (rng.uniform(size=300) > 0.3).astype(np.uint8)
+    d = _popcount_ref(a, b)
+    for ro, co in ((None, None), (row_ok, col_ok)):
+        got = ORBMatcher.best2(a, b, ro, co)
+        ref = _best2_ref(d, ro, co)
+        for g, r in zip(got, ref):
+            assert np.array_equal(g, r)
+    # no candidates at all
+    bi, bd, sd = ORBMatcher.best2(a[:5], b[:0])
+    assert bi.tolist() == [-1] * 5 and bd.tolist() == [256] * 5 and sd.tolist() == [256] * 5
+
+
+def test_hamming_csr():
+    from monoorbslam3_amd.matcher import ORBMatcher
+    a, b, _ = synth.make_descriptor_pair(200, seed=9)
+    rng = np.random.RandomState(2)
+    q_idx = rng.randint(0, 200, 50)
+    lens = rng.randint(0, 90, 50)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    c_idx = rng.randint(0, 200, off[-1])
+    out = ORBMatcher.hamming_csr(a, b, q_idx, off, c_idx)
+    d = _popcount_ref(a, b)
+    ref = np.concatenate([d[q_idx[q], c_idx[off[q]:off[q + 1]]] for q in range(50)])
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("bits,n", [(10, 2000), (4, 2000), (0, 600)])
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_bow(oracle_mod, bits, n, check_ori):
+    from monoorbslam3_amd.matcher import ORBMatcher
+    a, b, _ = synth.make_descriptor_pair(n, seed=bits + 1)
+    rng = np.random.RandomState(bits)
+    ang1 = rng.uniform(0, 360, n).astype(np.float32)
+    ang2 = ((ang1[rng.permutation(n)] + rng.normal(0, 20, n)) % 360).astype(np.float32)
+    ok = (rng.uniform(size=n) > 0.25).astype(np.uint8)
+    mp0 = np.where(rng.uniform(size=n) > 0.9, 7, -1).astype(np.int32)
+    fv1 = synth.feature_vector_by_prefix(a, bits)
+    fv2 = synth.feature_vector_by_prefix(b, bits)
+    m = ORBMatcher(0.7, check_ori)
+    n_got, mp_got = m.SearchByBow(a, ang1, ok, fv1, b, ang2, mp0, fv2)
+    n_ref, mp_ref = oracle_mod.search_by_bow(0.7, check_ori, a, ang1, ok, fv1, b, ang2, mp0, fv2)
+    assert n_got == n_ref and np.array_equal(mp_got, mp_ref)
+    assert n_got > 0
+
+
+@pytest.mark.parametrize("bits", [8, 3])
+@pytest.mark.parametrize("check_ori", [False, True])
+def test_search_for_triangulation(oracle_mod, bits, check_ori):
+    from monoorbslam3_amd.matcher import ORBMatcher
+    n = 1500
+    a, b, _ = synth.make_descriptor_pair(n, seed=bits + 20, flip_p=0.06)
+    rng = np.random.RandomState(bits)
+    ang1 = rng.uniform(0, 360, n).astype(np.float32)
+    ang2 = rng.uniform(0, 360, n).astype(np.float32)
+    h1 = (rng.uniform(size=n) > 0.6).astype(np.uint8)
+    h2 = (rng.uniform(size=n) > 0.6).astype(np.uint8)
+    fv1 = synth.feature_vector_by_prefix(a, bits)
+    fv2 = synth.feature_vector_by_prefix(b, bits)
+    m = ORBMatcher(0.6, check_ori)
+    n_got, m_got = m.SearchForTriangulation(a, ang1, h1, fv1, b, ang2, h2, fv2)
+    n_ref, m_ref = oracle_mod.search_for_triangulation(check_ori, a, ang1, h1, fv1, b, ang2, h2, fv2)
+    assert n_got == n_ref and np.array_equal(m_got, m_ref)
+    assert (m_got == 0).sum() == 0  # reference quirk: index 0 is never matched (ORBMatcher.cpp:484)
+
+
+def test_search_for_initialization_on_extracted_frames(oracle_mod):
+    """two shifted views of one scene through the GPU extractor, then the initialisation matcher"""
+    from monoorbslam3_amd.extractor import ORBExtractor
+    from monoorbslam3_amd.matcher import ORBMatcher
+    w, h = 752, 480
+    canvas = synth.make_canvas(w + 40, h + 20, seed=77)
+    f1 = np.ascontiguousarray(canvas[5:5 + h, 10:10 + w])
+    f2 = np.ascontiguousarray(canvas[9:9 + h, 22:22 + w])
+    ex = ORBExtractor(2000, 1.2, 8, 20, 7)
+    k1, d1 = ex(f1)
+    k2, d2 = ex(f2)
+    pre = np.stack([k1["x"], k1["y"]], axis=1)
+    for ori in (True, False):
+        m = ORBMatcher(0.9, ori)
+        n_got, m_got, pre_got = m.SearchForInitialization(k1, d1, k2, d2, w, h, pre, 100)
+        n_ref, m_ref, pre_ref = oracle_mod.search_for_initialization(0.9, ori, k1, d1, k2, d2, w, h, pre, 100)
+        assert n_got == n_ref and np.array_equal(m_got, m_ref) and np.array_equal(pre_got, pre_ref)
+        assert n_got > 50

@@ -1,0 +1,594 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference ships no fixtures or asserting tests for this path, so the
+oracle is pinned by (a) values derivable from the reference's code alone and (b) independent
+literal re-implementations in Python (real list / dict semantics) of the order-dependent
+routines.  Parity against the OpenCV-backed original stays UNPINNED.
+"""
+import hashlib
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from monoorbslam3_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def O(oracle_mod):
+    return oracle_mod
+
+
+# ---------------------------------------------------------------- (1) DescriptorDistance
+def test_hamming_kats(O):
+    x = (np.arange(32) * 7 % 256).astype(np.uint8)
+    assert O.hamming(x, x) == 0
+    assert O.hamming(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+    rng = np.random.RandomState(0)
+    for _ in range(200):
+        a = rng.randint(0, 256, 32).astype(np.uint8)
+        b = rng.randint(0, 256, 32).astype(np.uint8)
+        assert O.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
+
+
+# ---------------------------------------------------------------- (2)(3)(4) constructor tables
+def test_u_max_table(O):
+    # reference ORBExtractor.cpp:460-474
+    assert O.Oracle().u_max() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+
+
+def _quotas_py(n, sf=1.2, levels=8):
+    f = np.float32
+    inv2 = f(1.0) / (f(sf) * f(sf))
+    num = f(n) * (f(1) - inv2)
+    nd = f(float(num) / (1.0 - math.pow(float(inv2), levels)))
+    out, s = [], 0
+    for _ in range(levels - 1):
+        q = int(np.rint(nd))
+        out.append(q)
+        s += q
+        nd = f(nd * inv2)
+    out.append(max(n - s, 1))
+    return out
+
+
+@pytest.mark.parametrize("n,expect", [
+    (1000, [323, 224, 156, 108, 75, 52, 36, 26]),
+    (2000, [646, 449, 312, 216, 150, 104, 72, 51]),
+    (1500, [485, 336, 234, 162, 113, 78, 54, 38]),
+    (4000, None), (8000, None), (300, None)])
+def test_quota_tables(O, n, expect):
+    # reference ORBExtractor.cpp:443-452; literal values from SURVEY.md Appendix C
+    q = O.Oracle(n, 1.2, 8, 20, 7).quotas()
+    assert q == _quotas_py(n)
+    if expect:
+        assert q == expect
+    assert sum(q) == n or q[-1] == 1
+
+
+def test_requota_matches_fresh_constructor(O):
+    a = O.Oracle(1000, 1.2, 8, 20, 7)
+    a.requota(2000)
+    assert a.quotas() == O.Oracle(2000, 1.2, 8, 20, 7).quotas() == [646, 449, 312, 216, 150, 104, 72, 51]
+
+
+def test_scale_tables_and_level_sizes(O):
+    o = O.Oracle(2000, 1.2, 8, 20, 7)
+    sf = o.scale_factors()
+    f = np.float32
+    e = [f(1)]
+    for _ in range(7):
+        e.append(f(e[-1] * f(1.2)))
+    assert np.array_equal(sf, np.array(e, np.float32))
+    # SURVEY.md Appendix C
+    assert [o.level_size(1242, 375, l) for l in range(8)] == [
+        (1242, 375), (1035, 312), (862, 260), (719, 217), (599, 181), (499, 151), (416, 126), (347, 105)]
+    assert [o.level_size(752, 480, l) for l in range(8)] == [
+        (752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]
+    assert [o.level_size(1920, 1080, l) for l in range(8)] == [
+        (1920, 1080), (1600, 900), (1333, 750), (1111, 625), (926, 521), (772, 434), (643, 362), (536, 301)]
+
+
+# ---------------------------------------------------------------- (5) pattern
+def test_pattern_table(O):
+    g = json.load(open(os.path.join(GOLDEN, "brief_pattern.json")))
+    p = np.ctypeslib.as_array(O.lib().orbref_pattern(), shape=(1024,)).copy()
+    assert p[:4].tolist() == [8, -3, 9, 5] and p[-4:].tolist() == [-1, -6, 0, -11]  # ORBExtractor.cpp:109,:364
+    assert p.tolist() == g["values"]
+    assert hashlib.sha256(p.astype(np.int8).tobytes()).hexdigest() == g["sha256_int8"]
+    assert np.abs(p).max() <= 13  # every rotated sample stays inside the 19-px border
+
+
+# ---------------------------------------------------------------- (6) ComputeThreeMaxima
+def test_three_maxima(O):
+    h = [0] * 30
+    assert O.three_maxima(h) == (-1, 0, 1)  # all-empty quirk of the literal code (max2=-1, max3=-2 initialisers)
+    h = [0] * 30
+    h[3], h[7], h[9] = 50, 20, 6
+    assert O.three_maxima(h) == (3, 7, 9)
+    h[9] = 4           # 4 < 50/10 -> third dropped
+    assert O.three_maxima(h) == (3, 7, -1)
+    h[7] = 4           # second below a tenth -> both dropped
+    assert O.three_maxima(h) == (3, -1, -1)
+    h = [0] * 30
+    h[2], h[5] = 19, 1  # integer division: 19/10 == 1, so 1 is NOT < 1 and the second survives
+    assert O.three_maxima(h)[:2] == (2, 5)
+    h = [5] * 30        # ties: strict '>' keeps the first three bins
+    assert O.three_maxima(h) == (0, 1, 2)
+
+
+# ---------------------------------------------------------------- (8) FAST
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+        (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def _fast_py(img, x, y, t):
+    """definition: >= 9 contiguous ring pixels all > v+t or all < v-t; score = max_t' such that still a corner"""
+    v = int(img[y, x])
+    ring = [int(img[y + dy, x + dx]) for dx, dy in RING]
+
+    def corner(tt):
+        for s in range(16):
+            arc = [ring[(s + j) % 16] for j in range(9)]
+            if all(p > v + tt for p in arc) or all(p < v - tt for p in arc):
+                return True
+        return False
+    if not corner(t):
+        return None
+    s = t
+    while s < 255 and corner(s + 1):
+        s += 1
+    return s
+
+
+def test_fast_hand_made(O):
+    o = O.Oracle()
+    img = np.full((21, 21), 100, np.uint8)
+    img[10, 10] = 160  # isolated bright dot: the whole ring is darker by 60 -> score 59
+    k = o.fast_box(img, 5, 5, 16, 16, 20)
+    assert len(k) == 1 and (k["x"][0], k["y"][0], k["response"][0]) == (10, 10, 59)
+    assert o.fast_strength(img, 10, 10) == 59
+    assert len(o.fast_box(img, 5, 5, 16, 16, 60)) == 0  # needs diff > t
+    # a straight vertical edge is not a corner (only 7..8 contiguous ring pixels differ)
+    img = np.full((21, 21), 50, np.uint8)
+    img[:, 11:] = 200
+    assert len(o.fast_box(img, 5, 5, 16, 16, 20)) == 0
+    # corner of a bright quadrant on dark ground
+    img = np.full((25, 25), 40, np.uint8)
+    img[12:, 12:] = 140
+    # the corner pixel sees 11 contiguous ring pixels darker by 100 -> strength 99; its diagonal
+    # neighbour (13,13) scores the same, so the strict 3x3 NMS drops both (as OpenCV does)
+    assert o.fast_strength(img, 12, 12) == 99 == _fast_py(img, 12, 12, 20)
+    assert o.fast_strength(img, 13, 13) == 99
+    k = o.fast_box(img, 4, 4, 21, 21, 20)
+    assert all((int(r["x"]), int(r["y"])) not in ((12, 12), (13, 13)) for r in k)
+    # a single-pixel box has no in-box neighbours, so the same corner is kept there
+    k = o.fast_box(img, 12, 12, 13, 13, 20)
+    assert len(k) == 1 and int(k["response"][0]) == 99
+
+
+def test_fast_strength_is_threshold_free_score(O):
+    """S(p) from the closed form == OpenCV-style score for every threshold at which p is a corner"""
+    o = O.Oracle()
+    rng = np.random.RandomState(4)
+    img = (rng.randint(0, 256, (40, 40)) // 32 * 32).astype(np.uint8)  # coarse levels -> many corners
+    n_checked = 0
+    for y in range(3, 37):
+        for x in range(3, 37):
+            s = o.fast_strength(img, x, y)
+            for t in (1, 7, 20, 60):
+                ref = _fast_py(img, x, y, t)
+                if ref is None:
+                    assert s < t
+                else:
+                    assert s == ref and s >= t
+                    n_checked += 1
+    assert n_checked > 100
+
+
+def test_fast_box_nms_and_fallback(O):
+    o = O.Oracle(1000, 1.2, 8, 20, 7)
+    img = synth.make_frames(1, 200, 120, seed=8)[0]
+    # box results == brute force definition + strict 3x3 NMS with zeros outside the box
+    x0, y0, x1, y1 = 19, 19, 49, 49
+    for t in (20, 7):
+        sc = np.zeros((y1 - y0 + 2, x1 - x0 + 2), int)
+        for y in range(y0, y1):
+            for x in range(x0, x1):
+                s = _fast_py(img, x, y, t)
+                sc[y - y0 + 1, x - x0 + 1] = s if s is not None else 0
+        ref = []
+        for y in range(1, sc.shape[0] - 1):
+            for x in range(1, sc.shape[1] - 1):
+                v = sc[y, x]
+                nb = sc[y - 1:y + 2, x - 1:x + 2].copy()
+                nb[1, 1] = -1
+                if v > 0 and (v > nb).all():
+                    ref.append((x - 1 + x0, y - 1 + y0, v))
+        k = o.fast_box(img, x0, y0, x1, y1, t)
+        assert [(int(r["x"]), int(r["y"]), int(r["response"])) for r in k] == ref
+    # level candidates: every cell uses 20, or 7 when 20 finds nothing (ORBExtractor.cpp:601-607)
+    c = o.level_candidates(img)
+    got = sorted((int(r["y"]), int(r["x"]), int(r["response"])) for r in c)
+    ref = []
+    for cy in range(19, 120 - 19, 30):
+        for cx in range(19, 200 - 19, 30):
+            bx1, by1 = min(cx + 30, 200 - 19), min(cy + 30, 120 - 19)
+            k = o.fast_box(img, cx, cy, bx1, by1, 20)
+            if len(k) == 0:
+                k = o.fast_box(img, cx, cy, bx1, by1, 7)
+            ref += [(int(r["y"]) - 19, int(r["x"]) - 19, int(r["response"])) for r in k]
+    assert got == sorted(ref) and len(got) > 20
+
+
+# ---------------------------------------------------------------- resize / blur arithmetic
+def _resize_py(src, dw, dh):
+    f = np.float32
+    sh, sw = src.shape
+
+    def taps(dn, sn, clamp):
+        scale = 1.0 / (float(dn) / sn)
+        res = []
+        for d in range(dn):
+            fx = f((d + 0.5) * scale - 0.5)
+            s = int(math.floor(fx))
+            fx = f(fx - f(s))
+            if clamp:
+                if s < 0:
+                    fx, s = f(0), 0
+                if s >= sn - 1:
+                    fx, s = f(0), sn - 1
+            res.append((s, int(np.rint(f(f(1) - fx) * f(2048))), int(np.rint(fx * f(2048)))))
+        return res
+    xt, yt = taps(dw, sw, True), taps(dh, sh, False)
+    out = np.zeros((dh, dw), np.uint8)
+    for dy, (sy, b0, b1) in enumerate(yt):
+        r0, r1 = min(max(sy, 0), sh - 1), min(max(sy + 1, 0), sh - 1)
+        for dx, (sx, a0, a1) in enumerate(xt):
+            sx1 = min(sx + 1, sw - 1)
+            h0 = int(src[r0, sx]) * a0 + int(src[r0, sx1]) * a1
+            h1 = int(src[r1, sx]) * a0 + int(src[r1, sx1]) * a1
+            out[dy, dx] = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 255
+    return out
+
+
+def test_resize_against_python_model(O):
+    o = O.Oracle()
+    rng = np.random.RandomState(5)
+    src = rng.randint(0, 256, (37, 53)).astype(np.uint8)
+    for dw, dh in ((44, 31), (45, 30), (53, 37), (20, 11)):
+        assert np.array_equal(o.resize(src, dw, dh), _resize_py(src, dw, dh))
+    flat = np.full((40, 60), 173, np.uint8)
+    assert (o.resize(flat, 50, 33) == 173).all()  # taps sum to 2048 -> constants are preserved
+
+
+def test_blur_fixed_point(O):
+    o = O.Oracle()
+    taps = np.array([18, 34, 48, 56, 48, 34, 18])
+    assert taps.sum() == 256
+    flat = np.full((20, 30), 201, np.uint8)
+    assert (o.blur(flat) == 201).all()
+    imp = np.zeros((21, 21), np.uint8)
+    imp[10, 10] = 255
+    ref = (np.outer(taps, taps) * 255 + (1 << 15)) >> 16
+    assert np.array_equal(o.blur(imp)[7:14, 7:14], ref)
+    # BORDER_REFLECT_101 at the corner: pixel (0,0) sees rows/cols 3,2,1,0,1,2,3
+    rng = np.random.RandomState(6)
+    img = rng.randint(0, 256, (12, 14)).astype(np.uint8)
+    idx = [3, 2, 1, 0, 1, 2, 3]
+    h = np.array([[int((taps * img[r, idx]).sum())] for r in idx])[:, 0]
+    assert o.blur(img)[0, 0] == ((taps * h).sum() + (1 << 15)) >> 16
+    # alternative (plain-rounded, sum 257) tap set is selectable
+    o1 = O.Oracle(blur_variant=1)
+    assert o1.blur(flat)[5, 5] == min(255, (201 * 257 * 257 + (1 << 15)) >> 16)
+
+
+# ---------------------------------------------------------------- orientation / rotation arithmetic
+def test_fast_atan2(O):
+    L = O.lib()
+    assert L.orbref_fast_atan2(0.0, 1.0) == 0.0
+    assert abs(L.orbref_fast_atan2(1.0, 0.0) - 90.0) < 1e-4
+    assert abs(L.orbref_fast_atan2(0.0, -1.0) - 180.0) < 1e-4
+    assert abs(L.orbref_fast_atan2(-1.0, 0.0) - 270.0) < 1e-4
+    rng = np.random.RandomState(7)
+    worst = 0.0
+    for _ in range(5000):
+        y, x = rng.randint(-200000, 200000, 2)
+        if x == 0 and y == 0:
+            continue
+        a = L.orbref_fast_atan2(float(y), float(x))
+        ref = math.degrees(math.atan2(y, x)) % 360.0
+        d = abs(a - ref)
+        worst = max(worst, min(d, 360 - d))
+        assert 0.0 <= a <= 360.0
+    assert worst < 0.05  # polynomial accuracy (OpenCV documents ~0.3 deg)
+
+
+def test_sincos_matches_libm(O):
+    o = O.Oracle()
+    f = np.float32
+    fac = f(math.pi / float(f(180.0)))
+    for a in np.linspace(0, 360, 20001, dtype=np.float32):
+        c, s = o.sincos_deg(float(a))
+        r = float(f(a) * fac)
+        assert c == f(math.cos(r)) and s == f(math.sin(r))
+
+
+def test_ic_angle_symmetry(O):
+    o = O.Oracle()
+    img = np.full((41, 41), 10, np.uint8)
+    img[:, 21:] = 200          # brighter to the right -> centroid on +x -> 0 degrees
+    assert o.ic_angle(img, 20, 20) == 0.0
+    assert abs(o.ic_angle(np.ascontiguousarray(img.T), 20, 20) - 90.0) < 1e-3
+    assert abs(o.ic_angle(np.ascontiguousarray(img[:, ::-1]), 20, 20) - 180.0) < 1e-3
+
+
+# ---------------------------------------------------------------- (9) descriptor bit order
+def test_brief_bit_order(O):
+    """angle 0: sample(idx) = blur[y + py][x + px]; bit i of byte j <- pair 8j+i (ORBExtractor.cpp:66-94)"""
+    o = O.Oracle()
+    pat = np.array(json.load(open(os.path.join(GOLDEN, "brief_pattern.json")))["values"]).reshape(256, 4)
+    rng = np.random.RandomState(8)
+    img = rng.randint(0, 256, (45, 45)).astype(np.uint8)
+    d = o.brief(img, 22, 22, 0.0)
+    for pair in range(256):
+        x0, y0, x1, y1 = pat[pair]
+        bit = int(img[22 + y0, 22 + x0] < img[22 + y1, 22 + x1])
+        assert (d[pair // 8] >> (pair % 8)) & 1 == bit
+    # 90 degrees: (a, b) = (cos, sin) ~ (0, 1): row offset = round(px*b + py*a) = px, col offset = -py
+    d90 = o.brief(img, 22, 22, 90.0)
+    for pair in range(256):
+        x0, y0, x1, y1 = pat[pair]
+        bit = int(img[22 + x0, 22 - y0] < img[22 + x1, 22 - y1])
+        assert (d90[pair // 8] >> (pair % 8)) & 1 == bit
+
+
+# ---------------------------------------------------------------- (7) DivideNode / DistributeOctree
+def _octree_py(cands, min_x, max_x, min_y, max_y, n_features):
+    """Literal Python model of ORBExtractor.cpp:640-830 with real list semantics; the pointer
+    tie-break of the (size, node*) sort is replaced by creation order."""
+    W, H = max_x - min_x, max_y - min_y
+    f = np.float32
+    n_ini = int(math.ceil(float(f(W) / f(H))))
+    h_x = int(math.ceil(float(f(W) / f(n_ini))))
+    seq = [0]
+
+    def node(ulx, uly, brx, bry):
+        seq[0] += 1
+        return {"b": (ulx, uly, brx, bry), "p": [], "nomore": False, "seq": seq[0]}
+    lst = []
+    for i in range(n_ini):
+        lst.append(node(h_x * i, 0, max_x if i == n_ini - 1 else h_x * (i + 1), H))
+    ini = list(lst)
+    for k, (x, y, r) in enumerate(cands):
+        ini[int(x) // h_x]["p"].append(k)
+    lst = [n for n in lst if n["p"]]
+    for n in lst:
+        if len(n["p"]) == 1:
+            n["nomore"] = True
+
+    def divide(n):
+        ulx, uly, brx, bry = n["b"]
+        hx, hy = (brx - ulx) // 2, (bry - uly) // 2
+        ch = [node(ulx, uly, ulx + hx, uly + hy), node(ulx + hx, uly, brx, uly + hy),
+              node(ulx, uly + hy, ulx + hx, bry), node(ulx + hx, uly + hy, brx, bry)]
+        for k in n["p"]:
+            x, y, _ = cands[k]
+            if int(x) < ulx + hx:
+                ch[0 if int(y) < uly + hy else 2]["p"].append(k)
+            else:
+                ch[1 if int(y) < uly + hy else 3]["p"].append(k)
+        for c in ch:
+            if len(c["p"]) == 1:
+                c["nomore"] = True
+        return ch
+    finish = False
+    while not finish:
+        pre = len(lst)
+        to_expand = 0
+        vec = []
+        for n in list(lst):          # children are pushed to the front and not revisited this round
+            if n["nomore"]:
+                continue
+            for c in divide(n):
+                if c["p"]:
+                    lst.insert(0, c)
+                    if len(c["p"]) > 1:
+                        to_expand += 1
+                        vec.append(c)
+            lst.remove(n)
+        if len(lst) > n_features or len(lst) == pre:
+            finish = True
+        elif len(lst) + 3 * to_expand > n_features:
+            while not finish:
+                pre = len(lst)
+                prev = sorted(vec, key=lambda c: (len(c["p"]), c["seq"]))
+                vec = []
+                for n in prev:
+                    for c in divide(n):
+                        if c["p"]:
+                            lst.insert(0, c)
+                            if len(c["p"]) > 1:
+                                vec.append(c)
+                    lst.remove(n)
+                    if len(lst) >= n_features:
+                        break
+                if len(lst) >= n_features or len(lst) == pre:
+                    finish = True
+    out = []
+    for n in lst:
+        best = n["p"][0]
+        for k in n["p"][1:]:
+            if cands[k][2] > cands[best][2]:
+                best = k
+        out.append(cands[best])
+    return out
+
+
+def test_divide_node_hand_made(O):
+    o = O.Oracle()
+    # region 100 x 60 (minX=19, maxX=119, minY=19, maxY=79): nIni = ceil(100/60) = 2, hX = 50;
+    # last initial node spans x in [50, 119) (absolute maxX quirk, ORBExtractor.cpp:665)
+    pts = [(10, 10, 30.0), (40, 50, 31.0), (60, 10, 32.0), (99, 59, 33.0), (70, 40, 34.0)]
+    c = np.array(pts, dtype=O.CAND_DTYPE)
+    out = o.distribute(c, 19, 119, 19, 79, 5)
+    ref = _octree_py(pts, 19, 119, 19, 79, 5)
+    assert [(r["x"], r["y"], r["response"]) for r in out] == [tuple(map(float, p)) for p in ref]
+    assert len(out) == 5
+    # one feature wanted: the first round always runs (the size test comes after it, :750) and
+    # already separates all five points, so five come back although one was asked for
+    out1 = o.distribute(c, 19, 119, 19, 79, 1)
+    ref1 = _octree_py(pts, 19, 119, 19, 79, 1)
+    assert len(out1) == 5 and [r["response"] for r in out1] == [p[2] for p in ref1]
+
+
+@pytest.mark.parametrize("seed,n,w,h,nf", [(0, 400, 300, 120, 60), (1, 3000, 1204, 337, 646), (2, 50, 200, 200, 100),
+                                           (3, 1500, 640, 90, 300), (4, 2500, 500, 400, 1000), (5, 7, 90, 300, 3)])
+def test_octree_against_python_list_model(O, seed, n, w, h, nf):
+    o = O.Oracle()
+    rng = np.random.RandomState(seed)
+    xy = set()
+    while len(xy) < n:
+        xy.add((int(rng.randint(0, w)), int(rng.randint(0, h))))
+    # reference emission order: 30-px cells row-major, row-major inside a cell
+    pts = sorted(xy, key=lambda p: (p[1] // 30, p[0] // 30, p[1] % 30, p[0] % 30))
+    cands = [(x, y, float(rng.randint(7, 40))) for x, y in pts]  # few distinct responses -> many ties
+    c = np.array(cands, dtype=O.CAND_DTYPE)
+    out = o.distribute(c, 19, 19 + w, 19, 19 + h, nf)
+    ref = _octree_py(cands, 19, 19 + w, 19, 19 + h, nf)
+    assert [(r["x"], r["y"], r["response"]) for r in out] == [tuple(map(float, p)) for p in ref]
+
+
+# ---------------------------------------------------------------- matchers vs literal Python models
+def _rot_bin(a1, a2):
+    f = np.float32
+    rot = f(a1) - f(a2)
+    if rot < 0:
+        rot = f(rot + f(360))
+    b = int(np.rint(f(rot * f(f(1) / f(30)))))
+    return 0 if b == 30 else b
+
+
+def _fv_dict(csr):
+    ids, off, idx = csr
+    return {int(ids[k]): [int(v) for v in idx[off[k]:off[k + 1]]] for k in range(len(ids))}
+
+
+def _ham(a, b):
+    return int(np.unpackbits(a ^ b).sum())
+
+
+def _bow_py(O, nn, ori, d1, a1, ok, fv1, d2, a2, mp, fv2):
+    mp = mp.copy()
+    n = 0
+    hist = [[] for _ in range(30)]
+    F1, F2 = _fv_dict(fv1), _fv_dict(fv2)
+    for node in sorted(set(F1) & set(F2)):
+        for i1 in F1[node]:
+            if not ok[i1]:
+                continue
+            best, second, bi = 256, 256, -1
+            for i2 in F2[node]:
+                if mp[i2] != -1:
+                    continue
+                d = _ham(d1[i1], d2[i2])
+                if d < best:
+                    second, best, bi = best, d, i2
+                elif d < second:
+                    second = d
+            if best <= 50 and np.float32(best) < np.float32(nn) * np.float32(second):
+                mp[bi] = i1
+                n += 1
+                if ori:
+                    hist[_rot_bin(a1[i1], a2[bi])].append(bi)
+    if ori:
+        i1, i2, i3 = O.three_maxima([len(h) for h in hist])
+        for b in range(30):
+            if b in (i1, i2, i3):
+                continue
+            for j in hist[b]:
+                mp[j] = -1
+                n -= 1
+    return n, mp
+
+
+@pytest.mark.parametrize("bits", [6, 2])
+@pytest.mark.parametrize("ori", [True, False])
+def test_search_by_bow_model(O, bits, ori):
+    n = 400
+    a, b, _ = synth.make_descriptor_pair(n, seed=bits)
+    rng = np.random.RandomState(bits)
+    a1 = rng.uniform(0, 360, n).astype(np.float32)
+    a2 = rng.uniform(0, 360, n).astype(np.float32)
+    ok = (rng.uniform(size=n) > 0.3).astype(np.uint8)
+    mp0 = np.where(rng.uniform(size=n) > 0.9, 3, -1).astype(np.int32)
+    fv1, fv2 = synth.feature_vector_by_prefix(a, bits), synth.feature_vector_by_prefix(b, bits)
+    got = O.search_by_bow(0.7, ori, a, a1, ok, fv1, b, a2, mp0, fv2)
+    ref = _bow_py(O, 0.7, ori, a, a1, ok, fv1, b, a2, mp0, fv2)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[0] > 0
+
+
+def test_search_for_triangulation_model(O):
+    n = 300
+    a, b, _ = synth.make_descriptor_pair(n, seed=31, flip_p=0.05)
+    rng = np.random.RandomState(31)
+    a1 = rng.uniform(0, 360, n).astype(np.float32)
+    a2 = rng.uniform(0, 360, n).astype(np.float32)
+    h1 = (rng.uniform(size=n) > 0.5).astype(np.uint8)
+    h2 = (rng.uniform(size=n) > 0.5).astype(np.uint8)
+    fv1, fv2 = synth.feature_vector_by_prefix(a, 3), synth.feature_vector_by_prefix(b, 3)
+    h2[0] = 0
+    n_got, m = O.search_for_triangulation(False, a, a1, h1, fv1, b, a2, h2, fv2)
+    F1, F2 = _fv_dict(fv1), _fv_dict(fv2)
+    ref = np.full(n, -1, np.int32)
+    taken = np.zeros(n, bool)
+    cnt = 0
+    for node in sorted(set(F1) & set(F2)):
+        for i1 in F1[node]:
+            if h1[i1]:
+                continue
+            best, bi = 50, -1
+            for i2 in F2[node]:
+                if taken[i2] or h2[i2]:
+                    continue
+                d = _ham(a[i1], b[i2])
+                if d < best:
+                    best, bi = d, i2
+            if bi > 0:
+                ref[i1] = bi
+                taken[bi] = True
+                cnt += 1
+    assert n_got == cnt and np.array_equal(m, ref) and cnt > 0 and not (m == 0).any()
+
+
+def test_features_in_area(O):
+    rng = np.random.RandomState(9)
+    n = 500
+    kps = np.zeros(n, O.KP_DTYPE)
+    kps["x"] = rng.uniform(0, 640, n).astype(np.float32)
+    kps["y"] = rng.uniform(0, 480, n).astype(np.float32)
+    kps["octave"] = rng.randint(0, 8, n)
+    for (x, y, r, lo, hi) in [(100.0, 100.0, 50.0, 0, 0), (630.0, 470.0, 30.0, 2, 4), (5.0, 5.0, 100.0, -1, -1),
+                              (320.0, 240.0, 15.5, 1, 7)]:
+        got = O.features_in_area(kps, 640, 480, x, y, r, lo, hi)
+        check = lo > 0 or hi >= 0
+        ref = [i for i in range(n) if abs(kps["x"][i] - np.float32(x)) <= r and abs(kps["y"][i] - np.float32(y)) <= r
+               and (not check or (kps["octave"][i] >= lo and (hi < 0 or kps["octave"][i] <= hi)))]
+        assert sorted(got.tolist()) == ref
+
+
+# ---------------------------------------------------------------- committed golden fixtures
+def test_golden_extract_fixture(O):
+    """oracle output on a committed small frame (fixture generated by tools/gen_golden.py FROM THE ORACLE;
+    it guards against drift, it is not a reference-generated vector)"""
+    z = np.load(os.path.join(GOLDEN, "extract_320x240_n300.npz"))
+    o = O.Oracle(300, 1.2, 8, 20, 7)
+    kps, desc, counts = o.extract(z["image"])
+    assert counts == z["counts"].tolist()
+    for f in ("x", "y", "angle", "response", "octave"):
+        assert np.array_equal(kps[f], z[f]), f
+    assert np.array_equal(desc, z["desc"])
