@@ -236,6 +236,7 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
         HIP_TRY(dev_alloc(&b.img_arena, img_fs * B));
         HIP_TRY(dev_alloc(&b.cand, cand_fs * B));
         HIP_TRY(dev_alloc(&b.pnode, cand_fs * B));
+        HIP_TRY(dev_alloc(&b.pcode, cand_fs * B));
         HIP_TRY(dev_alloc(&b.cand_count, (size_t)ORBX_MAX_LEVELS * B));
         HIP_TRY(dev_alloc(&b.bnd0, node_fs * B));
         HIP_TRY(dev_alloc(&b.bnd1, node_fs * B));
@@ -354,7 +355,7 @@ extern "C" void orbx_destroy(orbx_t *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     OrbxBuffers &b = c->buf;
-    void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
+    void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.pcode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
                     b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.sel_count, c->d_levels, c->d_umax, c->d_taps,
                     c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n};
     for (void *p : ptrs) if (p) (void)hipFree(p);

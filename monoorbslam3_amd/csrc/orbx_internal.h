@@ -49,6 +49,7 @@ struct OrbxBuffers {
     unsigned long long *cand;  size_t cand_frame_stride;  // packed candidates
     int *cand_count;                                      // [frame][level]
     uint32_t *pnode;                                      // [frame][cand slot] quadtree node of each candidate
+    uint32_t *pcode;                                      // [frame][cand slot] 16 x 2-bit quadtree descent of each candidate
     // quadtree scratch, per frame `node_frame_stride` node slots
     size_t node_frame_stride;
     short4 *bnd0, *bnd1;

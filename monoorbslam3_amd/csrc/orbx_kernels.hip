@@ -534,11 +534,318 @@ __global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree(const OrbxLevels *_
     if (tid == 0) *out_count = n_out;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Same algorithm with the node list resident in LDS (the default path).
+//
+// Node rectangles of the reference form, per initial node, a product grid: the x-interval of a node
+// depends only on the left/right choices along its path and the y-interval only on the up/down
+// choices (DivideNode halves each axis independently).  So every candidate's whole descent --
+// two bits per depth -- is computed ONCE from its (x, y) ("pcode"), and a pass needs no node
+// rectangles at all: the quadrant of point p in a node of depth d is bits [31-2d, 30-2d] of
+// pcode[p].  Per pass the candidates are streamed coalesced from HBM/L2 (position + code), all
+// list state (count|depth per node, ranks, child slots) lives in LDS, and child occupancy uses
+// LDS atomics.
+// ---------------------------------------------------------------------------------------------
+struct OctL {
+    const u64 *cand;
+    uint32_t *pnode, *pcode;
+    uint32_t *node[2]; // depth << 24 | count
+    uint32_t *childcnt;
+    uint16_t *rank, *newpos, *node_of_rank, *childpos;
+    int n;
+};
+#define OCT_NORANK 0xFFFFu
+
+__device__ __forceinline__ void octl_child_counts(const OctL &c, int cur, int nrank)
+{
+    for (int i = threadIdx.x; i < 4 * nrank; i += ORBX_OCT_THREADS) c.childcnt[i] = 0;
+    __syncthreads();
+    for (int p = threadIdx.x; p < c.n; p += ORBX_OCT_THREADS) {
+        const uint32_t old = c.pnode[p], code = c.pcode[p];
+        const uint32_t r = c.rank[old];
+        if (r != OCT_NORANK) {
+            const uint32_t d = c.node[cur][old] >> 24;
+            atomicAdd(&c.childcnt[4 * r + ((code >> (30 - 2 * d)) & 3)], 1u);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void octl_apply(const OctL &c, int cur, int size, int nsplit, int *new_size, int *n_expand,
+                                           int *lds)
+{
+    const int nxt = cur ^ 1;
+    const int len = 4 * nsplit;
+    const int chunk = (len + ORBX_OCT_THREADS - 1) / ORBX_OCT_THREADS;
+    const int i0 = min((int)threadIdx.x * chunk, len), i1 = min(i0 + chunk, len);
+    int s = 0, e = 0;
+    for (int i = i0; i < i1; ++i) {
+        s += c.childcnt[i] > 0;
+        e += c.childcnt[i] > 1;
+    }
+    int T, E;
+    int ci = block_scan_excl(s, &T, lds);
+    block_scan_excl(e, &E, lds);
+    const int chunk2 = (size + ORBX_OCT_THREADS - 1) / ORBX_OCT_THREADS;
+    const int j0 = min((int)threadIdx.x * chunk2, size), j1 = min(j0 + chunk2, size);
+    int u = 0;
+    for (int j = j0; j < j1; ++j) u += !(c.rank[j] < (uint32_t)nsplit);
+    int U;
+    int ui = block_scan_excl(u, &U, lds);
+    for (int i = i0; i < i1; ++i) {
+        const uint32_t n = c.childcnt[i];
+        if (n > 0) {
+            const int pos = T - 1 - ci;
+            const uint32_t pd = c.node[cur][c.node_of_rank[i >> 2]] >> 24;
+            c.node[nxt][pos] = ((pd + 1) << 24) | n;
+            c.childpos[i] = (uint16_t)pos;
+            ++ci;
+        }
+    }
+    for (int j = j0; j < j1; ++j) {
+        if (!(c.rank[j] < (uint32_t)nsplit)) {
+            const int pos = T + ui;
+            c.node[nxt][pos] = c.node[cur][j];
+            c.newpos[j] = (uint16_t)pos;
+            ++ui;
+        }
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < c.n; p += ORBX_OCT_THREADS) {
+        const uint32_t old = c.pnode[p];
+        const uint32_t r = c.rank[old];
+        uint32_t np;
+        if (r < (uint32_t)nsplit) {
+            const uint32_t d = c.node[cur][old] >> 24;
+            np = c.childpos[4 * r + ((c.pcode[p] >> (30 - 2 * d)) & 3)];
+        } else {
+            np = c.newpos[old];
+        }
+        c.pnode[p] = np;
+    }
+    __syncthreads();
+    *new_size = T + U;
+    *n_expand = E;
+}
+
+__global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree_lds(const OrbxLevels *__restrict__ levels, OrbxBuffers b)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int lds[16];
+    __shared__ int s_first;
+
+    const int level = blockIdx.x, frame = blockIdx.y;
+    const OrbxLevel lv = levels->lv[level];
+    const int tid = threadIdx.x;
+    OctL c;
+    c.cand = b.cand + (size_t)frame * b.cand_frame_stride + lv.cand_off;
+    c.pnode = b.pnode + (size_t)frame * b.cand_frame_stride + lv.cand_off;
+    c.pcode = b.pcode + (size_t)frame * b.cand_frame_stride + lv.cand_off;
+    c.n = min(b.cand_count[frame * ORBX_MAX_LEVELS + level], lv.cand_cap);
+    int *out_count = &b.sel_count[frame * ORBX_MAX_LEVELS + level];
+    if (c.n <= 0 || lv.region_w <= 0 || lv.region_h <= 0) {
+        if (tid == 0) *out_count = 0;
+        return;
+    }
+    const int N = lv.quota, M = lv.node_cap, NSC = max(lv.quota, lv.n_ini) + 4;
+    int P2 = 1;
+    while (P2 < N) P2 <<= 1;
+    u64 *sort_keys = reinterpret_cast<u64 *>(smem);
+    c.node[0] = reinterpret_cast<uint32_t *>(sort_keys + P2);
+    c.node[1] = c.node[0] + M;
+    c.childcnt = c.node[1] + M;
+    c.rank = reinterpret_cast<uint16_t *>(c.childcnt + 4 * NSC);
+    c.newpos = c.rank + M;
+    c.node_of_rank = c.newpos + M;
+    c.childpos = c.node_of_rank + NSC;
+
+    // ---- descent code of every candidate + initial nodes (:645-686)
+    int cur = 0;
+    for (int i = tid; i < lv.n_ini; i += ORBX_OCT_THREADS) c.childcnt[i] = 0;
+    __syncthreads();
+    for (int p = tid; p < c.n; p += ORBX_OCT_THREADS) {
+        const u64 cd = c.cand[p];
+        const int x = (int)(cd & 0xFFFF), y = (int)((cd >> 16) & 0xFFFF);
+        const int idx = x / lv.h_x;
+        int ulx = lv.h_x * idx, brx = (idx == lv.n_ini - 1) ? (lv.w - ORBX_EDGE) : lv.h_x * (idx + 1); // :665
+        int uly = 0, bry = lv.region_h;
+        uint32_t code = 0;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const int midx = ulx + (brx - ulx) / 2, midy = uly + (bry - uly) / 2; // DivideNode :368-369
+            const int qx = x >= midx, qy = y >= midy;                             // :397-407
+            ulx = qx ? midx : ulx; brx = qx ? brx : midx;
+            uly = qy ? midy : uly; bry = qy ? bry : midy;
+            code |= (uint32_t)(qx | (qy << 1)) << (30 - 2 * d);
+        }
+        c.pcode[p] = code;
+        c.pnode[p] = idx;
+        atomicAdd(&c.childcnt[idx], 1u);
+    }
+    __syncthreads();
+    int size;
+    {
+        const int chunk = (lv.n_ini + ORBX_OCT_THREADS - 1) / ORBX_OCT_THREADS;
+        const int i0 = min(tid * chunk, lv.n_ini), i1 = min(i0 + chunk, lv.n_ini);
+        int s = 0;
+        for (int i = i0; i < i1; ++i) s += c.childcnt[i] > 0;
+        int pos = block_scan_excl(s, &size, lds);
+        for (int i = i0; i < i1; ++i)
+            if (c.childcnt[i] > 0) {
+                c.node[cur][pos] = c.childcnt[i]; // depth 0
+                c.newpos[i] = (uint16_t)pos++;
+            }
+        __syncthreads();
+        for (int p = tid; p < c.n; p += ORBX_OCT_THREADS) c.pnode[p] = c.newpos[c.pnode[p]];
+        __syncthreads();
+    }
+
+    // ---- main rounds (:692-751)
+    bool finish = false;
+    while (!finish) {
+        const int pre = size;
+        const int chunk = (size + ORBX_OCT_THREADS - 1) / ORBX_OCT_THREADS;
+        const int j0 = min(tid * chunk, size), j1 = min(j0 + chunk, size);
+        int s = 0;
+        for (int j = j0; j < j1; ++j) s += (c.node[cur][j] & 0xFFFFFF) > 1;
+        int nsplit;
+        int r = block_scan_excl(s, &nsplit, lds);
+        for (int j = j0; j < j1; ++j) {
+            if ((c.node[cur][j] & 0xFFFFFF) > 1) { c.rank[j] = (uint16_t)r; c.node_of_rank[r] = (uint16_t)j; ++r; }
+            else c.rank[j] = OCT_NORANK;
+        }
+        __syncthreads();
+        octl_child_counts(c, cur, nsplit);
+        int n_expand;
+        octl_apply(c, cur, size, nsplit, &size, &n_expand, lds);
+        cur ^= 1;
+        if (size > N || size == pre) {
+            finish = true;
+        } else if (size + 3 * n_expand > N) {
+            // ---- final phase (:752-809)
+            while (!finish) {
+                const int pre2 = size;
+                const int ch2 = (size + ORBX_OCT_THREADS - 1) / ORBX_OCT_THREADS;
+                const int a0 = min(tid * ch2, size), a1 = min(a0 + ch2, size);
+                int k = 0;
+                for (int j = a0; j < a1; ++j) k += (c.node[cur][j] & 0xFFFFFF) > 1;
+                int K;
+                int ko = block_scan_excl(k, &K, lds);
+                int P = 1;
+                while (P < K) P <<= 1;
+                for (int j = a0; j < a1; ++j) {
+                    c.rank[j] = OCT_NORANK;
+                    const uint32_t cn = c.node[cur][j] & 0xFFFFFF;
+                    if (cn > 1) sort_keys[ko++] = ((u64)cn << 32) | (u64)(0xFFFFFFFFu - (uint32_t)j);
+                }
+                for (int i = K + tid; i < P; i += ORBX_OCT_THREADS) sort_keys[i] = ~0ull;
+                __syncthreads();
+                for (int kk = 2; kk <= P; kk <<= 1)
+                    for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                        for (int i = tid; i < P; i += ORBX_OCT_THREADS) {
+                            const int ixj = i ^ jj;
+                            if (ixj > i) {
+                                const u64 x = sort_keys[i], y = sort_keys[ixj];
+                                if ((x > y) == ((i & kk) == 0)) { sort_keys[i] = y; sort_keys[ixj] = x; }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                for (int sidx = tid; sidx < K; sidx += ORBX_OCT_THREADS) {
+                    const int pos = (int)(0xFFFFFFFFu - (uint32_t)(sort_keys[sidx] & 0xFFFFFFFFu));
+                    c.rank[pos] = (uint16_t)sidx;
+                    c.node_of_rank[sidx] = (uint16_t)pos;
+                }
+                if (tid == 0) s_first = K;
+                __syncthreads();
+                octl_child_counts(c, cur, K);
+                const int ch3 = (K + ORBX_OCT_THREADS - 1) / ORBX_OCT_THREADS;
+                const int b0 = min(tid * ch3, K), b1 = min(b0 + ch3, K);
+                int g = 0;
+                for (int i = b0; i < b1; ++i) {
+                    int ne = 0;
+                    for (int q = 0; q < 4; ++q) ne += c.childcnt[4 * i + q] > 0;
+                    g += ne - 1;
+                }
+                int G;
+                int acc = size + block_scan_excl(g, &G, lds);
+                for (int i = b0; i < b1; ++i) {
+                    int ne = 0;
+                    for (int q = 0; q < 4; ++q) ne += c.childcnt[4 * i + q] > 0;
+                    acc += ne - 1;
+                    if (acc >= N) { atomicMin(&s_first, i); break; }
+                }
+                __syncthreads();
+                const int nsplit2 = min(s_first + 1, K);
+                __syncthreads();
+                int ne2;
+                octl_apply(c, cur, size, nsplit2, &size, &ne2, lds);
+                cur ^= 1;
+                if (size >= N || size == pre2) finish = true;
+            }
+        }
+    }
+
+    // ---- strongest point per node (:812-827); the node arrays are dead now and hold the maxima
+    u64 *best = reinterpret_cast<u64 *>(c.node[0]);
+    __syncthreads();
+    for (int j = tid; j < size; j += ORBX_OCT_THREADS) best[j] = 0;
+    __syncthreads();
+    const uint32_t ncols = (uint32_t)lv.n_cols;
+    for (int p = tid; p < c.n; p += ORBX_OCT_THREADS) {
+        const u64 cd = c.cand[p];
+        const uint32_t x = (uint32_t)(cd & 0xFFFF), y = (uint32_t)((cd >> 16) & 0xFFFF), resp = (uint32_t)(cd >> 32);
+        const uint32_t order = ((y / ORBX_CELL) * ncols + x / ORBX_CELL) * (ORBX_CELL * ORBX_CELL) +
+                               (y % ORBX_CELL) * ORBX_CELL + x % ORBX_CELL;
+        atomicMax(&best[c.pnode[p]], ((u64)resp << 32) | (u64)(0xFFFFFFFFu - order));
+    }
+    __syncthreads();
+    uint2 *sel = b.sel + (size_t)frame * levels->kcap_total + lv.kp_off;
+    const int n_out = min(size, lv.kcap);
+    for (int j = tid; j < n_out; j += ORBX_OCT_THREADS) {
+        const u64 k = best[j];
+        const uint32_t order = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFu);
+        const uint32_t cell = order / (ORBX_CELL * ORBX_CELL), in = order % (ORBX_CELL * ORBX_CELL);
+        const uint32_t x = (cell % ncols) * ORBX_CELL + in % ORBX_CELL + ORBX_EDGE;
+        const uint32_t y = (cell / ncols) * ORBX_CELL + in / ORBX_CELL + ORBX_EDGE;
+        sel[j] = make_uint2(x | (y << 16), (uint32_t)(k >> 32));
+    }
+    if (tid == 0) *out_count = n_out;
+}
+
+size_t orbx_octree_lds_bytes(const OrbxLevels &levels)
+{
+    size_t need = 0;
+    for (int l = 0; l < levels.n_levels; ++l) {
+        const OrbxLevel &v = levels.lv[l];
+        size_t P2 = 1;
+        while (P2 < (size_t)v.quota) P2 <<= 1;
+        const size_t M = v.node_cap, NSC = (size_t)(v.quota > v.n_ini ? v.quota : v.n_ini) + 4;
+        const size_t bytes = 8 * P2 + 8 * M + 16 * NSC + 4 * M + 2 * NSC + 8 * NSC + 64;
+        if (bytes > need) need = bytes;
+    }
+    return need;
+}
+
 void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLevels &levels, const OrbxBuffers &b,
                         int n_frames, size_t sort_lds_bytes)
 {
     dim3 grid(levels.n_levels, n_frames);
-    hipLaunchKernelGGL(k_octree, grid, dim3(ORBX_OCT_THREADS), sort_lds_bytes, s, d_levels, b);
+    const size_t lds_bytes = orbx_octree_lds_bytes(levels);
+    bool small_nodes = true; // 16-bit list positions
+    for (int l = 0; l < levels.n_levels; ++l) small_nodes = small_nodes && levels.lv[l].node_cap < 65535;
+    if (lds_bytes <= 160 * 1024 - 256 && small_nodes) {
+        static size_t configured = 0;
+        if (lds_bytes > configured) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree_lds),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            configured = lds_bytes;
+        }
+        hipLaunchKernelGGL(k_octree_lds, grid, dim3(ORBX_OCT_THREADS), lds_bytes, s, d_levels, b);
+    } else {
+        // quotas too large for the LDS-resident list: same algorithm with the list in global scratch
+        hipLaunchKernelGGL(k_octree, grid, dim3(ORBX_OCT_THREADS), sort_lds_bytes, s, d_levels, b);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -45,7 +45,9 @@ def _check_frame(ex, orc, img, kps, desc, frame=0, stages=True):
     assert np.array_equal(desc, odesc)
 
 
-@pytest.mark.parametrize("w,h,nf", [(1242, 375, 2000), (752, 480, 1000), (640, 200, 500)])
+# 6000 features: per-level quotas too large for the LDS-resident quadtree -> global-scratch kernel
+@pytest.mark.parametrize("w,h,nf", [(1242, 375, 2000), (752, 480, 1000), (640, 200, 500), (1242, 375, 6000),
+                                    (1242, 375, 4000)])
 def test_single_frame_all_stages(oracle_mod, w, h, nf):
     ex, orc = _mk(oracle_mod, nf, w, h)
     img = synth.make_frames(1, w, h, seed=synth.DEFAULT_SEED + w)[0]
