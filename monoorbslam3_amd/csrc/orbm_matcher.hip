@@ -81,8 +81,14 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t *__restric
     }
 }
 
-// best / second-best per query row, one wave per row.  Partial results merge exactly like the
-// sequential strict-'<' scan: best = smallest (distance, index), second = 2nd smallest distance.
+// best / second-best per query row.  A workgroup owns 32 query rows (8 per wave, descriptors held
+// in scalar registers) and streams the candidate set through LDS in 128-descriptor chunks, so the
+// candidates are read from L2 once per 32 rows instead of once per row.  Per pair: 8 xor + 8
+// v_bcnt_u32_b32 (accumulating) + a branch-free (best, second) update.  Partial results merge
+// exactly like the sequential strict-'<' scan of ORBMatcher.cpp:155-161: best = smallest
+// (distance, index) key, second = 2nd smallest distance.
+#define B2_ROWS 8
+#define B2_CHUNK 128
 __global__ __launch_bounds__(256) void k_best2(const uint8_t *__restrict__ a, size_t a_stride,
                                                const int32_t *__restrict__ na_p, int na_max,
                                                const uint8_t *__restrict__ b, size_t b_stride,
@@ -91,39 +97,80 @@ __global__ __launch_bounds__(256) void k_best2(const uint8_t *__restrict__ a, si
                                                int32_t *__restrict__ best_idx, uint16_t *__restrict__ best,
                                                uint16_t *__restrict__ second)
 {
-    const int p = blockIdx.y;
-    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint4 sb[2][2][B2_CHUNK]; // [buffer][descriptor half][descriptor]
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int na = na_p ? min(na_p[p], na_max) : na_max, nb = nb_p ? min(nb_p[p], nb_max) : nb_max;
-    if (i >= na_max) return;
-    const size_t orow = (size_t)p * a_stride + i;
-    if (i >= na || (row_ok && !row_ok[orow])) {
-        if (lane == 0) { best_idx[orow] = -1; best[orow] = 256; second[orow] = 256; }
-        return;
-    }
-    const Desc256 da = load_desc(a + orow * 32);
+    const int row0 = blockIdx.x * (4 * B2_ROWS) + wave * B2_ROWS;
+    if (blockIdx.x * (4 * B2_ROWS) >= na_max) return;
+    const uint8_t *A = a + (size_t)p * a_stride * 32;
     const uint8_t *B = b + (size_t)p * b_stride * 32;
     const uint8_t *ok = col_ok ? col_ok + (size_t)p * b_stride : nullptr;
-    uint32_t k1 = (256u << 23) | 0x7FFFFFu; // (distance << 23) | index
-    uint32_t s2 = 256;
-    for (int j = lane; j < nb; j += 64) {
-        if (ok && !ok[j]) continue;
-        const uint32_t d = (uint32_t)ham256(da, load_desc(B + (size_t)j * 32));
-        const uint32_t k = (d << 23) | (uint32_t)j;
-        if (k < k1) { s2 = min(s2, k1 >> 23); k1 = k; }
-        else s2 = min(s2, d);
+
+    uint32_t ar[B2_ROWS][8];
+#pragma unroll
+    for (int r = 0; r < B2_ROWS; ++r) {
+        const int row = min(row0 + r, max(na_max - 1, 0)); // clamped rows are computed but never stored
+        const uint32_t *pa = reinterpret_cast<const uint32_t *>(A + (size_t)row * 32);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) ar[r][w] = __builtin_amdgcn_readfirstlane(pa[w]);
+    }
+    const uint32_t SENT = (256u << 23) | 0x7FFFFFu;
+    uint32_t k1[B2_ROWS], s2[B2_ROWS];
+#pragma unroll
+    for (int r = 0; r < B2_ROWS; ++r) { k1[r] = SENT; s2[r] = 256; }
+
+    const int n_chunks = (nb + B2_CHUNK - 1) / B2_CHUNK;
+    auto stage = [&](int chunk, int buf) {
+        const int j = chunk * B2_CHUNK + (tid >> 1);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (j < nb) v = *reinterpret_cast<const uint4 *>(B + (size_t)j * 32 + (tid & 1) * 16);
+        sb[buf][tid & 1][tid >> 1] = v;
+    };
+    if (n_chunks > 0) stage(0, 0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) stage(c + 1, buf ^ 1);
+#pragma unroll
+        for (int h = 0; h < B2_CHUNK / 64; ++h) {
+            const int jl = h * 64 + lane, j = c * B2_CHUNK + jl;
+            const uint4 lo = sb[buf][0][jl], hi = sb[buf][1][jl];
+            const bool valid = j < nb && (!ok || ok[j]);
+#pragma unroll
+            for (int r = 0; r < B2_ROWS; ++r) {
+                uint32_t d = __popc(lo.x ^ ar[r][0]);
+                d += __popc(lo.y ^ ar[r][1]); d += __popc(lo.z ^ ar[r][2]); d += __popc(lo.w ^ ar[r][3]);
+                d += __popc(hi.x ^ ar[r][4]); d += __popc(hi.y ^ ar[r][5]); d += __popc(hi.z ^ ar[r][6]);
+                d += __popc(hi.w ^ ar[r][7]);
+                const uint32_t k = valid ? ((d << 23) | (uint32_t)j) : SENT;
+                const uint32_t mn = min(k, k1[r]), mx = max(k, k1[r]);
+                k1[r] = mn;
+                s2[r] = min(s2[r], mx >> 23);
+            }
+        }
+        __syncthreads();
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t ok1 = __shfl_xor(k1, o), os2 = __shfl_xor(s2, o);
-        const uint32_t lo = min(k1, ok1), hi = max(k1, ok1);
-        s2 = min(min(s2, os2), hi >> 23);
-        k1 = lo;
-    }
-    if (lane == 0) {
-        const uint32_t d1 = k1 >> 23;
-        best_idx[orow] = d1 < 256 ? (int32_t)(k1 & 0x7FFFFFu) : -1; // a 256-distance candidate never beats the initial 256
-        best[orow] = (uint16_t)min(d1, 256u);
-        second[orow] = (uint16_t)min(s2, 256u);
+    for (int r = 0; r < B2_ROWS; ++r) {
+        uint32_t kk = k1[r], ss = s2[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t ok1 = __shfl_xor(kk, o), os2 = __shfl_xor(ss, o);
+            const uint32_t mn = min(kk, ok1), mx = max(kk, ok1);
+            ss = min(min(ss, os2), mx >> 23);
+            kk = mn;
+        }
+        const int row = row0 + r;
+        if (lane == 0 && row < na_max) {
+            const size_t orow = (size_t)p * a_stride + row;
+            const bool live = row < na && (!row_ok || row_ok[orow]);
+            const uint32_t d1 = kk >> 23;
+            // a 256-distance candidate never beats the initial 256 of the reference loop
+            best_idx[orow] = (live && d1 < 256) ? (int32_t)(kk & 0x7FFFFFu) : -1;
+            best[orow] = live ? (uint16_t)min(d1, 256u) : (uint16_t)256;
+            second[orow] = live ? (uint16_t)min(ss, 256u) : (uint16_t)256;
+        }
     }
 }
 
@@ -238,7 +285,7 @@ extern "C" int orbm_best2_device(orbm_t *c, int n_pairs, const uint8_t *d_a, siz
     if (nb_max >= (1 << 23)) return orbx_set_error(ORBX_E_UNSUPPORTED, "more than 2^23 candidates per problem");
     if (na_max == 0) return ORBX_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    dim3 grid((na_max + 3) / 4, n_pairs);
+    dim3 grid((na_max + 4 * B2_ROWS - 1) / (4 * B2_ROWS), n_pairs);
     hipLaunchKernelGGL(k_best2, grid, dim3(256), 0, s, d_a, a_stride, d_na, na_max, d_b, b_stride, d_nb, nb_max,
                        d_row_ok, d_col_ok, d_best_idx, d_best, d_second);
     M_TRY(hipGetLastError());

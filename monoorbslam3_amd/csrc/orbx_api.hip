@@ -47,6 +47,8 @@ struct orbx_ctx {
     OrbxLevels *d_levels;
     OrbxTap *d_xtap[ORBX_MAX_LEVELS], *d_ytap[ORBX_MAX_LEVELS];
     int *d_umax, *d_taps;
+    uint16_t *d_fast_segs; int n_fast_segs;
+    uint16_t *d_blur_tiles; int n_blur_tiles;
     uint8_t *d_l0_stage; size_t l0_stage_fs;
     orbx_kp *d_out_kp; uint8_t *d_out_desc; int32_t *d_out_n; int out_cap;
     // capacities actually allocated
@@ -270,6 +272,22 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
         c->l0_stage_pitch = g.l0_pitch;
         c->sort_lds_bytes = g.sort_lds;
         HIP_TRY(hipMemcpy(c->d_levels, &c->levels, sizeof(OrbxLevels), hipMemcpyHostToDevice));
+        {
+            const int ns = orbx_build_fast_segments(c->levels, nullptr);
+            std::vector<uint16_t> segs((size_t)std::max(ns, 1) * 4);
+            orbx_build_fast_segments(c->levels, segs.data());
+            HIP_TRY(dev_alloc(&c->d_fast_segs, segs.size()));
+            HIP_TRY(hipMemcpy(c->d_fast_segs, segs.data(), segs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            c->n_fast_segs = ns;
+        }
+        {
+            const int nt = orbx_build_blur_tiles(c->levels, nullptr);
+            std::vector<uint16_t> tl((size_t)std::max(nt, 1) * 4);
+            orbx_build_blur_tiles(c->levels, tl.data());
+            HIP_TRY(dev_alloc(&c->d_blur_tiles, tl.size()));
+            HIP_TRY(hipMemcpy(c->d_blur_tiles, tl.data(), tl.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            c->n_blur_tiles = nt;
+        }
         std::vector<OrbxTap> taps;
         for (int l = 1; l < c->levels.n_levels; ++l) {
             const OrbxLevel &d = c->levels.lv[l], &s = c->levels.lv[l - 1];
@@ -357,7 +375,7 @@ extern "C" void orbx_destroy(orbx_t *c)
     OrbxBuffers &b = c->buf;
     void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.pcode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
                     b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.sel_count, c->d_levels, c->d_umax, c->d_taps,
-                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n};
+                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n, c->d_fast_segs, c->d_blur_tiles};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         if (c->d_xtap[l]) (void)hipFree(c->d_xtap[l]);
@@ -424,18 +442,9 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
                            n_frames);
     }
     if (t) HIP_TRY(hipEventRecord(c->ev[1], s));
-    for (int l = 0; l < L; ++l) {
-        const uint8_t *sp; size_t sfs; int spitch;
-        raw(l, &sp, &sfs, &spitch);
-        orbx_launch_fast(s, sp, sfs, spitch, LV.lv[l], l, ORBX_MAX_LEVELS, b, LV.ini_th, LV.min_th, n_frames);
-    }
+    orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_segs, c->n_fast_segs, n_frames);
     if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
-    for (int l = 0; l < L; ++l) {
-        const uint8_t *sp; size_t sfs; int spitch;
-        raw(l, &sp, &sfs, &spitch);
-        orbx_launch_blur(s, sp, sfs, spitch, b.img_arena + LV.lv[l].blur_off, b.img_frame_stride, LV.lv[l].pitch,
-                         LV.lv[l].w, LV.lv[l].h, c->d_taps, n_frames);
-    }
+    orbx_launch_blur(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames);
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));
     orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes);
     if (t) HIP_TRY(hipEventRecord(c->ev[4], s));

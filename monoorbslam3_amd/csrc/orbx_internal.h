@@ -64,10 +64,13 @@ struct OrbxBuffers {
 void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh,
                         uint8_t *dst, size_t dst_fs, int dst_pitch, int dw, int dh,
                         const OrbxTap *xtap, const OrbxTap *ytap, int n_frames);
-void orbx_launch_fast(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, const OrbxLevel &lv, int level,
-                      int n_levels, const OrbxBuffers &b, int ini_th, int min_th, int n_frames);
-void orbx_launch_blur(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, uint8_t *dst, size_t dst_fs,
-                      int dst_pitch, int w, int h, const int *taps7, int n_frames);
+void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
+                      const OrbxLevels &levels, const OrbxBuffers &b, const void *d_segs, int n_segs, int n_frames);
+int orbx_build_fast_segments(const OrbxLevels &levels, uint16_t *out);
+void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
+                      const OrbxLevels &levels, const OrbxBuffers &b, const void *d_tiles, int n_tiles, const int *taps7,
+                      int n_frames);
+int orbx_build_blur_tiles(const OrbxLevels &levels, uint16_t *out);
 void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLevels &levels, const OrbxBuffers &b,
                         int n_frames, size_t sort_lds_bytes);
 void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,

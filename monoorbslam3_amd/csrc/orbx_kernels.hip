@@ -62,8 +62,10 @@ void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int sr
 // "corner at t" <=> S >= t, and OpenCV's stored score of a corner is S for every t,
 // so one strength tile answers both the ini and the min threshold of a cell.
 // ---------------------------------------------------------------------------------------------
-#define FAST_TP 40 // LDS tile pitch (36 used)
 
+#ifndef FAST_TP
+#define FAST_TP 256
+#endif
 __device__ __forceinline__ int fast_strength(const uint8_t *t /* centre pixel in the LDS tile */, int tlow)
 {
     const int v = t[0];
@@ -98,85 +100,223 @@ __device__ __forceinline__ int fast_strength(const uint8_t *t /* centre pixel in
     return s >= tlow ? s : 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ src, size_t src_fs, int src_pitch,
-                                                    OrbxLevel lv, int level, int n_levels, u64 *__restrict__ cand,
-                                                    size_t cand_fs, int *__restrict__ cand_count, int ini_th,
-                                                    int min_th)
+// One workgroup = one strip segment: up to FAST_SEG horizontally adjacent cells of one cell row of
+// one level of one frame; a single launch covers every level (segment table).  Steps:
+//   1. the (30+6)-row tile goes HBM -> LDS with dword loads (the segment's left edge is 16-byte
+//      aligned in level coordinates because 30*FAST_SEG is a multiple of 16);
+//   2. every pixel takes the 4-point compass test (any 9-arc holds two adjacent compass points);
+//      survivors are compacted into an LDS queue with wave64 ballot + popcount;
+//   3. queue entries get the exact strength (dense lanes, no divergence on flat image areas);
+//   4. strict 3x3 NMS inside each cell, per-cell "anything at the ini threshold?" vote, emission.
+#define FAST_SEG 8
+// FAST_TP (defined above) = tile pitch in bytes: 8*30 + 6 = 246 used
+#define FAST_SP 256                    // score-map pitch: 1 + 240 + 1 used
+#define FAST_QCAP (FAST_SEG * 30 * 30) // every pixel may survive the compass test
+
+struct FastSeg { // one strip segment
+    uint16_t level, cy, cx0, ncells;
+};
+struct FastSrc {
+    const uint8_t *base[ORBX_MAX_LEVELS];
+    size_t frame_stride[ORBX_MAX_LEVELS];
+    int pitch[ORBX_MAX_LEVELS];
+};
+struct __attribute__((packed, aligned(1))) UnalignedU32 { uint32_t v; };
+
+__global__ __launch_bounds__(256) void k_fast_strips(FastSrc src, const OrbxLevels *__restrict__ levels,
+                                                     const FastSeg *__restrict__ segs, u64 *__restrict__ cand,
+                                                     size_t cand_fs, int *__restrict__ cand_count)
 {
-    __shared__ uint8_t tile[36 * FAST_TP];
-    __shared__ uint8_t score[32 * 32]; // cell + 1-px ring of zeros
-    __shared__ int s_n_ini, s_n_emit, s_base;
+    __shared__ __align__(16) uint8_t tile[36 * FAST_TP];
+    __shared__ __align__(16) uint8_t score[32 * FAST_SP];
+    __shared__ uint16_t queue[FAST_QCAP];
+    __shared__ int s_qn, s_n_emit, s_base;
+    __shared__ int s_n_ini[FAST_SEG];
 
-    const int frame = blockIdx.z;
-    const int cx = blockIdx.x, cy = blockIdx.y;
-    const int x0 = ORBX_EDGE + cx * ORBX_CELL, y0 = ORBX_EDGE + cy * ORBX_CELL;
-    const int cw = min(ORBX_CELL, lv.w - ORBX_EDGE - x0), ch = min(ORBX_CELL, lv.h - ORBX_EDGE - y0);
-    const uint8_t *S = src + (size_t)frame * src_fs;
-    const int tid = threadIdx.x;
-    const int tlow = min(ini_th, min_th);
+    const FastSeg sg = segs[blockIdx.x];
+    const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int level = sg.level;
+    const OrbxLevel &lv = levels->lv[level];
+    const int ini_th = levels->ini_th, min_th = levels->min_th, tlow = min(ini_th, min_th);
+    const int x0 = ORBX_EDGE + sg.cx0 * ORBX_CELL, y0 = ORBX_EDGE + sg.cy * ORBX_CELL;
+    const int wpx = min(sg.ncells * ORBX_CELL, lv.w - ORBX_EDGE - x0); // pixels of the region in this segment
+    const int hpx = min(ORBX_CELL, lv.h - ORBX_EDGE - y0);
+    const int tw = wpx + 6, th = hpx + 6;
+    const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level] + (size_t)(y0 - 3) * src.pitch[level] +
+                       (x0 - 3);
+    const int pitch = src.pitch[level];
 
-    for (int i = tid; i < 32 * 32 / 4; i += 256) reinterpret_cast<uint32_t *>(score)[i] = 0;
-    if (tid == 0) { s_n_ini = 0; s_n_emit = 0; }
-    const int tw = cw + 6, th = ch + 6;
-    for (int i = tid; i < tw * th; i += 256) {
-        const int ty = i / tw, tx = i - ty * tw;
-        tile[ty * FAST_TP + tx] = S[(size_t)(y0 - 3 + ty) * src_pitch + (x0 - 3 + tx)];
-    }
-    __syncthreads();
-    for (int i = tid; i < cw * ch; i += 256) {
-        const int py = i / cw, px = i - py * cw;
-        score[(py + 1) * 32 + px + 1] = (uint8_t)fast_strength(&tile[(py + 3) * FAST_TP + px + 3], tlow);
-    }
-    __syncthreads();
-    // 3x3 strict NMS inside the cell; remember each thread's (up to 4) survivors
-    uint32_t mine[4];
-    int n_mine = 0, n_ini = 0;
-    for (int i = tid; i < cw * ch; i += 256) {
-        const int py = i / cw, px = i - py * cw;
-        const uint8_t *s = &score[(py + 1) * 32 + px + 1];
-        const int sc = s[0];
-        if (sc > 0 && sc > s[-1] && sc > s[1] && sc > s[-33] && sc > s[-32] && sc > s[-31] && sc > s[31] &&
-            sc > s[32] && sc > s[33]) {
-            mine[n_mine++] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc << 16);
-            n_ini += sc >= ini_th;
+    for (int i = tid; i < 32 * FAST_SP / 16; i += 256) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) { s_qn = 0; s_n_emit = 0; }
+    if (tid < FAST_SEG) s_n_ini[tid] = 0;
+    // ---- 1. tile load: dwords while a whole dword is inside the image row, bytes for the tail
+    {
+        const int dw_per_row = (tw + 3) >> 2;
+        const int row_left = lv.w - (x0 - 3); // bytes from the tile's left edge to the end of the image row
+        for (int i = tid; i < dw_per_row * th; i += 256) {
+            const int ty = i / dw_per_row, tx = (i - ty * dw_per_row) * 4;
+            const uint8_t *p = S + (size_t)ty * pitch + tx;
+            uint32_t v;
+            if (tx + 4 <= row_left) v = reinterpret_cast<const UnalignedU32 *>(p)->v;
+            else {
+                v = 0;
+                for (int k = 0; k < row_left - tx; ++k) v |= (uint32_t)p[k] << (8 * k);
+            }
+            *reinterpret_cast<uint32_t *>(&tile[ty * FAST_TP + tx]) = v;
         }
     }
-    if (n_ini) atomicAdd(&s_n_ini, n_ini);
     __syncthreads();
-    const int thr = s_n_ini > 0 ? ini_th : min_th; // reference :604-607 -- retry the cell at the min threshold
-    int keep = 0;
-    for (int k = 0; k < n_mine; ++k) keep += (int)(mine[k] >> 16) >= thr;
-    int slot = 0;
-    if (keep) slot = atomicAdd(&s_n_emit, keep);
-    __syncthreads();
-    if (tid == 0 && s_n_emit > 0) s_base = atomicAdd(&cand_count[frame * n_levels + level], s_n_emit);
-    __syncthreads();
-    if (keep) {
-        u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + s_base + slot;
-        for (int k = 0; k < n_mine; ++k) {
-            const int sc = mine[k] >> 16;
-            if (sc >= thr) {
-                const uint32_t x = cx * ORBX_CELL + (mine[k] & 255), y = cy * ORBX_CELL + ((mine[k] >> 8) & 255);
-                *out++ = (u64)(x | (y << 16)) | ((u64)sc << 32);
+    // ---- 2. compass test, 4 pixels per lane per step; tile column = region column + 3
+    {
+        const int runs_per_row = (wpx + 3 + 3) >> 2; // dword columns covering tile columns [0, wpx+3)
+        const int n_runs = runs_per_row * hpx;
+        for (int i0 = 0; i0 < n_runs; i0 += 256) {
+            const int i = i0 + tid;
+            uint32_t pass = 0;
+            int r = 0, g = 0;
+            if (i < n_runs) {
+                r = i / runs_per_row; g = i - r * runs_per_row;
+                const uint8_t *row = &tile[(r + 3) * FAST_TP + 4 * g];
+                const uint32_t cm = g > 0 ? *reinterpret_cast<const uint32_t *>(row - 4) : 0u;
+                const uint32_t c0 = *reinterpret_cast<const uint32_t *>(row);
+                const uint32_t cp = *reinterpret_cast<const uint32_t *>(row + 4);
+                const uint32_t up = *reinterpret_cast<const uint32_t *>(row - 3 * FAST_TP);
+                const uint32_t dn = *reinterpret_cast<const uint32_t *>(row + 3 * FAST_TP);
+                const u64 wide = ((u64)cp << 32) | c0; // bytes 0..7 from the run start
+                const u64 widem = ((u64)c0 << 32) | cm; // bytes -4..3
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int v = (c0 >> (8 * k)) & 255;
+                    const int dE = v - (int)((wide >> (8 * (k + 3))) & 255);  // (+3, 0)
+                    const int dW = v - (int)((widem >> (8 * (k + 1))) & 255); // (-3, 0)
+                    const int dS = v - (int)((dn >> (8 * k)) & 255);          // (0, +3)
+                    const int dN = v - (int)((up >> (8 * k)) & 255);          // (0, -3)
+                    const int hi = min(max(dS, dN), max(dE, dW)), lo = max(min(dS, dN), min(dE, dW));
+                    const int col = 4 * g + k - 3; // region column
+                    const bool ok = (hi > tlow || lo < -tlow) && col >= 0 && col < wpx;
+                    pass |= (uint32_t)ok << k;
+                }
             }
+            // wave64 compaction: every lane holds a 4-bit mask
+            const int cnt = __popc(pass);
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(incl, o);
+                if (lane >= o) incl += y;
+            }
+            const int wave_total = __shfl(incl, 63);
+            int base = 0;
+            if (lane == 63 && wave_total) base = atomicAdd(&s_qn, wave_total);
+            base = __shfl(base, 63);
+            int slot = base + incl - cnt;
+            uint32_t m = pass;
+            while (m) {
+                const int k = __ffs(m) - 1;
+                m &= m - 1;
+                queue[slot++] = (uint16_t)((r << 8) | (4 * g + k - 3));
+            }
+        }
+    }
+    __syncthreads();
+    const int qn = s_qn;
+    // ---- 3. exact strength of the survivors
+    for (int i = tid; i < qn; i += 256) {
+        const int e = queue[i], r = e >> 8, col = e & 255;
+        const int sc = fast_strength(&tile[(r + 3) * FAST_TP + col + 3], tlow);
+        score[(r + 1) * FAST_SP + col + 1] = (uint8_t)sc;
+    }
+    __syncthreads();
+    // ---- 4. NMS inside each 30-px cell, vote, emission
+    uint32_t keepers[(FAST_QCAP + 255) / 256 > 8 ? 8 : (FAST_QCAP + 255) / 256];
+    int n_keep = 0;
+    // a thread sees at most ceil(qn/256) entries; local maxima are at most 1 in 4 of them, but keep it simple:
+    // survivors beyond the private list are re-derived in the emission loop
+    for (int i = tid; i < qn; i += 256) {
+        const int e = queue[i], r = e >> 8, col = e & 255;
+        const uint8_t *sp = &score[(r + 1) * FAST_SP + col + 1];
+        const int sc = sp[0];
+        bool keep = false;
+        if (sc > 0) {
+            const int xin = col % ORBX_CELL;
+            const bool l = xin != 0, rr = xin != ORBX_CELL - 1; // neighbours in the adjacent cell count as 0
+            keep = sc > sp[-FAST_SP] && sc > sp[FAST_SP] && (!l || (sc > sp[-1] && sc > sp[-FAST_SP - 1] && sc > sp[FAST_SP - 1])) &&
+                   (!rr || (sc > sp[1] && sc > sp[-FAST_SP + 1] && sc > sp[FAST_SP + 1]));
+        }
+        if (keep && sc >= ini_th) atomicAdd(&s_n_ini[col / ORBX_CELL], 1);
+        queue[i] = keep ? (uint16_t)e : (uint16_t)0xFFFF; // rows < 30, so 0xFFFF never is a valid entry
+        (void)keepers; (void)n_keep;
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < qn; i += 256) {
+        const int e = queue[i];
+        if (e == 0xFFFF) continue;
+        const int r = e >> 8, col = e & 255;
+        const int sc = score[(r + 1) * FAST_SP + col + 1];
+        const int thr = s_n_ini[col / ORBX_CELL] > 0 ? ini_th : min_th; // reference :604-607
+        if (sc >= thr) ++mine; else queue[i] = 0xFFFF;
+    }
+    int slot = 0;
+    if (mine) slot = atomicAdd(&s_n_emit, mine);
+    __syncthreads();
+    if (tid == 0 && s_n_emit > 0) s_base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], s_n_emit);
+    __syncthreads();
+    if (mine) {
+        u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + s_base + slot;
+        for (int i = tid; i < qn; i += 256) {
+            const int e = queue[i];
+            if (e == 0xFFFF) continue;
+            const int r = e >> 8, col = e & 255;
+            const uint32_t sc = score[(r + 1) * FAST_SP + col + 1];
+            const uint32_t x = sg.cx0 * ORBX_CELL + col, y = sg.cy * ORBX_CELL + r;
+            *out++ = (u64)(x | (y << 16)) | ((u64)sc << 32);
         }
     }
 }
 
-void orbx_launch_fast(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, const OrbxLevel &lv, int level,
-                      int n_levels, const OrbxBuffers &b, int ini_th, int min_th, int n_frames)
+void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
+                      const OrbxLevels &levels, const OrbxBuffers &b, const void *d_segs, int n_segs, int n_frames)
 {
-    if (lv.n_cols <= 0 || lv.n_rows <= 0) return;
-    dim3 grid(lv.n_cols, lv.n_rows, n_frames);
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, src, src_fs, src_pitch, lv, level, n_levels, b.cand,
-                       b.cand_frame_stride, b.cand_count, ini_th, min_th);
+    if (n_segs <= 0) return;
+    FastSrc src;
+    for (int l = 0; l < levels.n_levels; ++l) {
+        src.base[l] = l == 0 ? l0 : b.img_arena + levels.lv[l].raw_off;
+        src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
+        src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
+    }
+    hipLaunchKernelGGL(k_fast_strips, dim3(n_segs, n_frames), dim3(256), 0, s, src, d_levels,
+                       reinterpret_cast<const FastSeg *>(d_segs), b.cand, b.cand_frame_stride, b.cand_count);
+}
+
+// host side: segment table for the current geometry (4 x uint16 per segment)
+int orbx_build_fast_segments(const OrbxLevels &levels, uint16_t *out /* 4 per segment, or NULL to count */)
+{
+    int n = 0;
+    for (int l = 0; l < levels.n_levels; ++l) {
+        const OrbxLevel &v = levels.lv[l];
+        for (int cy = 0; cy < v.n_rows; ++cy)
+            for (int cx0 = 0; cx0 < v.n_cols; cx0 += FAST_SEG) {
+                if (out) {
+                    out[4 * n + 0] = (uint16_t)l; out[4 * n + 1] = (uint16_t)cy; out[4 * n + 2] = (uint16_t)cx0;
+                    out[4 * n + 3] = (uint16_t)((v.n_cols - cx0) < FAST_SEG ? (v.n_cols - cx0) : FAST_SEG);
+                }
+                ++n;
+            }
+    }
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------------
 // 7x7 Gaussian, 8.8 fixed-point taps, BORDER_REFLECT_101: H pass exact in u16, V pass rounded >>16
 // ---------------------------------------------------------------------------------------------
 #define BL_W 64
-#define BL_H 16
+#define BL_H 32
+#define BL_RP 80 // raw tile pitch: tile column rc <-> level x = x0 - 8 + rc
+struct BlurTile {
+    uint16_t level, tx, ty, pad;
+};
+
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     if (len == 1) return 0;
@@ -184,51 +324,104 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_blur7(const uint8_t *__restrict__ src, size_t src_fs, int src_pitch,
-                                               uint8_t *__restrict__ dst, size_t dst_fs, int dst_pitch, int w,
-                                               int h, const int *__restrict__ taps)
+// One workgroup = one 64x32 output tile of one level of one frame; one launch covers all levels.
+// H pass: two v_dot4_u32_u8 per pixel on byte windows built with v_alignbyte; exact u16 results in LDS.
+// V pass: 7 multiply-adds per pixel, (sum + 2^15) >> 16, four pixels stored as one dword.
+__global__ __launch_bounds__(256) void k_blur_tiles(FastSrc src, const OrbxLevels *__restrict__ levels,
+                                                    const BlurTile *__restrict__ tiles, uint8_t *__restrict__ arena,
+                                                    size_t arena_fs, const int *__restrict__ taps)
 {
-    __shared__ uint8_t raw[(BL_H + 6) * (BL_W + 8)];
-    __shared__ uint16_t hor[(BL_H + 6) * BL_W];
-    const uint8_t *S = src + (size_t)blockIdx.z * src_fs;
-    uint8_t *D = dst + (size_t)blockIdx.z * dst_fs;
-    const int x0 = blockIdx.x * BL_W, y0 = blockIdx.y * BL_H;
-    const int tid = threadIdx.x;
+    __shared__ __align__(16) uint8_t raw[(BL_H + 6) * BL_RP];
+    __shared__ __align__(16) uint16_t hor[(BL_H + 6) * BL_W];
+    const BlurTile t = tiles[blockIdx.x];
+    const int frame = blockIdx.y, tid = threadIdx.x, level = t.level;
+    const OrbxLevel &lv = levels->lv[level];
+    const int w = lv.w, h = lv.h, pitch = src.pitch[level];
+    const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level];
+    uint8_t *D = arena + (size_t)frame * arena_fs + lv.blur_off;
+    const int x0 = t.tx * BL_W, y0 = t.ty * BL_H;
     int k[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) k[i] = taps[i];
-    for (int i = tid; i < (BL_H + 6) * (BL_W + 6); i += 256) {
-        const int ty = i / (BL_W + 6), tx = i - ty * (BL_W + 6);
-        const int sx = reflect101(x0 - 3 + tx, w), sy = reflect101(y0 - 3 + ty, h);
-        raw[ty * (BL_W + 8) + tx] = S[(size_t)sy * src_pitch + sx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (BL_H + 6) * BL_W; i += 256) {
-        const int ty = i / BL_W, tx = i - ty * BL_W;
-        const uint8_t *r = &raw[ty * (BL_W + 8) + tx];
-        uint32_t acc = 0;
+    const uint32_t K0 = (uint32_t)k[0] | ((uint32_t)k[1] << 8) | ((uint32_t)k[2] << 16) | ((uint32_t)k[3] << 24);
+    const uint32_t K1 = (uint32_t)k[4] | ((uint32_t)k[5] << 8) | ((uint32_t)k[6] << 16);
+
+    for (int i = tid; i < (BL_H + 6) * (BL_RP / 4); i += 256) {
+        const int ry = i / (BL_RP / 4), dc = i - ry * (BL_RP / 4);
+        const int gx = x0 - 8 + 4 * dc;
+        const uint8_t *row = S + (size_t)reflect101(y0 - 3 + ry, h) * pitch;
+        uint32_t v;
+        if (gx >= 0 && gx + 3 < w) v = reinterpret_cast<const UnalignedU32 *>(row + gx)->v;
+        else {
+            v = 0;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) acc += (uint32_t)k[j] * r[j];
-        hor[i] = (uint16_t)min(acc, 65535u);
-    }
-    __syncthreads();
-    for (int i = tid; i < BL_H * BL_W; i += 256) {
-        const int ty = i / BL_W, tx = i - ty * BL_W;
-        const int x = x0 + tx, y = y0 + ty;
-        if (x < w && y < h) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) acc += (uint32_t)k[j] * hor[(ty + j) * BL_W + tx];
-            D[(size_t)y * dst_pitch + x] = (uint8_t)min((acc + (1u << 15)) >> 16, 255u);
+            for (int b = 0; b < 4; ++b) v |= (uint32_t)row[reflect101(gx + b, w)] << (8 * b);
         }
+        *reinterpret_cast<uint32_t *>(&raw[ry * BL_RP + 4 * dc]) = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < (BL_H + 6) * (BL_W / 4); i += 256) {
+        const int ry = i / (BL_W / 4), g = i - ry * (BL_W / 4);
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(&raw[ry * BL_RP + 4 + 4 * g]); // bytes x-4 .. x+7
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        uint32_t o[4];
+        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false), false);
+        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false), false);
+        o[3] = __builtin_amdgcn_udot4(d2, K1, __builtin_amdgcn_udot4(d1, K0, 0u, false), false);
+        uint2 st;
+        st.x = min(o[0], 65535u) | (min(o[1], 65535u) << 16);
+        st.y = min(o[2], 65535u) | (min(o[3], 65535u) << 16);
+        *reinterpret_cast<uint2 *>(&hor[ry * BL_W + 4 * g]) = st;
+    }
+    __syncthreads();
+    for (int i = tid; i < BL_H * (BL_W / 4); i += 256) {
+        const int ty = i / (BL_W / 4), g = i - ty * (BL_W / 4);
+        const int x = x0 + 4 * g, y = y0 + ty;
+        if (x >= w || y >= h) continue;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const uint2 hv = *reinterpret_cast<const uint2 *>(&hor[(ty + j) * BL_W + 4 * g]);
+            a0 += (uint32_t)k[j] * (hv.x & 0xFFFF);
+            a1 += (uint32_t)k[j] * (hv.x >> 16);
+            a2 += (uint32_t)k[j] * (hv.y & 0xFFFF);
+            a3 += (uint32_t)k[j] * (hv.y >> 16);
+        }
+        const uint32_t r0 = min((a0 + 32768u) >> 16, 255u), r1 = min((a1 + 32768u) >> 16, 255u);
+        const uint32_t r2 = min((a2 + 32768u) >> 16, 255u), r3 = min((a3 + 32768u) >> 16, 255u);
+        // rows of the arena are padded to a multiple of 64 bytes: the dword store stays inside the row
+        *reinterpret_cast<uint32_t *>(D + (size_t)y * lv.pitch + x) = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
     }
 }
 
-void orbx_launch_blur(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, uint8_t *dst, size_t dst_fs,
-                      int dst_pitch, int w, int h, const int *taps7, int n_frames)
+void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
+                      const OrbxLevels &levels, const OrbxBuffers &b, const void *d_tiles, int n_tiles, const int *taps7,
+                      int n_frames)
 {
-    dim3 grid((w + BL_W - 1) / BL_W, (h + BL_H - 1) / BL_H, n_frames);
-    hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, s, src, src_fs, src_pitch, dst, dst_fs, dst_pitch, w, h, taps7);
+    if (n_tiles <= 0) return;
+    FastSrc src;
+    for (int l = 0; l < levels.n_levels; ++l) {
+        src.base[l] = l == 0 ? l0 : b.img_arena + levels.lv[l].raw_off;
+        src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
+        src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
+    }
+    hipLaunchKernelGGL(k_blur_tiles, dim3(n_tiles, n_frames), dim3(256), 0, s, src, d_levels,
+                       reinterpret_cast<const BlurTile *>(d_tiles), b.img_arena, b.img_frame_stride, taps7);
+}
+
+int orbx_build_blur_tiles(const OrbxLevels &levels, uint16_t *out /* 4 per tile, or NULL to count */)
+{
+    int n = 0;
+    for (int l = 0; l < levels.n_levels; ++l) {
+        const OrbxLevel &v = levels.lv[l];
+        for (int ty = 0; ty < (v.h + BL_H - 1) / BL_H; ++ty)
+            for (int tx = 0; tx < (v.w + BL_W - 1) / BL_W; ++tx) {
+                if (out) { out[4 * n] = (uint16_t)l; out[4 * n + 1] = (uint16_t)tx; out[4 * n + 2] = (uint16_t)ty; out[4 * n + 3] = 0; }
+                ++n;
+            }
+    }
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -302,7 +495,7 @@ __device__ void oct_child_counts(const OctCtx &c, int cur, int nrank)
     for (int p = threadIdx.x; p < c.n; p += ORBX_OCT_THREADS) {
         const int old = c.pnode[p];
         const int r = c.rank[old];
-        if (r >= 0) atomicAdd(&c.childcnt[4 * r + oct_quadrant(c.cand[p], c.bnd[cur][old])], 1);
+        if (r >= 0) atomicAdd(&c.childcnt[4 * r + oct_quadrant(c.cand[p], (cur ? c.bnd[1] : c.bnd[0])[old])], 1);
     }
     __syncthreads();
 }
@@ -335,8 +528,8 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nsplit, int *n
         const int n = c.childcnt[i];
         if (n > 0) {
             const int pos = T - 1 - ci;
-            c.bnd[nxt][pos] = oct_child_bounds(c.bnd[cur][c.node_of_rank[i >> 2]], i & 3);
-            c.cnt[nxt][pos] = n;
+            (nxt ? c.bnd[1] : c.bnd[0])[pos] = oct_child_bounds((cur ? c.bnd[1] : c.bnd[0])[c.node_of_rank[i >> 2]], i & 3);
+            (nxt ? c.cnt[1] : c.cnt[0])[pos] = n;
             c.childpos[i] = pos;
             ++ci;
         }
@@ -345,8 +538,8 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nsplit, int *n
         const int r = c.rank[j];
         if (!(r >= 0 && r < nsplit)) {
             const int pos = T + ui;
-            c.bnd[nxt][pos] = c.bnd[cur][j];
-            c.cnt[nxt][pos] = c.cnt[cur][j];
+            (nxt ? c.bnd[1] : c.bnd[0])[pos] = (cur ? c.bnd[1] : c.bnd[0])[j];
+            (nxt ? c.cnt[1] : c.cnt[0])[pos] = (cur ? c.cnt[1] : c.cnt[0])[j];
             c.newpos[j] = pos;
             ++ui;
         }
@@ -355,7 +548,7 @@ __device__ void oct_apply(const OctCtx &c, int cur, int size, int nsplit, int *n
     for (int p = threadIdx.x; p < c.n; p += ORBX_OCT_THREADS) {
         const int old = c.pnode[p];
         const int r = c.rank[old];
-        c.pnode[p] = (r >= 0 && r < nsplit) ? c.childpos[4 * r + oct_quadrant(c.cand[p], c.bnd[cur][old])]
+        c.pnode[p] = (r >= 0 && r < nsplit) ? c.childpos[4 * r + oct_quadrant(c.cand[p], (cur ? c.bnd[1] : c.bnd[0])[old])]
                                             : c.newpos[old];
     }
     __syncthreads();
@@ -412,8 +605,8 @@ __global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree(const OrbxLevels *_
                 bb.x = (short)(lv.h_x * i); bb.y = 0;
                 bb.z = (short)((i == lv.n_ini - 1) ? (lv.w - ORBX_EDGE) : lv.h_x * (i + 1)); // :665 absolute maxX
                 bb.w = (short)lv.region_h;
-                c.bnd[cur][pos] = bb;
-                c.cnt[cur][pos] = c.childcnt[i];
+                (cur ? c.bnd[1] : c.bnd[0])[pos] = bb;
+                (cur ? c.cnt[1] : c.cnt[0])[pos] = c.childcnt[i];
                 c.newpos[i] = pos++;
             }
         }
@@ -429,11 +622,11 @@ __global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree(const OrbxLevels *_
         const int chunk = (size + ORBX_OCT_THREADS - 1) / ORBX_OCT_THREADS;
         const int j0 = min(tid * chunk, size), j1 = min(j0 + chunk, size);
         int s = 0;
-        for (int j = j0; j < j1; ++j) s += c.cnt[cur][j] > 1;
+        for (int j = j0; j < j1; ++j) s += (cur ? c.cnt[1] : c.cnt[0])[j] > 1;
         int nsplit;
         int r = block_scan_excl(s, &nsplit, lds);
         for (int j = j0; j < j1; ++j) {
-            if (c.cnt[cur][j] > 1) { c.rank[j] = r; c.node_of_rank[r] = j; ++r; }
+            if ((cur ? c.cnt[1] : c.cnt[0])[j] > 1) { c.rank[j] = r; c.node_of_rank[r] = j; ++r; }
             else c.rank[j] = -1;
         }
         __syncthreads();
@@ -450,7 +643,7 @@ __global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree(const OrbxLevels *_
                 const int ch2 = (size + ORBX_OCT_THREADS - 1) / ORBX_OCT_THREADS;
                 const int a0 = min(tid * ch2, size), a1 = min(a0 + ch2, size);
                 int k = 0;
-                for (int j = a0; j < a1; ++j) k += c.cnt[cur][j] > 1;
+                for (int j = a0; j < a1; ++j) k += (cur ? c.cnt[1] : c.cnt[0])[j] > 1;
                 int K;
                 int ko = block_scan_excl(k, &K, lds);
                 int P = 1;
@@ -458,7 +651,7 @@ __global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree(const OrbxLevels *_
                 for (int j = a0; j < a1; ++j) {
                     c.rank[j] = -1;
                     // created later <=> closer to the list head, so creation order = descending position
-                    if (c.cnt[cur][j] > 1) sort_keys[ko++] = ((u64)c.cnt[cur][j] << 32) | (u64)(0xFFFFFFFFu - (uint32_t)j);
+                    if ((cur ? c.cnt[1] : c.cnt[0])[j] > 1) sort_keys[ko++] = ((u64)(cur ? c.cnt[1] : c.cnt[0])[j] << 32) | (u64)(0xFFFFFFFFu - (uint32_t)j);
                 }
                 for (int i = K + tid; i < P; i += ORBX_OCT_THREADS) sort_keys[i] = ~0ull;
                 __syncthreads();
@@ -564,7 +757,7 @@ __device__ __forceinline__ void octl_child_counts(const OctL &c, int cur, int nr
         const uint32_t old = c.pnode[p], code = c.pcode[p];
         const uint32_t r = c.rank[old];
         if (r != OCT_NORANK) {
-            const uint32_t d = c.node[cur][old] >> 24;
+            const uint32_t d = (cur ? c.node[1] : c.node[0])[old] >> 24;
             atomicAdd(&c.childcnt[4 * r + ((code >> (30 - 2 * d)) & 3)], 1u);
         }
     }
@@ -596,8 +789,8 @@ __device__ __forceinline__ void octl_apply(const OctL &c, int cur, int size, int
         const uint32_t n = c.childcnt[i];
         if (n > 0) {
             const int pos = T - 1 - ci;
-            const uint32_t pd = c.node[cur][c.node_of_rank[i >> 2]] >> 24;
-            c.node[nxt][pos] = ((pd + 1) << 24) | n;
+            const uint32_t pd = (cur ? c.node[1] : c.node[0])[c.node_of_rank[i >> 2]] >> 24;
+            (nxt ? c.node[1] : c.node[0])[pos] = ((pd + 1) << 24) | n;
             c.childpos[i] = (uint16_t)pos;
             ++ci;
         }
@@ -605,7 +798,7 @@ __device__ __forceinline__ void octl_apply(const OctL &c, int cur, int size, int
     for (int j = j0; j < j1; ++j) {
         if (!(c.rank[j] < (uint32_t)nsplit)) {
             const int pos = T + ui;
-            c.node[nxt][pos] = c.node[cur][j];
+            (nxt ? c.node[1] : c.node[0])[pos] = (cur ? c.node[1] : c.node[0])[j];
             c.newpos[j] = (uint16_t)pos;
             ++ui;
         }
@@ -616,7 +809,7 @@ __device__ __forceinline__ void octl_apply(const OctL &c, int cur, int size, int
         const uint32_t r = c.rank[old];
         uint32_t np;
         if (r < (uint32_t)nsplit) {
-            const uint32_t d = c.node[cur][old] >> 24;
+            const uint32_t d = (cur ? c.node[1] : c.node[0])[old] >> 24;
             np = c.childpos[4 * r + ((c.pcode[p] >> (30 - 2 * d)) & 3)];
         } else {
             np = c.newpos[old];
@@ -692,7 +885,7 @@ __global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree_lds(const OrbxLevel
         int pos = block_scan_excl(s, &size, lds);
         for (int i = i0; i < i1; ++i)
             if (c.childcnt[i] > 0) {
-                c.node[cur][pos] = c.childcnt[i]; // depth 0
+                (cur ? c.node[1] : c.node[0])[pos] = c.childcnt[i]; // depth 0
                 c.newpos[i] = (uint16_t)pos++;
             }
         __syncthreads();
@@ -707,11 +900,11 @@ __global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree_lds(const OrbxLevel
         const int chunk = (size + ORBX_OCT_THREADS - 1) / ORBX_OCT_THREADS;
         const int j0 = min(tid * chunk, size), j1 = min(j0 + chunk, size);
         int s = 0;
-        for (int j = j0; j < j1; ++j) s += (c.node[cur][j] & 0xFFFFFF) > 1;
+        for (int j = j0; j < j1; ++j) s += ((cur ? c.node[1] : c.node[0])[j] & 0xFFFFFF) > 1;
         int nsplit;
         int r = block_scan_excl(s, &nsplit, lds);
         for (int j = j0; j < j1; ++j) {
-            if ((c.node[cur][j] & 0xFFFFFF) > 1) { c.rank[j] = (uint16_t)r; c.node_of_rank[r] = (uint16_t)j; ++r; }
+            if (((cur ? c.node[1] : c.node[0])[j] & 0xFFFFFF) > 1) { c.rank[j] = (uint16_t)r; c.node_of_rank[r] = (uint16_t)j; ++r; }
             else c.rank[j] = OCT_NORANK;
         }
         __syncthreads();
@@ -728,14 +921,14 @@ __global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree_lds(const OrbxLevel
                 const int ch2 = (size + ORBX_OCT_THREADS - 1) / ORBX_OCT_THREADS;
                 const int a0 = min(tid * ch2, size), a1 = min(a0 + ch2, size);
                 int k = 0;
-                for (int j = a0; j < a1; ++j) k += (c.node[cur][j] & 0xFFFFFF) > 1;
+                for (int j = a0; j < a1; ++j) k += ((cur ? c.node[1] : c.node[0])[j] & 0xFFFFFF) > 1;
                 int K;
                 int ko = block_scan_excl(k, &K, lds);
                 int P = 1;
                 while (P < K) P <<= 1;
                 for (int j = a0; j < a1; ++j) {
                     c.rank[j] = OCT_NORANK;
-                    const uint32_t cn = c.node[cur][j] & 0xFFFFFF;
+                    const uint32_t cn = (cur ? c.node[1] : c.node[0])[j] & 0xFFFFFF;
                     if (cn > 1) sort_keys[ko++] = ((u64)cn << 32) | (u64)(0xFFFFFFFFu - (uint32_t)j);
                 }
                 for (int i = K + tid; i < P; i += ORBX_OCT_THREADS) sort_keys[i] = ~0ull;
@@ -850,8 +1043,10 @@ void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLev
 
 // ---------------------------------------------------------------------------------------------
 // Orientation (intensity centroid on the raw level) + steered BRIEF (on the blurred level) +
-// output record, one 256-thread workgroup per keypoint: thread t owns descriptor bit t and the
-// four waves write 8 bytes each from their 64-bit ballot.
+// output record.  One wave64 per keypoint, four keypoints per workgroup:
+//   * moments: lane = (patch row, left/right half), 62 lanes busy, wave reduction by shuffles;
+//   * lane 0 evaluates fastAtan2 and the double-precision sin/cos once, broadcast by readlane;
+//   * lane l owns descriptor bits l, l+64, l+128, l+192: four ballots give the 32 bytes.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__ l0, size_t l0_fs, int l0_pitch,
                                                      const OrbxLevels *__restrict__ levels, OrbxBuffers b,
@@ -859,20 +1054,20 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
                                                      uint8_t *__restrict__ out_desc, int cap,
                                                      int32_t *__restrict__ out_n)
 {
-    __shared__ float s_cs[2];
-    __shared__ float s_angle;
-    const int frame = blockIdx.y, slot = blockIdx.x, tid = threadIdx.x;
+    const int frame = blockIdx.y, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int L = levels->n_levels;
-    int level = 0;
-    for (int l = 1; l < L; ++l) level += slot >= levels->lv[l].kp_off;
-    const OrbxLevel lv = levels->lv[level];
-    const int i = slot - lv.kp_off;
     const int *cnts = b.sel_count + frame * ORBX_MAX_LEVELS;
-    if (slot == 0 && tid == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         int tot = 0;
         for (int l = 0; l < L; ++l) tot += cnts[l];
         out_n[frame] = tot;
     }
+    if (slot >= levels->kcap_total) return;
+    int level = 0;
+    for (int l = 1; l < L; ++l) level += slot >= levels->lv[l].kp_off;
+    const OrbxLevel &lv = levels->lv[level];
+    const int i = slot - lv.kp_off;
     if (i >= cnts[level]) return;
     int out_idx = i;
     for (int l = 0; l < level; ++l) out_idx += cnts[l];
@@ -880,56 +1075,60 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
 
     const uint2 rec = b.sel[(size_t)frame * levels->kcap_total + slot];
     const int x = rec.x & 0xFFFF, y = rec.x >> 16;
+    const int pitch = lv.pitch;
     const uint8_t *raw = level == 0 ? l0 + (size_t)frame * l0_fs : b.img_arena + (size_t)frame * b.img_frame_stride + lv.raw_off;
-    const int rpitch = level == 0 ? l0_pitch : lv.pitch;
+    const int rpitch = level == 0 ? l0_pitch : pitch;
     const uint8_t *blur = b.img_arena + (size_t)frame * b.img_frame_stride + lv.blur_off;
 
-    if (tid < 64) {
-        int m10 = 0, m01 = 0;
-        if (tid < 2 * ORBX_HALF_PATCH + 1) {
-            const int v = tid - ORBX_HALF_PATCH;
-            const int d = u_max[v < 0 ? -v : v];
-            const uint8_t *row = raw + (size_t)(y + v) * rpitch + x;
-            int rs = 0;
-            for (int u = -d; u <= d; ++u) {
-                const int val = row[u];
-                m10 += u * val;
-                rs += val;
-            }
-            m01 = v * rs;
+    int m10 = 0, m01 = 0;
+    if (lane < 2 * (2 * ORBX_HALF_PATCH + 1)) {
+        const int v = (lane >> 1) - ORBX_HALF_PATCH, half = lane & 1;
+        const int d = u_max[v < 0 ? -v : v];
+        const uint8_t *row = raw + (size_t)(y + v) * rpitch + x;
+        const int u0 = half ? 0 : -d, u1 = half ? d : -1;
+        int rs = 0;
+        for (int u = u0; u <= u1; ++u) {
+            const int val = row[u];
+            m10 += u * val;
+            rs += val;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m10 += __shfl_down(m10, o);
-            m01 += __shfl_down(m01, o);
-        }
-        if (tid == 0) {
-            const float ang = orb_fast_atan2((float)m01, (float)m10);
-            float cs, sn;
-            orb_sincos_deg(ang, &cs, &sn);
-            s_angle = ang;
-            s_cs[0] = cs;
-            s_cs[1] = sn;
-        }
+        m01 = v * rs;
     }
-    __syncthreads();
-    const float a = s_cs[0], bb = s_cs[1];
-    const uint8_t *center = blur + (size_t)y * lv.pitch + x;
-    const float px0 = (float)c_pattern[4 * tid], py0 = (float)c_pattern[4 * tid + 1];
-    const float px1 = (float)c_pattern[4 * tid + 2], py1 = (float)c_pattern[4 * tid + 3];
-    const int r0 = orb_round_f(ORB_FADD(ORB_FMUL(px0, bb), ORB_FMUL(py0, a)));
-    const int c0 = orb_round_f(ORB_FSUB(ORB_FMUL(px0, a), ORB_FMUL(py0, bb)));
-    const int r1 = orb_round_f(ORB_FADD(ORB_FMUL(px1, bb), ORB_FMUL(py1, a)));
-    const int c1 = orb_round_f(ORB_FSUB(ORB_FMUL(px1, a), ORB_FMUL(py1, bb)));
-    const int t0 = center[r0 * lv.pitch + c0], t1 = center[r1 * lv.pitch + c1];
-    const u64 bits = __ballot(t0 < t1);
-    uint8_t *desc = out_desc + ((size_t)frame * cap + out_idx) * 32;
-    if ((tid & 63) == 0) *reinterpret_cast<u64 *>(desc + 8 * (tid >> 6)) = bits;
-    if (tid == 0) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+    }
+    float ang = 0.f, a = 0.f, bb = 0.f;
+    if (lane == 0) {
+        ang = orb_fast_atan2((float)m01, (float)m10);
+        orb_sincos_deg(ang, &a, &bb);
+    }
+    a = __shfl(a, 0);
+    bb = __shfl(bb, 0);
+    const uint8_t *center = blur + (size_t)y * pitch + x;
+    u64 bits[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = lane + 64 * j;
+        const float px0 = (float)c_pattern[4 * t], py0 = (float)c_pattern[4 * t + 1];
+        const float px1 = (float)c_pattern[4 * t + 2], py1 = (float)c_pattern[4 * t + 3];
+        const int r0 = orb_round_f(ORB_FADD(ORB_FMUL(px0, bb), ORB_FMUL(py0, a)));
+        const int c0 = orb_round_f(ORB_FSUB(ORB_FMUL(px0, a), ORB_FMUL(py0, bb)));
+        const int r1 = orb_round_f(ORB_FADD(ORB_FMUL(px1, bb), ORB_FMUL(py1, a)));
+        const int c1 = orb_round_f(ORB_FSUB(ORB_FMUL(px1, a), ORB_FMUL(py1, bb)));
+        const int t0 = center[r0 * pitch + c0], t1 = center[r1 * pitch + c1];
+        bits[j] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        const u64 w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        *reinterpret_cast<u64 *>(out_desc + ((size_t)frame * cap + out_idx) * 32 + 8 * lane) = w;
+    }
+    if (lane == 0) {
         orbx_kp kp;
         float fx = (float)x, fy = (float)y;
         if (level != 0) { fx = ORB_FMUL(fx, lv.scale); fy = ORB_FMUL(fy, lv.scale); }
-        kp.x = fx; kp.y = fy; kp.size = lv.scale; kp.angle = s_angle; kp.response = (float)rec.y;
+        kp.x = fx; kp.y = fy; kp.size = lv.scale; kp.angle = ang; kp.response = (float)rec.y;
         kp.octave = level; kp.class_id = -1;
         out_kp[(size_t)frame * cap + out_idx] = kp;
     }
@@ -939,7 +1138,7 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
                              uint8_t *out_desc, int cap, int32_t *out_n, int n_frames)
 {
-    dim3 grid(levels.kcap_total, n_frames);
+    dim3 grid((levels.kcap_total + 3) / 4, n_frames);
     hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, b, u_max, out_kp,
                        out_desc, cap, out_n);
 }
