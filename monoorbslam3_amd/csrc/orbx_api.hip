@@ -48,6 +48,7 @@ struct orbx_ctx {
     OrbxTap *d_xtap[ORBX_MAX_LEVELS], *d_ytap[ORBX_MAX_LEVELS];
     int *d_umax, *d_taps;
     uint16_t *d_fast_segs; int n_fast_segs;
+    uint16_t *d_fast_cells; int n_fast_cells;
     uint16_t *d_blur_tiles; int n_blur_tiles;
     uint8_t *d_l0_stage; size_t l0_stage_fs;
     orbx_kp *d_out_kp; uint8_t *d_out_desc; int32_t *d_out_n; int out_cap;
@@ -279,6 +280,12 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
             HIP_TRY(dev_alloc(&c->d_fast_segs, segs.size()));
             HIP_TRY(hipMemcpy(c->d_fast_segs, segs.data(), segs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             c->n_fast_segs = ns;
+            const int nc = orbx_build_fast_cells(c->levels, nullptr);
+            std::vector<uint16_t> cells((size_t)std::max(nc, 1) * 4);
+            orbx_build_fast_cells(c->levels, cells.data());
+            HIP_TRY(dev_alloc(&c->d_fast_cells, cells.size()));
+            HIP_TRY(hipMemcpy(c->d_fast_cells, cells.data(), cells.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            c->n_fast_cells = nc;
         }
         {
             const int nt = orbx_build_blur_tiles(c->levels, nullptr);
@@ -292,6 +299,7 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
         for (int l = 1; l < c->levels.n_levels; ++l) {
             const OrbxLevel &d = c->levels.lv[l], &s = c->levels.lv[l - 1];
             linear_taps(d.w, s.w, true, taps);
+            while (taps.size() % 4) taps.push_back(taps.back()); // k_resize reads the column taps four at a time
             HIP_TRY(dev_alloc(&c->d_xtap[l], taps.size()));
             HIP_TRY(hipMemcpy(c->d_xtap[l], taps.data(), taps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice));
             linear_taps(d.h, s.h, false, taps);
@@ -375,7 +383,7 @@ extern "C" void orbx_destroy(orbx_t *c)
     OrbxBuffers &b = c->buf;
     void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.pcode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
                     b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.sel_count, c->d_levels, c->d_umax, c->d_taps,
-                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n, c->d_fast_segs, c->d_blur_tiles};
+                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n, c->d_fast_segs, c->d_fast_cells, c->d_blur_tiles};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         if (c->d_xtap[l]) (void)hipFree(c->d_xtap[l]);
@@ -442,7 +450,8 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
                            n_frames);
     }
     if (t) HIP_TRY(hipEventRecord(c->ev[1], s));
-    orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_segs, c->n_fast_segs, n_frames);
+    orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_segs, c->n_fast_segs, c->d_fast_cells, c->n_fast_cells,
+                     n_frames);
     if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
     orbx_launch_blur(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames);
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));

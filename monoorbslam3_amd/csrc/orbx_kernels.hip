@@ -17,6 +17,12 @@ __constant__ int8_t c_pattern[ORB_PATTERN_POINTS * 2] = {ORB_PATTERN_INT8_LIST};
 // ---------------------------------------------------------------------------------------------
 // Pyramid: fixed-point bilinear (11-bit taps), 4 output pixels per thread
 // ---------------------------------------------------------------------------------------------
+// Each thread produces 4 adjacent output pixels of one row.  Their source columns span at most 8
+// bytes (scale < 2), so the two source rows are fetched with one unaligned 64-bit load each and the
+// taps pick bytes out of the registers; the 4 x (offset, c0, c1) column taps come in as two 128-bit
+// loads.
+struct __attribute__((packed, aligned(1))) UnalignedU64 { unsigned long long v; };
+
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, size_t src_fs, int src_pitch, int sw,
                                                 int sh, uint8_t *__restrict__ dst, size_t dst_fs, int dst_pitch,
                                                 int dw, int dh, const OrbxTap *__restrict__ xtap,
@@ -28,21 +34,36 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     const uint8_t *S = src + (size_t)blockIdx.z * src_fs;
     uint8_t *D = dst + (size_t)blockIdx.z * dst_fs + (size_t)dy * dst_pitch;
     const OrbxTap ty = ytap[dy];
-    int sy0 = min(max(ty.ofs, 0), sh - 1), sy1 = min(max(ty.ofs + 1, 0), sh - 1);
+    const int sy0 = min(max(ty.ofs, 0), sh - 1), sy1 = min(max(ty.ofs + 1, 0), sh - 1);
     const uint8_t *S0 = S + (size_t)sy0 * src_pitch, *S1 = S + (size_t)sy1 * src_pitch;
     const int b0 = ty.c0, b1 = ty.c1;
+    // the tap table is padded to a multiple of 4 entries (host side), 32 bytes per thread
+    const uint4 t01 = reinterpret_cast<const uint4 *>(xtap + dx0)[0], t23 = reinterpret_cast<const uint4 *>(xtap + dx0)[1];
+    const int ofs[4] = {(int)t01.x, (int)t01.z, (int)t23.x, (int)t23.z};
+    const uint32_t cc[4] = {t01.y, t01.w, t23.y, t23.w}; // c0 | c1 << 16
+    const int sx0 = ofs[0];
+    unsigned long long w0, w1;
+    if (sx0 + 8 <= sw) {
+        w0 = reinterpret_cast<const UnalignedU64 *>(S0 + sx0)->v;
+        w1 = reinterpret_cast<const UnalignedU64 *>(S1 + sx0)->v;
+    } else { // right image edge: never read past the end of the row
+        w0 = w1 = 0;
+        for (int k = 0; k < sw - sx0; ++k) {
+            w0 |= (unsigned long long)S0[sx0 + k] << (8 * k);
+            w1 |= (unsigned long long)S1[sx0 + k] << (8 * k);
+        }
+    }
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int dx = dx0 + i;
-        if (dx < dw) {
-            const OrbxTap tx = xtap[dx];
-            const int sx = tx.ofs, sx1 = min(sx + 1, sw - 1);
-            const int r0 = S0[sx] * tx.c0 + S0[sx1] * tx.c1;
-            const int r1 = S1[sx] * tx.c0 + S1[sx1] * tx.c1;
-            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 255) << (8 * i);
-        }
+        const int o = 8 * (ofs[i] - sx0); // taps of the padding entries repeat the last column: still within 8 bytes
+        const int c0 = (int)(short)(cc[i] & 0xFFFF), c1 = (int)(short)(cc[i] >> 16);
+        const int a0 = (int)((w0 >> o) & 255), a1 = (int)((w0 >> (o + 8)) & 255);
+        const int e0 = (int)((w1 >> o) & 255), e1 = (int)((w1 >> (o + 8)) & 255);
+        const int r0 = a0 * c0 + a1 * c1;
+        const int r1 = e0 * c0 + e1 * c1;
+        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)(v & 255) << (8 * i);
     }
     // rows of the arena are 64-byte aligned and padded, so the dword store is always in bounds
     *reinterpret_cast<uint32_t *>(D + dx0) = packed;
@@ -63,27 +84,47 @@ void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int sr
 // so one strength tile answers both the ini and the min threshold of a cell.
 // ---------------------------------------------------------------------------------------------
 
-#ifndef FAST_TP
-#define FAST_TP 256
-#endif
-__device__ __forceinline__ int fast_strength(const uint8_t *t /* centre pixel in the LDS tile */, int tlow)
+#define FAST_SEG 8   // cells per strip segment (30*8 = 240 px, a multiple of 16 -> aligned segment starts)
+#define FAST_TP 256  // tile pitch in bytes: 240 + 6 used
+#define FAST_SP 256  // score-map pitch: 1 + 240 + 1 used
+#define FAST_HALF 15 // rows per chunk of the survivor queues
+#define FAST_QCAP (FAST_SEG * 30 * FAST_HALF)
+#define FAST_KCAP (FAST_SEG * 15 * 15) // at most one strict 3x3 maximum per 2x2 block of a cell
+
+struct FastSeg { // one strip segment
+    uint16_t level, cy, cx0, ncells;
+};
+struct FastSrc {
+    const uint8_t *base[ORBX_MAX_LEVELS];
+    size_t frame_stride[ORBX_MAX_LEVELS];
+    int pitch[ORBX_MAX_LEVELS];
+};
+struct __attribute__((packed, aligned(1))) UnalignedU32 { uint32_t v; };
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void fast_load_ring(const uint8_t *t /* centre pixel in the LDS tile */, int d[16])
 {
     const int v = t[0];
-    int d[16];
     d[0] = v - t[3 * FAST_TP];      d[1] = v - t[3 * FAST_TP + 1];  d[2] = v - t[2 * FAST_TP + 2];
     d[3] = v - t[FAST_TP + 3];      d[4] = v - t[3];                d[5] = v - t[-FAST_TP + 3];
     d[6] = v - t[-2 * FAST_TP + 2]; d[7] = v - t[-3 * FAST_TP + 1]; d[8] = v - t[-3 * FAST_TP];
     d[9] = v - t[-3 * FAST_TP - 1]; d[10] = v - t[-2 * FAST_TP - 2]; d[11] = v - t[-FAST_TP - 3];
     d[12] = v - t[-3];              d[13] = v - t[FAST_TP - 3];     d[14] = v - t[2 * FAST_TP - 2];
     d[15] = v - t[3 * FAST_TP - 1];
-    // an arc of 9 out of 16 holds one pixel of every opposite pair: cheap exact rejection
+}
+// an arc of 9 out of 16 holds one pixel of every opposite pair: exact necessary condition for S >= thr
+__device__ __forceinline__ bool fast_pairs(const int d[16], int thr)
+{
     int minhi = 1 << 20, maxlo = -(1 << 20);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         minhi = min(minhi, max(d[k], d[k + 8]));
         maxlo = max(maxlo, min(d[k], d[k + 8]));
     }
-    if (minhi <= tlow && maxlo >= -tlow) return 0; // S < tlow: irrelevant for both thresholds
+    return minhi > thr || maxlo < -thr;
+}
+__device__ __forceinline__ int fast_score(const int d[16])
+{
     int m3[16], M3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -96,187 +137,414 @@ __device__ __forceinline__ int fast_strength(const uint8_t *t /* centre pixel in
         best_min = max(best_min, min(min(m3[k], m3[(k + 3) & 15]), m3[(k + 6) & 15]));
         best_max = min(best_max, max(max(M3[k], M3[(k + 3) & 15]), M3[(k + 6) & 15]));
     }
-    const int s = max(best_min, -best_max) - 1;
-    return s >= tlow ? s : 0;
+    return max(best_min, -best_max) - 1;
+}
+
+// byte pair (i, j) of the 8 bytes {hi:lo} zero-extended into the two 16-bit halves
+#define PERM_SEL(i, j) ((uint32_t)(i) | (0x0cu << 8) | ((uint32_t)(j) << 16) | (0x0cu << 24))
+__device__ __forceinline__ s16x2 pk_bytes(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    const uint32_t r = __builtin_amdgcn_perm(hi, lo, sel);
+    return __builtin_bit_cast(s16x2, r);
 }
 
 // One workgroup = one strip segment: up to FAST_SEG horizontally adjacent cells of one cell row of
-// one level of one frame; a single launch covers every level (segment table).  Steps:
-//   1. the (30+6)-row tile goes HBM -> LDS with dword loads (the segment's left edge is 16-byte
-//      aligned in level coordinates because 30*FAST_SEG is a multiple of 16);
-//   2. every pixel takes the 4-point compass test (any 9-arc holds two adjacent compass points);
-//      survivors are compacted into an LDS queue with wave64 ballot + popcount;
-//   3. queue entries get the exact strength (dense lanes, no divergence on flat image areas);
-//   4. strict 3x3 NMS inside each cell, per-cell "anything at the ini threshold?" vote, emission.
-#define FAST_SEG 8
-// FAST_TP (defined above) = tile pitch in bytes: 8*30 + 6 = 246 used
-#define FAST_SP 256                    // score-map pitch: 1 + 240 + 1 used
-#define FAST_QCAP (FAST_SEG * 30 * 30) // every pixel may survive the compass test
-
-struct FastSeg { // one strip segment
-    uint16_t level, cy, cx0, ncells;
-};
-struct FastSrc {
-    const uint8_t *base[ORBX_MAX_LEVELS];
-    size_t frame_stride[ORBX_MAX_LEVELS];
-    int pitch[ORBX_MAX_LEVELS];
-};
-struct __attribute__((packed, aligned(1))) UnalignedU32 { uint32_t v; };
-
+// one level of one frame; a single launch covers every level (segment table).
+//   1. the (30+6)-row tile goes HBM -> LDS with dword loads (segment starts are 16-byte aligned in
+//      level coordinates because 30*FAST_SEG is a multiple of 16);
+//   2. every pixel takes the 4-point compass test (any 9-arc holds two adjacent compass points),
+//      two pixels per instruction in packed 16-bit lanes; survivors are compacted into an LDS
+//      queue (popcount + wave prefix);
+//   3. queue 1 takes the exact 8-pair test, its survivors (ballot + mbcnt compaction) the exact
+//      strength, written to a u8 score map;
+//   4. strict 3x3 NMS inside each 30-px cell from the score map, keepers appended to a list.
+// Everything runs at the ini threshold first; cells left without a keeper are redone at the min
+// threshold (reference :604-607).  Both answers are exact for their cells.
 __global__ __launch_bounds__(256) void k_fast_strips(FastSrc src, const OrbxLevels *__restrict__ levels,
                                                      const FastSeg *__restrict__ segs, u64 *__restrict__ cand,
-                                                     size_t cand_fs, int *__restrict__ cand_count)
+                                                     size_t cand_fs, int *__restrict__ cand_count, int dbg)
 {
     __shared__ __align__(16) uint8_t tile[36 * FAST_TP];
     __shared__ __align__(16) uint8_t score[32 * FAST_SP];
-    __shared__ uint16_t queue[FAST_QCAP];
-    __shared__ int s_qn, s_n_emit, s_base;
-    __shared__ int s_n_ini[FAST_SEG];
+    __shared__ uint16_t queue1[FAST_QCAP], queue2[FAST_QCAP];
+    __shared__ uint32_t keepers[FAST_KCAP];
+    __shared__ int s_q1n, s_q2n, s_nkeep, s_base;
+    __shared__ int s_cell_keep[FAST_SEG];
 
     const FastSeg sg = segs[blockIdx.x];
-    const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int level = sg.level;
     const OrbxLevel &lv = levels->lv[level];
-    const int ini_th = levels->ini_th, min_th = levels->min_th, tlow = min(ini_th, min_th);
     const int x0 = ORBX_EDGE + sg.cx0 * ORBX_CELL, y0 = ORBX_EDGE + sg.cy * ORBX_CELL;
-    const int wpx = min(sg.ncells * ORBX_CELL, lv.w - ORBX_EDGE - x0); // pixels of the region in this segment
+    const int wpx = min(sg.ncells * ORBX_CELL, lv.w - ORBX_EDGE - x0); // region pixels in this segment
     const int hpx = min(ORBX_CELL, lv.h - ORBX_EDGE - y0);
     const int tw = wpx + 6, th = hpx + 6;
-    const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level] + (size_t)(y0 - 3) * src.pitch[level] +
-                       (x0 - 3);
     const int pitch = src.pitch[level];
+    const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level] + (size_t)(y0 - 3) * pitch + (x0 - 3);
 
     for (int i = tid; i < 32 * FAST_SP / 16; i += 256) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) { s_qn = 0; s_n_emit = 0; }
-    if (tid < FAST_SEG) s_n_ini[tid] = 0;
-    // ---- 1. tile load: dwords while a whole dword is inside the image row, bytes for the tail
+    if (tid == 0) s_nkeep = 0;
+    if (tid < FAST_SEG) s_cell_keep[tid] = 0;
+    // ---- 1. tile load: lane = dword column, wave = row (mod 4)
     {
-        const int dw_per_row = (tw + 3) >> 2;
+        const int dw_per_row = (tw + 3) >> 2; // <= 62
         const int row_left = lv.w - (x0 - 3); // bytes from the tile's left edge to the end of the image row
-        for (int i = tid; i < dw_per_row * th; i += 256) {
-            const int ty = i / dw_per_row, tx = (i - ty * dw_per_row) * 4;
+        const int tx = lane * 4;
+        if (lane < dw_per_row) {
+            for (int ty = wave; ty < th; ty += 4) {
+                const uint8_t *p = S + (size_t)ty * pitch + tx;
+                uint32_t v;
+                if (tx + 4 <= row_left) v = reinterpret_cast<const UnalignedU32 *>(p)->v;
+                else {
+                    v = 0;
+                    for (int k = 0; k < row_left - tx; ++k) v |= (uint32_t)p[k] << (8 * k);
+                }
+                *reinterpret_cast<uint32_t *>(&tile[ty * FAST_TP + tx]) = v;
+            }
+        }
+    }
+    if (dbg & 1) return;
+    const int runs_per_row = (wpx + 3 + 3) >> 2; // dword columns covering tile columns [0, wpx + 3)
+    const int ncells = sg.ncells;
+    uint32_t cellmask = (1u << ncells) - 1;
+    int thr = levels->ini_th;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        // which of this lane's four pixels (tile columns 4*lane .. +3, region column = tile column - 3)
+        // are region pixels of a cell that is processed in this pass
+        uint32_t colmask = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int col = 4 * lane + k - 3;
+            if (col >= 0 && col < wpx && ((cellmask >> (col / ORBX_CELL)) & 1)) colmask |= 1u << k;
+        }
+        const s16x2 T = {(short)thr, (short)thr};
+        for (int r0 = 0; r0 < hpx; r0 += FAST_HALF) {
+            const int r1 = min(r0 + FAST_HALF, hpx);
+            if (tid == 0) { s_q1n = 0; s_q2n = 0; }
+            __syncthreads(); // also orders the tile load / previous chunk's score writes
+            // ---- 2. compass test
+            uint32_t mask = 0;
+            if (colmask && lane < runs_per_row) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = r0 + wave + 4 * it;
+                    if (r < r1) {
+                        const uint8_t *row = &tile[(r + 3) * FAST_TP + 4 * lane];
+                        const uint32_t cm = lane > 0 ? *reinterpret_cast<const uint32_t *>(row - 4) : 0u;
+                        const uint32_t c0 = *reinterpret_cast<const uint32_t *>(row);
+                        const uint32_t cp = *reinterpret_cast<const uint32_t *>(row + 4);
+                        const uint32_t up = *reinterpret_cast<const uint32_t *>(row - 3 * FAST_TP);
+                        const uint32_t dn = *reinterpret_cast<const uint32_t *>(row + 3 * FAST_TP);
+                        uint32_t bits = 0;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) { // pixels (0,1) then (2,3)
+                            const s16x2 V = pk_bytes(0, c0, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));
+                            const s16x2 dE = V - pk_bytes(cp, c0, h ? PERM_SEL(5, 6) : PERM_SEL(3, 4)); // (+3, 0)
+                            const s16x2 dW = V - pk_bytes(c0, cm, h ? PERM_SEL(3, 4) : PERM_SEL(1, 2)); // (-3, 0)
+                            const s16x2 dS = V - pk_bytes(0, dn, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));  // (0, +3)
+                            const s16x2 dN = V - pk_bytes(0, up, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));  // (0, -3)
+                            const s16x2 hi = __builtin_elementwise_min(__builtin_elementwise_max(dS, dN),
+                                                                       __builtin_elementwise_max(dE, dW));
+                            const s16x2 lo = __builtin_elementwise_max(__builtin_elementwise_min(dS, dN),
+                                                                       __builtin_elementwise_min(dE, dW));
+                            const s16x2 m = __builtin_elementwise_max(hi, -lo) - T; // > 0 <=> passes
+                            bits |= (uint32_t)(m.x > 0) << (2 * h);
+                            bits |= (uint32_t)(m.y > 0) << (2 * h + 1);
+                        }
+                        mask |= (bits & colmask) << (4 * it);
+                    }
+                }
+            }
+            {
+                const int cnt = __popc(mask);
+                int incl = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int y = __shfl_up(incl, o);
+                    if (lane >= o) incl += y;
+                }
+                const int wave_total = __shfl(incl, 63);
+                int base = 0;
+                if (lane == 63 && wave_total) base = atomicAdd(&s_q1n, wave_total);
+                base = __shfl(base, 63);
+                int slot = base + incl - cnt;
+                uint32_t m = mask;
+                while (m) {
+                    const int b = __ffs(m) - 1;
+                    m &= m - 1;
+                    const int r = r0 + wave + 4 * (b >> 2);
+                    queue1[slot++] = (uint16_t)((r << 8) | (4 * lane + (b & 3) - 3));
+                }
+            }
+            __syncthreads();
+            // ---- 3a. exact 8-pair test on queue 1 -> queue 2
+            const int q1n = (dbg & 2) ? 0 : s_q1n;
+            for (int i0 = 0; i0 < q1n; i0 += 256) {
+                const int i = i0 + tid;
+                bool ok = false;
+                int e = 0;
+                if (i < q1n) {
+                    e = queue1[i];
+                    int d[16];
+                    fast_load_ring(&tile[((e >> 8) + 3) * FAST_TP + (e & 255) + 3], d);
+                    ok = fast_pairs(d, thr);
+                }
+                const u64 mk = __ballot(ok);
+                if (mk) {
+                    const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_q2n, (int)__popcll(mk));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (ok) queue2[base + pre] = (uint16_t)e;
+                }
+            }
+            __syncthreads();
+            // ---- 3b. exact strength of the survivors
+            const int q2n = (dbg & 4) ? 0 : s_q2n;
+            for (int i = tid; i < q2n; i += 256) {
+                const int e = queue2[i], r = e >> 8, col = e & 255;
+                int d[16];
+                fast_load_ring(&tile[(r + 3) * FAST_TP + col + 3], d);
+                const int sc = fast_score(d);
+                if (sc >= thr) score[(r + 1) * FAST_SP + col + 1] = (uint8_t)sc;
+            }
+        }
+        __syncthreads();
+        // ---- 4. NMS inside each cell, straight from the score map: lane = dword column, wave = row (mod 4)
+        if (lane <= (wpx + 1) >> 2 && !(dbg & 8)) {
+            for (int r = wave; r < hpx; r += 4) {
+                const uint32_t wd = *reinterpret_cast<const uint32_t *>(&score[(r + 1) * FAST_SP + 4 * lane]);
+                if (wd == 0) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int sc = (wd >> (8 * k)) & 255;
+                    const int col = 4 * lane + k - 1;
+                    if (sc == 0 || col < 0 || col >= wpx) continue;
+                    const int cell = col / ORBX_CELL, xin = col - cell * ORBX_CELL;
+                    if (!((cellmask >> cell) & 1)) continue;
+                    const uint8_t *sp = &score[(r + 1) * FAST_SP + col + 1];
+                    const bool l = xin != 0, rr = xin != ORBX_CELL - 1; // neighbours in the adjacent cell count as 0
+                    const bool keep = sc > sp[-FAST_SP] && sc > sp[FAST_SP] &&
+                                      (!l || (sc > sp[-1] && sc > sp[-FAST_SP - 1] && sc > sp[FAST_SP - 1])) &&
+                                      (!rr || (sc > sp[1] && sc > sp[-FAST_SP + 1] && sc > sp[FAST_SP + 1]));
+                    if (keep) {
+                        keepers[atomicAdd(&s_nkeep, 1)] = (uint32_t)r | ((uint32_t)col << 8) | ((uint32_t)sc << 16);
+                        atomicAdd(&s_cell_keep[cell], 1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // cells without a keeper are redone at the min threshold (reference :604-607)
+        uint32_t empty = 0;
+        for (int c = 0; c < ncells; ++c) empty |= (uint32_t)(s_cell_keep[c] == 0) << c;
+        if (pass == 1 || empty == 0) break;
+        cellmask = empty;
+        thr = levels->min_th;
+    }
+    // ---- emission
+    const int nk = s_nkeep;
+    if (nk == 0) return;
+    if (tid == 0) s_base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], nk);
+    __syncthreads();
+    u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + s_base;
+    for (int i = tid; i < nk; i += 256) {
+        const uint32_t e = keepers[i];
+        const uint32_t x = sg.cx0 * ORBX_CELL + ((e >> 8) & 255), y = sg.cy * ORBX_CELL + (e & 255);
+        out[i] = (u64)(x | (y << 16)) | ((u64)(e >> 16) << 32);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One WAVE per cell: the same pipeline as k_fast_strips, but a 64-thread workgroup owns one 30x30
+// cell end to end, so no phase waits for other waves and up to ~20 independent waves per CU hide
+// each other's LDS / L2 latency.  The tile rows overlap with the neighbour cells' (36x36 bytes per
+// 30x30 cell, served by L2).
+// ---------------------------------------------------------------------------------------------
+#define FC_TP 40 // tile pitch; tile column tc <-> level x = x0 - 4 + tc, region columns tc in [4, 4 + cw)
+#define FC_SP 40 // score-map pitch; score column = tc - 3, so the cell occupies columns 1..cw
+struct FastCell {
+    uint16_t level, cy, cx, pad;
+};
+__device__ __forceinline__ void fastc_load_ring(const uint8_t *t, int d[16])
+{
+    const int v = t[0];
+    d[0] = v - t[3 * FC_TP];      d[1] = v - t[3 * FC_TP + 1];  d[2] = v - t[2 * FC_TP + 2];
+    d[3] = v - t[FC_TP + 3];      d[4] = v - t[3];              d[5] = v - t[-FC_TP + 3];
+    d[6] = v - t[-2 * FC_TP + 2]; d[7] = v - t[-3 * FC_TP + 1]; d[8] = v - t[-3 * FC_TP];
+    d[9] = v - t[-3 * FC_TP - 1]; d[10] = v - t[-2 * FC_TP - 2]; d[11] = v - t[-FC_TP - 3];
+    d[12] = v - t[-3];            d[13] = v - t[FC_TP - 3];     d[14] = v - t[2 * FC_TP - 2];
+    d[15] = v - t[3 * FC_TP - 1];
+}
+struct __attribute__((packed, aligned(1))) UnalignedU64b { unsigned long long v; };
+
+__global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxLevels *__restrict__ levels,
+                                                        const FastCell *__restrict__ cells, u64 *__restrict__ cand,
+                                                        size_t cand_fs, int *__restrict__ cand_count)
+{
+    __shared__ __align__(16) uint8_t tile[36 * FC_TP];
+    __shared__ __align__(16) uint8_t score[32 * FC_SP];
+    __shared__ uint16_t queue1[ORBX_CELL * ORBX_CELL], queue2[ORBX_CELL * ORBX_CELL];
+    __shared__ uint32_t keepers[15 * 15];
+    __shared__ int s_nkeep;
+
+    const FastCell cl = cells[blockIdx.x];
+    const int frame = blockIdx.y, lane = threadIdx.x;
+    const int level = cl.level;
+    const OrbxLevel &lv = levels->lv[level];
+    const int x0 = ORBX_EDGE + cl.cx * ORBX_CELL, y0 = ORBX_EDGE + cl.cy * ORBX_CELL;
+    const int cw = min(ORBX_CELL, lv.w - ORBX_EDGE - x0), ch = min(ORBX_CELL, lv.h - ORBX_EDGE - y0);
+    const int th = ch + 6;
+    const int pitch = src.pitch[level];
+    const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level] + (size_t)(y0 - 3) * pitch + (x0 - 4);
+
+    for (int i = lane; i < 32 * FC_SP / 16; i += 64) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
+    if (lane == 0) s_nkeep = 0;
+    {
+        const int row_left = lv.w - (x0 - 4); // bytes from the tile's left edge to the end of the image row
+        for (int i = lane; i < 5 * th; i += 64) {
+            const int ty = i / 5, tx = (i - 5 * ty) * 8;
             const uint8_t *p = S + (size_t)ty * pitch + tx;
-            uint32_t v;
-            if (tx + 4 <= row_left) v = reinterpret_cast<const UnalignedU32 *>(p)->v;
+            unsigned long long v;
+            if (tx + 8 <= row_left) v = reinterpret_cast<const UnalignedU64b *>(p)->v;
             else {
                 v = 0;
-                for (int k = 0; k < row_left - tx; ++k) v |= (uint32_t)p[k] << (8 * k);
+                for (int k = 0; k < row_left - tx; ++k) v |= (unsigned long long)p[k] << (8 * k);
             }
-            *reinterpret_cast<uint32_t *>(&tile[ty * FAST_TP + tx]) = v;
+            *reinterpret_cast<unsigned long long *>(&tile[ty * FC_TP + tx]) = v;
         }
     }
     __syncthreads();
-    // ---- 2. compass test, 4 pixels per lane per step; tile column = region column + 3
-    {
-        const int runs_per_row = (wpx + 3 + 3) >> 2; // dword columns covering tile columns [0, wpx+3)
-        const int n_runs = runs_per_row * hpx;
-        for (int i0 = 0; i0 < n_runs; i0 += 256) {
-            const int i = i0 + tid;
-            uint32_t pass = 0;
-            int r = 0, g = 0;
-            if (i < n_runs) {
-                r = i / runs_per_row; g = i - r * runs_per_row;
-                const uint8_t *row = &tile[(r + 3) * FAST_TP + 4 * g];
-                const uint32_t cm = g > 0 ? *reinterpret_cast<const uint32_t *>(row - 4) : 0u;
+    int thr = levels->ini_th;
+    for (int pass = 0; pass < 2; ++pass) {
+        const s16x2 T = {(short)thr, (short)thr};
+        // ---- compass test: item = (row, run of 4 tile columns 4g..4g+3), g = 1..8
+        uint32_t mask = 0;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = it * 64 + lane;
+            const int r = i >> 3, g = (i & 7) + 1;
+            if (r < ch) {
+                const uint8_t *row = &tile[(r + 3) * FC_TP + 4 * g];
+                const uint32_t cm = *reinterpret_cast<const uint32_t *>(row - 4);
                 const uint32_t c0 = *reinterpret_cast<const uint32_t *>(row);
                 const uint32_t cp = *reinterpret_cast<const uint32_t *>(row + 4);
-                const uint32_t up = *reinterpret_cast<const uint32_t *>(row - 3 * FAST_TP);
-                const uint32_t dn = *reinterpret_cast<const uint32_t *>(row + 3 * FAST_TP);
-                const u64 wide = ((u64)cp << 32) | c0; // bytes 0..7 from the run start
-                const u64 widem = ((u64)c0 << 32) | cm; // bytes -4..3
+                const uint32_t up = *reinterpret_cast<const uint32_t *>(row - 3 * FC_TP);
+                const uint32_t dn = *reinterpret_cast<const uint32_t *>(row + 3 * FC_TP);
+                uint32_t bits = 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int v = (c0 >> (8 * k)) & 255;
-                    const int dE = v - (int)((wide >> (8 * (k + 3))) & 255);  // (+3, 0)
-                    const int dW = v - (int)((widem >> (8 * (k + 1))) & 255); // (-3, 0)
-                    const int dS = v - (int)((dn >> (8 * k)) & 255);          // (0, +3)
-                    const int dN = v - (int)((up >> (8 * k)) & 255);          // (0, -3)
-                    const int hi = min(max(dS, dN), max(dE, dW)), lo = max(min(dS, dN), min(dE, dW));
-                    const int col = 4 * g + k - 3; // region column
-                    const bool ok = (hi > tlow || lo < -tlow) && col >= 0 && col < wpx;
-                    pass |= (uint32_t)ok << k;
+                for (int h = 0; h < 2; ++h) {
+                    const s16x2 V = pk_bytes(0, c0, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));
+                    const s16x2 dE = V - pk_bytes(cp, c0, h ? PERM_SEL(5, 6) : PERM_SEL(3, 4));
+                    const s16x2 dW = V - pk_bytes(c0, cm, h ? PERM_SEL(3, 4) : PERM_SEL(1, 2));
+                    const s16x2 dS = V - pk_bytes(0, dn, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));
+                    const s16x2 dN = V - pk_bytes(0, up, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));
+                    const s16x2 hi = __builtin_elementwise_min(__builtin_elementwise_max(dS, dN),
+                                                               __builtin_elementwise_max(dE, dW));
+                    const s16x2 lo = __builtin_elementwise_max(__builtin_elementwise_min(dS, dN),
+                                                               __builtin_elementwise_min(dE, dW));
+                    const s16x2 m = __builtin_elementwise_max(hi, -lo) - T;
+                    bits |= (uint32_t)(m.x > 0) << (2 * h);
+                    bits |= (uint32_t)(m.y > 0) << (2 * h + 1);
                 }
+                const int nvalid = min(max(cw + 4 - 4 * g, 0), 4); // region columns end at tc = 4 + cw
+                mask |= (bits & ((1u << nvalid) - 1)) << (4 * it);
             }
-            // wave64 compaction: every lane holds a 4-bit mask
-            const int cnt = __popc(pass);
+        }
+        int q1n;
+        {
+            const int cnt = __popc(mask);
             int incl = cnt;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const int y = __shfl_up(incl, o);
                 if (lane >= o) incl += y;
             }
-            const int wave_total = __shfl(incl, 63);
-            int base = 0;
-            if (lane == 63 && wave_total) base = atomicAdd(&s_qn, wave_total);
-            base = __shfl(base, 63);
-            int slot = base + incl - cnt;
-            uint32_t m = pass;
+            q1n = __shfl(incl, 63);
+            int slot = incl - cnt;
+            uint32_t m = mask;
             while (m) {
-                const int k = __ffs(m) - 1;
+                const int b = __ffs(m) - 1;
                 m &= m - 1;
-                queue[slot++] = (uint16_t)((r << 8) | (4 * g + k - 3));
+                const int i = (b >> 2) * 64 + lane;
+                queue1[slot++] = (uint16_t)(((i >> 3) << 8) | (4 * ((i & 7) + 1) + (b & 3))); // (row, tc)
             }
         }
-    }
-    __syncthreads();
-    const int qn = s_qn;
-    // ---- 3. exact strength of the survivors
-    for (int i = tid; i < qn; i += 256) {
-        const int e = queue[i], r = e >> 8, col = e & 255;
-        const int sc = fast_strength(&tile[(r + 3) * FAST_TP + col + 3], tlow);
-        score[(r + 1) * FAST_SP + col + 1] = (uint8_t)sc;
-    }
-    __syncthreads();
-    // ---- 4. NMS inside each 30-px cell, vote, emission
-    uint32_t keepers[(FAST_QCAP + 255) / 256 > 8 ? 8 : (FAST_QCAP + 255) / 256];
-    int n_keep = 0;
-    // a thread sees at most ceil(qn/256) entries; local maxima are at most 1 in 4 of them, but keep it simple:
-    // survivors beyond the private list are re-derived in the emission loop
-    for (int i = tid; i < qn; i += 256) {
-        const int e = queue[i], r = e >> 8, col = e & 255;
-        const uint8_t *sp = &score[(r + 1) * FAST_SP + col + 1];
-        const int sc = sp[0];
-        bool keep = false;
-        if (sc > 0) {
-            const int xin = col % ORBX_CELL;
-            const bool l = xin != 0, rr = xin != ORBX_CELL - 1; // neighbours in the adjacent cell count as 0
-            keep = sc > sp[-FAST_SP] && sc > sp[FAST_SP] && (!l || (sc > sp[-1] && sc > sp[-FAST_SP - 1] && sc > sp[FAST_SP - 1])) &&
-                   (!rr || (sc > sp[1] && sc > sp[-FAST_SP + 1] && sc > sp[FAST_SP + 1]));
+        __syncthreads();
+        // ---- exact 8-pair test -> queue 2
+        int q2n = 0;
+        for (int i0 = 0; i0 < q1n; i0 += 64) {
+            const int i = i0 + lane;
+            bool ok = false;
+            int e = 0;
+            if (i < q1n) {
+                e = queue1[i];
+                int d[16];
+                fastc_load_ring(&tile[((e >> 8) + 3) * FC_TP + (e & 255)], d);
+                ok = fast_pairs(d, thr);
+            }
+            const u64 mk = __ballot(ok);
+            const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (ok) queue2[q2n + pre] = (uint16_t)e;
+            q2n += (int)__popcll(mk);
         }
-        if (keep && sc >= ini_th) atomicAdd(&s_n_ini[col / ORBX_CELL], 1);
-        queue[i] = keep ? (uint16_t)e : (uint16_t)0xFFFF; // rows < 30, so 0xFFFF never is a valid entry
-        (void)keepers; (void)n_keep;
-    }
-    __syncthreads();
-    int mine = 0;
-    for (int i = tid; i < qn; i += 256) {
-        const int e = queue[i];
-        if (e == 0xFFFF) continue;
-        const int r = e >> 8, col = e & 255;
-        const int sc = score[(r + 1) * FAST_SP + col + 1];
-        const int thr = s_n_ini[col / ORBX_CELL] > 0 ? ini_th : min_th; // reference :604-607
-        if (sc >= thr) ++mine; else queue[i] = 0xFFFF;
-    }
-    int slot = 0;
-    if (mine) slot = atomicAdd(&s_n_emit, mine);
-    __syncthreads();
-    if (tid == 0 && s_n_emit > 0) s_base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], s_n_emit);
-    __syncthreads();
-    if (mine) {
-        u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + s_base + slot;
-        for (int i = tid; i < qn; i += 256) {
-            const int e = queue[i];
-            if (e == 0xFFFF) continue;
-            const int r = e >> 8, col = e & 255;
-            const uint32_t sc = score[(r + 1) * FAST_SP + col + 1];
-            const uint32_t x = sg.cx0 * ORBX_CELL + col, y = sg.cy * ORBX_CELL + r;
-            *out++ = (u64)(x | (y << 16)) | ((u64)sc << 32);
+        __syncthreads();
+        // ---- exact strength
+        for (int i = lane; i < q2n; i += 64) {
+            const int e = queue2[i], r = e >> 8, tc = e & 255;
+            int d[16];
+            fastc_load_ring(&tile[(r + 3) * FC_TP + tc], d);
+            const int sc = fast_score(d);
+            if (sc >= thr) score[(r + 1) * FC_SP + tc - 3] = (uint8_t)sc;
         }
+        __syncthreads();
+        // ---- strict 3x3 NMS (everything outside the cell is 0 in the score map)
+        for (int i = lane; i < q2n; i += 64) {
+            const int e = queue2[i], r = e >> 8, tc = e & 255;
+            const uint8_t *sp = &score[(r + 1) * FC_SP + tc - 3];
+            const int sc = sp[0];
+            if (sc > 0 && sc > sp[-1] && sc > sp[1] && sc > sp[-FC_SP - 1] && sc > sp[-FC_SP] && sc > sp[-FC_SP + 1] &&
+                sc > sp[FC_SP - 1] && sc > sp[FC_SP] && sc > sp[FC_SP + 1])
+                keepers[atomicAdd(&s_nkeep, 1)] = (uint32_t)r | ((uint32_t)(tc - 4) << 8) | ((uint32_t)sc << 16);
+        }
+        __syncthreads();
+        if (s_nkeep > 0 || pass == 1) break;
+        thr = levels->min_th; // reference :604-607: nothing at the ini threshold -> redo the cell at the min threshold
+    }
+    const int nk = s_nkeep;
+    if (nk == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], nk);
+    base = __shfl(base, 0);
+    u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + base;
+    for (int i = lane; i < nk; i += 64) {
+        const uint32_t e = keepers[i];
+        const uint32_t x = cl.cx * ORBX_CELL + ((e >> 8) & 255), y = cl.cy * ORBX_CELL + (e & 255);
+        out[i] = (u64)(x | (y << 16)) | ((u64)(e >> 16) << 32);
     }
 }
 
+int orbx_build_fast_cells(const OrbxLevels &levels, uint16_t *out /* 4 per cell, or NULL to count */)
+{
+    int n = 0;
+    for (int l = 0; l < levels.n_levels; ++l) {
+        const OrbxLevel &v = levels.lv[l];
+        for (int cy = 0; cy < v.n_rows; ++cy)
+            for (int cx = 0; cx < v.n_cols; ++cx) {
+                if (out) { out[4 * n] = (uint16_t)l; out[4 * n + 1] = (uint16_t)cy; out[4 * n + 2] = (uint16_t)cx; out[4 * n + 3] = 0; }
+                ++n;
+            }
+    }
+    return n;
+}
+
+int orbx_debug_flags = 0; // timing experiments only (tools/phase_timing.py); 0 in production
+extern "C" void orbx_debug_set_flags(int f) { orbx_debug_flags = f; }
+
 void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
-                      const OrbxLevels &levels, const OrbxBuffers &b, const void *d_segs, int n_segs, int n_frames)
+                      const OrbxLevels &levels, const OrbxBuffers &b, const void *d_segs, int n_segs, const void *d_cells,
+                      int n_cells, int n_frames)
 {
     if (n_segs <= 0) return;
     FastSrc src;
@@ -285,8 +553,13 @@ void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pit
         src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
         src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
     }
-    hipLaunchKernelGGL(k_fast_strips, dim3(n_segs, n_frames), dim3(256), 0, s, src, d_levels,
-                       reinterpret_cast<const FastSeg *>(d_segs), b.cand, b.cand_frame_stride, b.cand_count);
+    if (orbx_debug_flags & 16)
+        hipLaunchKernelGGL(k_fast_strips, dim3(n_segs, n_frames), dim3(256), 0, s, src, d_levels,
+                           reinterpret_cast<const FastSeg *>(d_segs), b.cand, b.cand_frame_stride, b.cand_count,
+                           orbx_debug_flags);
+    else
+        hipLaunchKernelGGL(k_fast_cells_wave, dim3(n_cells, n_frames), dim3(64), 0, s, src, d_levels,
+                           reinterpret_cast<const FastCell *>(d_cells), b.cand, b.cand_frame_stride, b.cand_count);
 }
 
 // host side: segment table for the current geometry (4 x uint16 per segment)
@@ -1080,19 +1353,36 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
     const int rpitch = level == 0 ? l0_pitch : pitch;
     const uint8_t *blur = b.img_arena + (size_t)frame * b.img_frame_stride + lv.blur_off;
 
+    // intensity centroid (:18-42): lane = (patch row, half).  Each lane fetches its 16 bytes with one
+    // unaligned 128-bit load (no dependent byte-load chain) and reduces them with v_dot4 / v_sad_u8:
+    //   right half: u = 0..15 at bytes x+0..x+15;  left half: u = -16..-1 at bytes x-16..x-1.
     int m10 = 0, m01 = 0;
     if (lane < 2 * (2 * ORBX_HALF_PATCH + 1)) {
         const int v = (lane >> 1) - ORBX_HALF_PATCH, half = lane & 1;
         const int d = u_max[v < 0 ? -v : v];
-        const uint8_t *row = raw + (size_t)(y + v) * rpitch + x;
-        const int u0 = half ? 0 : -d, u1 = half ? d : -1;
-        int rs = 0;
-        for (int u = u0; u <= u1; ++u) {
-            const int val = row[u];
-            m10 += u * val;
-            rs += val;
+        const uint8_t *p = raw + (size_t)(y + v) * rpitch + x + (half ? 0 : -16);
+        struct __attribute__((packed, aligned(1))) U128 { uint32_t w[4]; };
+        const U128 q = *reinterpret_cast<const U128 *>(p);
+        // keep |u| <= d: right half bytes 0..d, left half bytes (16-d)..15
+        uint32_t s = 0, wsum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t keep = 0;
+#pragma unroll
+            for (int bq = 0; bq < 4; ++bq) {
+                const int idx = 4 * k + bq;
+                const bool on = half ? (idx <= d) : (idx >= 16 - d);
+                keep |= on ? (0xFFu << (8 * bq)) : 0u;
+            }
+            const uint32_t w = q.w[k] & keep;
+            // |u| weights: right half idx, left half 16 - idx
+            const uint32_t wr = (uint32_t)(4 * k) | ((uint32_t)(4 * k + 1) << 8) | ((uint32_t)(4 * k + 2) << 16) | ((uint32_t)(4 * k + 3) << 24);
+            const uint32_t wl = (uint32_t)(16 - 4 * k) | ((uint32_t)(15 - 4 * k) << 8) | ((uint32_t)(14 - 4 * k) << 16) | ((uint32_t)(13 - 4 * k) << 24);
+            wsum = __builtin_amdgcn_udot4(w, half ? wr : wl, wsum, false);
+            s = __builtin_amdgcn_sad_u8(w, 0u, s);
         }
-        m01 = v * rs;
+        m10 = half ? (int)wsum : -(int)wsum;
+        m01 = v * (int)s;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
