@@ -53,15 +53,18 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
             w1 |= (unsigned long long)S1[sx0 + k] << (8 * k);
         }
     }
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t w0l = (uint32_t)w0, w0h = (uint32_t)(w0 >> 32), w1l = (uint32_t)w1, w1h = (uint32_t)(w1 >> 32);
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int o = 8 * (ofs[i] - sx0); // taps of the padding entries repeat the last column: still within 8 bytes
-        const int c0 = (int)(short)(cc[i] & 0xFFFF), c1 = (int)(short)(cc[i] >> 16);
-        const int a0 = (int)((w0 >> o) & 255), a1 = (int)((w0 >> (o + 8)) & 255);
-        const int e0 = (int)((w1 >> o) & 255), e1 = (int)((w1 >> (o + 8)) & 255);
-        const int r0 = a0 * c0 + a1 * c1;
-        const int r1 = e0 * c0 + e1 * c1;
+        // the two source bytes (o, o+1) of each row land in the 16-bit halves of one register (v_perm_b32),
+        // then one v_dot2_u32_u16 applies the taps (c0 | c1 << 16 as stored in the table)
+        const uint32_t o = (uint32_t)(ofs[i] - sx0); // 0..6; padding entries repeat the last column
+        const uint32_t sel = o * 0x00010001u + 0x0c010c00u;
+        const u16x2 cv = __builtin_bit_cast(u16x2, cc[i]);
+        const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w0h, w0l, sel)), cv, 0u, false);
+        const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1h, w1l, sel)), cv, 0u, false);
         const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
         packed |= (uint32_t)(v & 255) << (8 * i);
     }
@@ -583,9 +586,9 @@ int orbx_build_fast_segments(const OrbxLevels &levels, uint16_t *out /* 4 per se
 // ---------------------------------------------------------------------------------------------
 // 7x7 Gaussian, 8.8 fixed-point taps, BORDER_REFLECT_101: H pass exact in u16, V pass rounded >>16
 // ---------------------------------------------------------------------------------------------
-#define BL_W 64
-#define BL_H 32
-#define BL_RP 80 // raw tile pitch: tile column rc <-> level x = x0 - 8 + rc
+#define BL_W 256 // tile = 64 lanes x 4 pixels wide ...
+#define BL_ROWS 32
+#define BL_H (4 * BL_ROWS) // ... and 4 waves x 32 rows high
 struct BlurTile {
     uint16_t level, tx, ty, pad;
 };
@@ -597,74 +600,82 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-// One workgroup = one 64x32 output tile of one level of one frame; one launch covers all levels.
-// H pass: two v_dot4_u32_u8 per pixel on byte windows built with v_alignbyte; exact u16 results in LDS.
-// V pass: 7 multiply-adds per pixel, (sum + 2^15) >> 16, four pixels stored as one dword.
-__global__ __launch_bounds__(256) void k_blur_tiles(FastSrc src, const OrbxLevels *__restrict__ levels,
-                                                    const BlurTile *__restrict__ tiles, uint8_t *__restrict__ arena,
-                                                    size_t arena_fs, const int *__restrict__ taps)
+// horizontal 7-tap sums (exact, <= 65535) of the four pixels whose left neighbourhood starts at byte 0
+// of d1: d0|d1|d2 hold level bytes x-4 .. x+7
+__device__ __forceinline__ void blur_hrow(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t K0, uint32_t K1, uint32_t o[4])
 {
-    __shared__ __align__(16) uint8_t raw[(BL_H + 6) * BL_RP];
-    __shared__ __align__(16) uint16_t hor[(BL_H + 6) * BL_W];
+    o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false), false);
+    o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false), false);
+    o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false), false);
+    o[3] = __builtin_amdgcn_udot4(d2, K1, __builtin_amdgcn_udot4(d1, K0, 0u, false), false);
+}
+
+// 7x7 Gaussian as a register sliding window: a thread owns 4 adjacent columns and walks down 32 output
+// rows.  Per input row it loads 12 bytes, forms the four horizontal sums with v_alignbyte + v_dot4_u32_u8
+// and keeps the last seven rows of sums in registers (ring unrolled by 7, so slots are compile-time);
+// every row after the sixth emits one output dword = sat8((sum k_j * H_j + 2^15) >> 16).  No LDS, no barrier.
+__global__ __launch_bounds__(256) void k_blur_cols(FastSrc src, const OrbxLevels *__restrict__ levels,
+                                                   const BlurTile *__restrict__ tiles, uint8_t *__restrict__ arena,
+                                                   size_t arena_fs, const int *__restrict__ taps)
+{
     const BlurTile t = tiles[blockIdx.x];
-    const int frame = blockIdx.y, tid = threadIdx.x, level = t.level;
+    const int frame = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, level = t.level;
     const OrbxLevel &lv = levels->lv[level];
     const int w = lv.w, h = lv.h, pitch = src.pitch[level];
+    const int x = t.tx * BL_W + 4 * lane;
+    const int ys = t.ty * BL_H + wave * BL_ROWS;
+    if (x >= w || ys >= h) return;
+    const int ye = min(ys + BL_ROWS, h);
     const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level];
     uint8_t *D = arena + (size_t)frame * arena_fs + lv.blur_off;
-    const int x0 = t.tx * BL_W, y0 = t.ty * BL_H;
-    int k[7];
+    uint32_t k[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) k[i] = taps[i];
-    const uint32_t K0 = (uint32_t)k[0] | ((uint32_t)k[1] << 8) | ((uint32_t)k[2] << 16) | ((uint32_t)k[3] << 24);
-    const uint32_t K1 = (uint32_t)k[4] | ((uint32_t)k[5] << 8) | ((uint32_t)k[6] << 16);
+    for (int i = 0; i < 7; ++i) k[i] = (uint32_t)taps[i];
+    const uint32_t K0 = k[0] | (k[1] << 8) | (k[2] << 16) | (k[3] << 24), K1 = k[4] | (k[5] << 8) | (k[6] << 16);
+    const bool interior = x >= 4 && x + 8 <= w; // all 12 bytes inside the row
+    uint32_t hq[7][4];
 
-    for (int i = tid; i < (BL_H + 6) * (BL_RP / 4); i += 256) {
-        const int ry = i / (BL_RP / 4), dc = i - ry * (BL_RP / 4);
-        const int gx = x0 - 8 + 4 * dc;
-        const uint8_t *row = S + (size_t)reflect101(y0 - 3 + ry, h) * pitch;
-        uint32_t v;
-        if (gx >= 0 && gx + 3 < w) v = reinterpret_cast<const UnalignedU32 *>(row + gx)->v;
-        else {
-            v = 0;
+    auto load_row = [&](int rr, uint32_t o[4]) {
+        const uint8_t *row = S + (size_t)reflect101(rr, h) * pitch;
+        uint32_t d0, d1, d2;
+        if (interior) {
+            d0 = reinterpret_cast<const UnalignedU32 *>(row + x - 4)->v;
+            d1 = reinterpret_cast<const UnalignedU32 *>(row + x)->v;
+            d2 = reinterpret_cast<const UnalignedU32 *>(row + x + 4)->v;
+        } else { // BORDER_REFLECT_101 on the columns
+            d0 = d1 = d2 = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) v |= (uint32_t)row[reflect101(gx + b, w)] << (8 * b);
+            for (int b = 0; b < 4; ++b) {
+                d0 |= (uint32_t)row[reflect101(x - 4 + b, w)] << (8 * b);
+                d1 |= (uint32_t)row[reflect101(x + b, w)] << (8 * b);
+                d2 |= (uint32_t)row[reflect101(x + 4 + b, w)] << (8 * b);
+            }
         }
-        *reinterpret_cast<uint32_t *>(&raw[ry * BL_RP + 4 * dc]) = v;
-    }
-    __syncthreads();
-    for (int i = tid; i < (BL_H + 6) * (BL_W / 4); i += 256) {
-        const int ry = i / (BL_W / 4), g = i - ry * (BL_W / 4);
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(&raw[ry * BL_RP + 4 + 4 * g]); // bytes x-4 .. x+7
-        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-        uint32_t o[4];
-        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false), false);
-        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false), false);
-        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false), false);
-        o[3] = __builtin_amdgcn_udot4(d2, K1, __builtin_amdgcn_udot4(d1, K0, 0u, false), false);
-        uint2 st;
-        st.x = min(o[0], 65535u) | (min(o[1], 65535u) << 16);
-        st.y = min(o[2], 65535u) | (min(o[3], 65535u) << 16);
-        *reinterpret_cast<uint2 *>(&hor[ry * BL_W + 4 * g]) = st;
-    }
-    __syncthreads();
-    for (int i = tid; i < BL_H * (BL_W / 4); i += 256) {
-        const int ty = i / (BL_W / 4), g = i - ty * (BL_W / 4);
-        const int x = x0 + 4 * g, y = y0 + ty;
-        if (x >= w || y >= h) continue;
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        blur_hrow(d0, d1, d2, K0, K1, o);
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const uint2 hv = *reinterpret_cast<const uint2 *>(&hor[(ty + j) * BL_W + 4 * g]);
-            a0 += (uint32_t)k[j] * (hv.x & 0xFFFF);
-            a1 += (uint32_t)k[j] * (hv.x >> 16);
-            a2 += (uint32_t)k[j] * (hv.y & 0xFFFF);
-            a3 += (uint32_t)k[j] * (hv.y >> 16);
+        for (int i = 0; i < 4; ++i) o[i] = min(o[i], 65535u);
+    };
+    // prime the ring with input rows ys-3 .. ys+2 in slots 0..5
+#pragma unroll
+    for (int s = 0; s < 6; ++s) load_row(ys - 3 + s, hq[s]);
+    for (int y0 = ys; y0 < ye; y0 += 7) {
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            const int y = y0 + s; // output row; its newest input row y+3 goes to slot (6+s)%7
+            if (y < ye) {
+                load_row(y + 3, hq[(6 + s) % 7]);
+                uint32_t r[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t acc = 32768u;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) acc += k[j] * hq[(s + j) % 7][i]; // oldest row y-3 sits in slot s%7
+                    r[i] = min(acc >> 16, 255u);
+                }
+                // rows of the arena are padded to a multiple of 64 bytes: the dword store stays inside the row
+                *reinterpret_cast<uint32_t *>(D + (size_t)y * lv.pitch + x) = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+            }
         }
-        const uint32_t r0 = min((a0 + 32768u) >> 16, 255u), r1 = min((a1 + 32768u) >> 16, 255u);
-        const uint32_t r2 = min((a2 + 32768u) >> 16, 255u), r3 = min((a3 + 32768u) >> 16, 255u);
-        // rows of the arena are padded to a multiple of 64 bytes: the dword store stays inside the row
-        *reinterpret_cast<uint32_t *>(D + (size_t)y * lv.pitch + x) = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
     }
 }
 
@@ -679,7 +690,7 @@ void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pit
         src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
         src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
     }
-    hipLaunchKernelGGL(k_blur_tiles, dim3(n_tiles, n_frames), dim3(256), 0, s, src, d_levels,
+    hipLaunchKernelGGL(k_blur_cols, dim3(n_tiles, n_frames), dim3(256), 0, s, src, d_levels,
                        reinterpret_cast<const BlurTile *>(d_tiles), b.img_arena, b.img_frame_stride, taps7);
 }
 
