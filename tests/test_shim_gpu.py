@@ -1,0 +1,66 @@
+"""The C++ shims with the reference's class signatures, run end to end on the GPU and compared with the
+ctypes path and the oracle (same bits expected everywhere)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from monoorbslam3_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_shim_end_to_end(oracle_mod, tmp_path):
+    from monoorbslam3_amd.extractor import KP_DTYPE
+    from monoorbslam3_amd.matcher import ORBMatcher
+    exe = str(tmp_path / "shim_smoke")
+    lib = os.path.join(ROOT, "monoorbslam3_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "monoorbslam3_amd", "compat"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_smoke.cpp"), "-o", exe,
+                           "-L", lib, "-lorbx", "-Wl,-rpath," + lib])
+    w, h = 752, 480
+    canvas = synth.make_canvas(w + 40, h + 20, seed=1234)
+    f1 = np.ascontiguousarray(canvas[5:5 + h, 10:10 + w])
+    f2 = np.ascontiguousarray(canvas[8:8 + h, 19:19 + w])
+    raw = tmp_path / "in.raw"
+    with open(raw, "wb") as f:
+        f.write(b"%d %d\n" % (w, h))
+        f.write(f1.tobytes())
+        f.write(f2.tobytes())
+    out = tmp_path / "out.bin"
+    print(subprocess.check_output([exe, str(raw), str(out)], text=True))
+    buf = open(out, "rb").read()
+    n1, n2, n_ini, n_bow, n_tri, levels = np.frombuffer(buf, np.int32, 6)
+    o = 24
+    k1 = np.frombuffer(buf, KP_DTYPE, n1, o); o += 28 * n1
+    d1 = np.frombuffer(buf, np.uint8, 32 * n1, o).reshape(n1, 32); o += 32 * n1
+    k2 = np.frombuffer(buf, KP_DTYPE, n2, o); o += 28 * n2
+    d2 = np.frombuffer(buf, np.uint8, 32 * n2, o).reshape(n2, 32); o += 32 * n2
+    m_ini = np.frombuffer(buf, np.int32, n1, o); o += 4 * n1
+    bow = np.frombuffer(buf, np.int32, n2, o); o += 4 * n2
+    m_tri = np.frombuffer(buf, np.int32, n1, o)
+    assert levels == 8
+    # extraction: the 2N "initial" extractor of a 1000-feature one == oracle with re-quota
+    orc = oracle_mod.Oracle(1000, 1.2, 8, 20, 7)
+    orc.requota(2000)
+    for img, k, d in ((f1, k1, d1), (f2, k2, d2)):
+        ok, od, _ = orc.extract(img)
+        assert len(ok) == len(k)
+        for fld in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+            assert np.array_equal(k[fld], ok[fld]), fld
+        assert np.array_equal(d, od)
+    # matchers vs oracle on the same data
+    pre = np.stack([k1["x"], k1["y"]], axis=1)
+    r_n, r_m, _ = oracle_mod.search_for_initialization(0.9, True, k1, d1, k2, d2, w, h, pre, 100)
+    assert (n_ini, m_ini.tolist()) == (r_n, r_m.tolist()) and n_ini > 50
+    fv1 = synth.feature_vector_by_prefix(d1, 6)
+    fv2 = synth.feature_vector_by_prefix(d2, 6)
+    ok1 = (np.arange(n1) % 3 != 0).astype(np.uint8)
+    r_n, r_mp = oracle_mod.search_by_bow(0.7, True, d1, k1["angle"], ok1, fv1, d2, k2["angle"], np.full(n2, -1, np.int32), fv2)
+    assert n_bow == r_n and np.array_equal(bow, r_mp) and n_bow > 20
+    r_n, r_m = oracle_mod.search_for_triangulation(False, d1, k1["angle"], ok1, fv1, d2, k2["angle"], np.zeros(n2, np.uint8), fv2)
+    assert n_tri == r_n and np.array_equal(m_tri, r_m)
+    assert ORBMatcher.DescriptorDistance(d1[0], d2[0]) == int(np.unpackbits(d1[0] ^ d2[0]).sum())
