@@ -252,6 +252,7 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
         HIP_TRY(dev_alloc(&b.childpos, 4 * node_fs * B));
         HIP_TRY(dev_alloc(&b.best, node_fs * B));
         HIP_TRY(dev_alloc(&b.sel, (size_t)kcap * B));
+        HIP_TRY(dev_alloc(&b.kp_ang, (size_t)kcap * B));
         HIP_TRY(dev_alloc(&b.sel_count, (size_t)ORBX_MAX_LEVELS * B));
         HIP_TRY(dev_alloc(&c->d_l0_stage, l0_fs * B));
         c->alloc_batch = B; c->alloc_img_fs = img_fs; c->alloc_cand_fs = cand_fs; c->alloc_node_fs = node_fs;
@@ -382,7 +383,7 @@ extern "C" void orbx_destroy(orbx_t *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     OrbxBuffers &b = c->buf;
     void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.pcode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
-                    b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.sel_count, c->d_levels, c->d_umax, c->d_taps,
+                    b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.kp_ang, b.sel_count, c->d_levels, c->d_umax, c->d_taps,
                     c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n, c->d_fast_segs, c->d_fast_cells, c->d_blur_tiles};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {

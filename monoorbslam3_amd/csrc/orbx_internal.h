@@ -59,6 +59,7 @@ struct OrbxBuffers {
     unsigned long long *best;
     uint2 *sel;                                           // [frame][kcap_total] selected keypoints (x | y<<16, response)
     int *sel_count;                                       // [frame][level]
+    float4 *kp_ang;                                       // [frame][kcap_total] (angle, cos, sin, -) per selected keypoint
 };
 
 void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh,

@@ -12,6 +12,20 @@
 
 typedef unsigned long long u64;
 
+// XCD-aware work mapping (speed only, never correctness).  Workgroups are dealt round-robin over the 8 XCDs,
+// each with a private 4 MB L2; linear block id -> (xcd = id % 8, j = id / 8) and XCD x takes the frames
+// congruent to x (mod 8), so everything that touches one frame's pyramid meets in one L2.
+// Launch with orbx_xcd_grid(per_frame, n_frames) blocks.
+__device__ __forceinline__ bool xcd_remap(int per_frame, int n_frames, int *frame, int *item)
+{
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    const int g = j / per_frame;
+    *item = j - g * per_frame;
+    *frame = g * 8 + xcd;
+    return *frame < n_frames;
+}
+static inline unsigned orbx_xcd_grid(int per_frame, int n_frames) { return 8u * (unsigned)((n_frames + 7) / 8) * (unsigned)per_frame; }
+
 __constant__ int8_t c_pattern[ORB_PATTERN_POINTS * 2] = {ORB_PATTERN_INT8_LIST};
 
 // ---------------------------------------------------------------------------------------------
@@ -23,60 +37,69 @@ __constant__ int8_t c_pattern[ORB_PATTERN_POINTS * 2] = {ORB_PATTERN_INT8_LIST};
 // loads.
 struct __attribute__((packed, aligned(1))) UnalignedU64 { unsigned long long v; };
 
+#define RS_ROWS 4 // output rows per thread: 2*RS_ROWS independent 64-bit loads in flight per thread
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, size_t src_fs, int src_pitch, int sw,
                                                 int sh, uint8_t *__restrict__ dst, size_t dst_fs, int dst_pitch,
                                                 int dw, int dh, const OrbxTap *__restrict__ xtap,
                                                 const OrbxTap *__restrict__ ytap)
 {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    if (dx0 >= dw || dy >= dh) return;
+    const int dy0 = (blockIdx.y * 4 + threadIdx.y) * RS_ROWS;
+    if (dx0 >= dw || dy0 >= dh) return;
     const uint8_t *S = src + (size_t)blockIdx.z * src_fs;
-    uint8_t *D = dst + (size_t)blockIdx.z * dst_fs + (size_t)dy * dst_pitch;
-    const OrbxTap ty = ytap[dy];
-    const int sy0 = min(max(ty.ofs, 0), sh - 1), sy1 = min(max(ty.ofs + 1, 0), sh - 1);
-    const uint8_t *S0 = S + (size_t)sy0 * src_pitch, *S1 = S + (size_t)sy1 * src_pitch;
-    const int b0 = ty.c0, b1 = ty.c1;
+    uint8_t *D = dst + (size_t)blockIdx.z * dst_fs;
     // the tap table is padded to a multiple of 4 entries (host side), 32 bytes per thread
     const uint4 t01 = reinterpret_cast<const uint4 *>(xtap + dx0)[0], t23 = reinterpret_cast<const uint4 *>(xtap + dx0)[1];
     const int ofs[4] = {(int)t01.x, (int)t01.z, (int)t23.x, (int)t23.z};
     const uint32_t cc[4] = {t01.y, t01.w, t23.y, t23.w}; // c0 | c1 << 16
     const int sx0 = ofs[0];
-    unsigned long long w0, w1;
-    if (sx0 + 8 <= sw) {
-        w0 = reinterpret_cast<const UnalignedU64 *>(S0 + sx0)->v;
-        w1 = reinterpret_cast<const UnalignedU64 *>(S1 + sx0)->v;
-    } else { // right image edge: never read past the end of the row
-        w0 = w1 = 0;
-        for (int k = 0; k < sw - sx0; ++k) {
-            w0 |= (unsigned long long)S0[sx0 + k] << (8 * k);
-            w1 |= (unsigned long long)S1[sx0 + k] << (8 * k);
+    const bool wide_ok = sx0 + 8 <= sw;
+    unsigned long long w0[RS_ROWS], w1[RS_ROWS];
+    int b0[RS_ROWS], b1[RS_ROWS];
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+        const OrbxTap ty = ytap[min(dy0 + r, dh - 1)];
+        b0[r] = ty.c0; b1[r] = ty.c1;
+        const int sy0 = min(max(ty.ofs, 0), sh - 1), sy1 = min(max(ty.ofs + 1, 0), sh - 1);
+        const uint8_t *S0 = S + (size_t)sy0 * src_pitch + sx0, *S1 = S + (size_t)sy1 * src_pitch + sx0;
+        if (wide_ok) {
+            w0[r] = reinterpret_cast<const UnalignedU64 *>(S0)->v;
+            w1[r] = reinterpret_cast<const UnalignedU64 *>(S1)->v;
+        } else { // right image edge: never read past the end of the row
+            w0[r] = w1[r] = 0;
+            for (int k = 0; k < sw - sx0; ++k) {
+                w0[r] |= (unsigned long long)S0[k] << (8 * k);
+                w1[r] |= (unsigned long long)S1[k] << (8 * k);
+            }
         }
     }
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    const uint32_t w0l = (uint32_t)w0, w0h = (uint32_t)(w0 >> 32), w1l = (uint32_t)w1, w1h = (uint32_t)(w1 >> 32);
-    uint32_t packed = 0;
+    uint32_t sel[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        // the two source bytes (o, o+1) of each row land in the 16-bit halves of one register (v_perm_b32),
-        // then one v_dot2_u32_u16 applies the taps (c0 | c1 << 16 as stored in the table)
-        const uint32_t o = (uint32_t)(ofs[i] - sx0); // 0..6; padding entries repeat the last column
-        const uint32_t sel = o * 0x00010001u + 0x0c010c00u;
-        const u16x2 cv = __builtin_bit_cast(u16x2, cc[i]);
-        const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w0h, w0l, sel)), cv, 0u, false);
-        const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1h, w1l, sel)), cv, 0u, false);
-        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        packed |= (uint32_t)(v & 255) << (8 * i);
+    for (int i = 0; i < 4; ++i) sel[i] = (uint32_t)(ofs[i] - sx0) * 0x00010001u + 0x0c010c00u; // bytes (o, o+1) -> 16-bit halves
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+        if (dy0 + r >= dh) break;
+        const uint32_t w0l = (uint32_t)w0[r], w0h = (uint32_t)(w0[r] >> 32), w1l = (uint32_t)w1[r], w1h = (uint32_t)(w1[r] >> 32);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u16x2 cv = __builtin_bit_cast(u16x2, cc[i]);
+            const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w0h, w0l, sel[i])), cv, 0u, false);
+            const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1h, w1l, sel[i])), cv, 0u, false);
+            const int v = (((b0[r] * (r0 >> 4)) >> 16) + ((b1[r] * (r1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 255) << (8 * i);
+        }
+        // rows of the arena are 64-byte aligned and padded, so the dword store is always in bounds
+        *reinterpret_cast<uint32_t *>(D + (size_t)(dy0 + r) * dst_pitch + dx0) = packed;
     }
-    // rows of the arena are 64-byte aligned and padded, so the dword store is always in bounds
-    *reinterpret_cast<uint32_t *>(D + dx0) = packed;
 }
 
 void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh,
                         uint8_t *dst, size_t dst_fs, int dst_pitch, int dw, int dh, const OrbxTap *xtap,
                         const OrbxTap *ytap, int n_frames)
 {
-    dim3 block(64, 4), grid((dw + 255) / 256, (dh + 3) / 4, n_frames);
+    dim3 block(64, 4), grid((dw + 255) / 256, (dh + 4 * RS_ROWS - 1) / (4 * RS_ROWS), n_frames);
     hipLaunchKernelGGL(k_resize, grid, block, 0, s, src, src_fs, src_pitch, sw, sh, dst, dst_fs, dst_pitch, dw, dh,
                        xtap, ytap);
 }
@@ -384,7 +407,8 @@ struct __attribute__((packed, aligned(1))) UnalignedU64b { unsigned long long v;
 
 __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxLevels *__restrict__ levels,
                                                         const FastCell *__restrict__ cells, u64 *__restrict__ cand,
-                                                        size_t cand_fs, int *__restrict__ cand_count)
+                                                        size_t cand_fs, int *__restrict__ cand_count, int n_cells,
+                                                        int n_frames)
 {
     __shared__ __align__(16) uint8_t tile[36 * FC_TP];
     __shared__ __align__(16) uint8_t score[32 * FC_SP];
@@ -392,8 +416,10 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
     __shared__ uint32_t keepers[15 * 15];
     __shared__ int s_nkeep;
 
-    const FastCell cl = cells[blockIdx.x];
-    const int frame = blockIdx.y, lane = threadIdx.x;
+    int frame, cell_id;
+    if (!xcd_remap(n_cells, n_frames, &frame, &cell_id)) return;
+    const FastCell cl = cells[cell_id];
+    const int lane = threadIdx.x;
     const int level = cl.level;
     const OrbxLevel &lv = levels->lv[level];
     const int x0 = ORBX_EDGE + cl.cx * ORBX_CELL, y0 = ORBX_EDGE + cl.cy * ORBX_CELL;
@@ -561,8 +587,9 @@ void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pit
                            reinterpret_cast<const FastSeg *>(d_segs), b.cand, b.cand_frame_stride, b.cand_count,
                            orbx_debug_flags);
     else
-        hipLaunchKernelGGL(k_fast_cells_wave, dim3(n_cells, n_frames), dim3(64), 0, s, src, d_levels,
-                           reinterpret_cast<const FastCell *>(d_cells), b.cand, b.cand_frame_stride, b.cand_count);
+        hipLaunchKernelGGL(k_fast_cells_wave, dim3(orbx_xcd_grid(n_cells, n_frames)), dim3(64), 0, s, src, d_levels,
+                           reinterpret_cast<const FastCell *>(d_cells), b.cand, b.cand_frame_stride, b.cand_count, n_cells,
+                           n_frames);
 }
 
 // host side: segment table for the current geometry (4 x uint16 per segment)
@@ -1326,112 +1353,186 @@ void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLev
 }
 
 // ---------------------------------------------------------------------------------------------
-// Orientation (intensity centroid on the raw level) + steered BRIEF (on the blurred level) +
-// output record.  One wave64 per keypoint, four keypoints per workgroup:
-//   * moments: lane = (patch row, left/right half), 62 lanes busy, wave reduction by shuffles;
-//   * lane 0 evaluates fastAtan2 and the double-precision sin/cos once, broadcast by readlane;
-//   * lane l owns descriptor bits l, l+64, l+128, l+192: four ballots give the 32 bytes.
+// Orientation: intensity centroid on the raw level (:18-42), 16 lanes per keypoint, 16 keypoints per
+// workgroup.  A lane takes four (patch row, left/right half) tasks: one unaligned 128-bit load each,
+// bytes outside the circular patch masked off, v_dot4_u32_u8 for sum(|u|*I) and v_sad_u8 for sum(I).
+// After a 16-lane shuffle reduction the moments go through LDS to 16 lanes that evaluate fastAtan2 and
+// the double-precision sin/cos once per keypoint (one lane per keypoint instead of one wave).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__ l0, size_t l0_fs, int l0_pitch,
-                                                     const OrbxLevels *__restrict__ levels, OrbxBuffers b,
-                                                     const int *__restrict__ u_max, orbx_kp *__restrict__ out_kp,
-                                                     uint8_t *__restrict__ out_desc, int cap,
-                                                     int32_t *__restrict__ out_n)
+__global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, size_t l0_fs, int l0_pitch,
+                                                const OrbxLevels *__restrict__ levels, OrbxBuffers b,
+                                                const int *__restrict__ u_max, int per_frame, int n_frames)
 {
-    const int frame = blockIdx.y, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ int s_m[16][2];
+    int frame, blk;
+    if (!xcd_remap(per_frame, n_frames, &frame, &blk)) return;
+    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
     const int L = levels->n_levels;
     const int *cnts = b.sel_count + frame * ORBX_MAX_LEVELS;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int slot = blk * 16 + grp;
+    bool live = slot < levels->kcap_total;
+    int level = 0;
+    for (int l = 1; l < L; ++l) level += live && slot >= levels->lv[l].kp_off;
+    const OrbxLevel &lv = levels->lv[level];
+    live = live && (slot - lv.kp_off) < cnts[level];
+    int m10 = 0, m01 = 0;
+    if (live) {
+        const uint2 rec = b.sel[(size_t)frame * levels->kcap_total + slot];
+        const int x = rec.x & 0xFFFF, y = rec.x >> 16;
+        const uint8_t *raw = level == 0 ? l0 + (size_t)frame * l0_fs : b.img_arena + (size_t)frame * b.img_frame_stride + lv.raw_off;
+        const int rpitch = level == 0 ? l0_pitch : lv.pitch;
+        struct __attribute__((packed, aligned(1))) U128 { uint32_t w[4]; };
+        U128 q[4];
+        int vv[4], dd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { // task t = sub + 16k: row v = t/2 - 15, half = t & 1 (tasks 62, 63 are idle)
+            const int t = sub + 16 * k, v = min(t >> 1, 2 * ORBX_HALF_PATCH) - ORBX_HALF_PATCH;
+            vv[k] = v;
+            dd[k] = t < 2 * (2 * ORBX_HALF_PATCH + 1) ? u_max[v < 0 ? -v : v] : -1;
+            q[k] = *reinterpret_cast<const U128 *>(raw + (size_t)(y + v) * rpitch + x + ((t & 1) ? 0 : -16));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int half = (sub + 16 * k) & 1, d = dd[k];
+            uint32_t ssum = 0, wsum = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                // right half keeps bytes idx <= d (idx = 4w + byte), left half keeps idx >= 16 - d
+                const int n_lo = min(max(d + 1 - 4 * w, 0), 4);        // kept low bytes (right half)
+                const int n_hi = min(max(4 * w + 4 - (16 - d), 0), 4); // kept high bytes (left half)
+                const uint32_t m_lo = n_lo >= 4 ? 0xFFFFFFFFu : ((1u << (8 * n_lo)) - 1u);
+                const uint32_t m_hi = n_hi <= 0 ? 0u : (0xFFFFFFFFu << (8 * (4 - n_hi)));
+                const uint32_t wd = q[k].w[w] & (half ? m_lo : m_hi);
+                const uint32_t wr = (uint32_t)(4 * w) | ((uint32_t)(4 * w + 1) << 8) | ((uint32_t)(4 * w + 2) << 16) | ((uint32_t)(4 * w + 3) << 24);
+                const uint32_t wl = (uint32_t)(16 - 4 * w) | ((uint32_t)(15 - 4 * w) << 8) | ((uint32_t)(14 - 4 * w) << 16) | ((uint32_t)(13 - 4 * w) << 24);
+                wsum = __builtin_amdgcn_udot4(wd, half ? wr : wl, wsum, false);
+                ssum = __builtin_amdgcn_sad_u8(wd, 0u, ssum);
+            }
+            m10 += half ? (int)wsum : -(int)wsum;
+            m01 += vv[k] * (int)ssum;
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+    }
+    if (sub == 0) { s_m[grp][0] = m10; s_m[grp][1] = m01; }
+    __syncthreads();
+    if (tid < 16) {
+        const int s2 = blk * 16 + tid;
+        if (s2 < levels->kcap_total) {
+            const float ang = orb_fast_atan2((float)s_m[tid][1], (float)s_m[tid][0]);
+            float cs, sn;
+            orb_sincos_deg(ang, &cs, &sn);
+            b.kp_ang[(size_t)frame * levels->kcap_total + s2] = make_float4(ang, cs, sn, 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Steered BRIEF on the blurred level (:50-97) + output record (:507-546, :626-632).  One wave64 per
+// keypoint, four keypoints per workgroup; lane l owns descriptor bits l, l+64, l+128, l+192 and four
+// ballots give the 32 bytes.
+// ---------------------------------------------------------------------------------------------
+#define DP_W 64 // patch pitch: four ALIGNED 16-byte loads per row starting at floor16(x-19)
+#define DP_H 37
+#define DP_K 4  // keypoints per wave: their record / patch loads are all issued before the first use
+__global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restrict__ levels, OrbxBuffers b,
+                                                     orbx_kp *__restrict__ out_kp, uint8_t *__restrict__ out_desc,
+                                                     int cap, int32_t *__restrict__ out_n, int dbg, int per_frame,
+                                                     int n_frames)
+{
+    // the 37x37 neighbourhood of each keypoint is staged row by row (coalesced, ~45 cache lines) and the
+    // 512 rotated samples are byte gathers from LDS instead of ~250 scattered cache-line touches
+    __shared__ __align__(16) uint8_t patch[4][DP_K][DP_H * DP_W];
+    int frame, blk;
+    if (!xcd_remap(per_frame, n_frames, &frame, &blk)) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int L = levels->n_levels;
+    const int *cnts = b.sel_count + frame * ORBX_MAX_LEVELS;
+    if (blk == 0 && threadIdx.x == 0) {
         int tot = 0;
         for (int l = 0; l < L; ++l) tot += cnts[l];
         out_n[frame] = tot;
     }
-    if (slot >= levels->kcap_total) return;
-    int level = 0;
-    for (int l = 1; l < L; ++l) level += slot >= levels->lv[l].kp_off;
-    const OrbxLevel &lv = levels->lv[level];
-    const int i = slot - lv.kp_off;
-    if (i >= cnts[level]) return;
-    int out_idx = i;
-    for (int l = 0; l < level; ++l) out_idx += cnts[l];
-    if (out_idx >= cap) return;
-
-    const uint2 rec = b.sel[(size_t)frame * levels->kcap_total + slot];
-    const int x = rec.x & 0xFFFF, y = rec.x >> 16;
-    const int pitch = lv.pitch;
-    const uint8_t *raw = level == 0 ? l0 + (size_t)frame * l0_fs : b.img_arena + (size_t)frame * b.img_frame_stride + lv.raw_off;
-    const int rpitch = level == 0 ? l0_pitch : pitch;
-    const uint8_t *blur = b.img_arena + (size_t)frame * b.img_frame_stride + lv.blur_off;
-
-    // intensity centroid (:18-42): lane = (patch row, half).  Each lane fetches its 16 bytes with one
-    // unaligned 128-bit load (no dependent byte-load chain) and reduces them with v_dot4 / v_sad_u8:
-    //   right half: u = 0..15 at bytes x+0..x+15;  left half: u = -16..-1 at bytes x-16..x-1.
-    int m10 = 0, m01 = 0;
-    if (lane < 2 * (2 * ORBX_HALF_PATCH + 1)) {
-        const int v = (lane >> 1) - ORBX_HALF_PATCH, half = lane & 1;
-        const int d = u_max[v < 0 ? -v : v];
-        const uint8_t *p = raw + (size_t)(y + v) * rpitch + x + (half ? 0 : -16);
-        struct __attribute__((packed, aligned(1))) U128 { uint32_t w[4]; };
-        const U128 q = *reinterpret_cast<const U128 *>(p);
-        // keep |u| <= d: right half bytes 0..d, left half bytes (16-d)..15
-        uint32_t s = 0, wsum = 0;
+    bool live[DP_K];
+    int level[DP_K], out_idx[DP_K];
+    uint2 rec[DP_K];
+    float4 ang[DP_K];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t keep = 0;
-#pragma unroll
-            for (int bq = 0; bq < 4; ++bq) {
-                const int idx = 4 * k + bq;
-                const bool on = half ? (idx <= d) : (idx >= 16 - d);
-                keep |= on ? (0xFFu << (8 * bq)) : 0u;
-            }
-            const uint32_t w = q.w[k] & keep;
-            // |u| weights: right half idx, left half 16 - idx
-            const uint32_t wr = (uint32_t)(4 * k) | ((uint32_t)(4 * k + 1) << 8) | ((uint32_t)(4 * k + 2) << 16) | ((uint32_t)(4 * k + 3) << 24);
-            const uint32_t wl = (uint32_t)(16 - 4 * k) | ((uint32_t)(15 - 4 * k) << 8) | ((uint32_t)(14 - 4 * k) << 16) | ((uint32_t)(13 - 4 * k) << 24);
-            wsum = __builtin_amdgcn_udot4(w, half ? wr : wl, wsum, false);
-            s = __builtin_amdgcn_sad_u8(w, 0u, s);
+    for (int k = 0; k < DP_K; ++k) {
+        const int slot = (blk * 4 + wv) * DP_K + k;
+        live[k] = slot < levels->kcap_total;
+        int lvl = 0;
+        for (int l = 1; l < L; ++l) lvl += live[k] && slot >= levels->lv[l].kp_off;
+        level[k] = lvl;
+        const int i = slot - levels->lv[lvl].kp_off;
+        live[k] = live[k] && i < cnts[lvl];
+        int oi = i;
+        for (int l = 0; l < lvl; ++l) oi += cnts[l];
+        out_idx[k] = oi;
+        live[k] = live[k] && oi < cap;
+        rec[k] = make_uint2(0, 0);
+        ang[k] = make_float4(0.f, 1.f, 0.f, 0.f);
+        if (live[k]) {
+            rec[k] = b.sel[(size_t)frame * levels->kcap_total + slot];
+            ang[k] = b.kp_ang[(size_t)frame * levels->kcap_total + slot];
         }
-        m10 = half ? (int)wsum : -(int)wsum;
-        m01 = v * (int)s;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
+    for (int k = 0; k < DP_K; ++k) {
+        if (live[k] && !(dbg & 32)) {
+            const OrbxLevel &lv = levels->lv[level[k]];
+            const int x = rec[k].x & 0xFFFF, y = rec[k].x >> 16, pitch = lv.pitch;
+            // arena rows are 64-byte aligned, so one shift (x-19)&15 serves the whole patch: the rows go to LDS
+            // as they are (148 aligned 128-bit loads per keypoint) and only the centre index moves
+            const uint8_t *corner = b.img_arena + (size_t)frame * b.img_frame_stride + lv.blur_off + (size_t)(y - 18) * pitch + ((x - 19) & ~15);
+            for (int q = lane; q < DP_H * (DP_W / 16); q += 64) {
+                const int r = q >> 2, dc = q & 3;
+                *reinterpret_cast<uint4 *>(&patch[wv][k][r * DP_W + 16 * dc]) =
+                    *reinterpret_cast<const uint4 *>(corner + (size_t)r * pitch + 16 * dc);
+            }
+        }
     }
-    float ang = 0.f, a = 0.f, bb = 0.f;
-    if (lane == 0) {
-        ang = orb_fast_atan2((float)m01, (float)m10);
-        orb_sincos_deg(ang, &a, &bb);
-    }
-    a = __shfl(a, 0);
-    bb = __shfl(bb, 0);
-    const uint8_t *center = blur + (size_t)y * pitch + x;
-    u64 bits[4];
+    __syncthreads();
+    // this lane's four sampling pairs (the same for every keypoint)
+    float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int t = lane + 64 * j;
-        const float px0 = (float)c_pattern[4 * t], py0 = (float)c_pattern[4 * t + 1];
-        const float px1 = (float)c_pattern[4 * t + 2], py1 = (float)c_pattern[4 * t + 3];
-        const int r0 = orb_round_f(ORB_FADD(ORB_FMUL(px0, bb), ORB_FMUL(py0, a)));
-        const int c0 = orb_round_f(ORB_FSUB(ORB_FMUL(px0, a), ORB_FMUL(py0, bb)));
-        const int r1 = orb_round_f(ORB_FADD(ORB_FMUL(px1, bb), ORB_FMUL(py1, a)));
-        const int c1 = orb_round_f(ORB_FSUB(ORB_FMUL(px1, a), ORB_FMUL(py1, bb)));
-        const int t0 = center[r0 * pitch + c0], t1 = center[r1 * pitch + c1];
-        bits[j] = __ballot(t0 < t1);
+        px0[j] = (float)c_pattern[4 * t]; py0[j] = (float)c_pattern[4 * t + 1];
+        px1[j] = (float)c_pattern[4 * t + 2]; py1[j] = (float)c_pattern[4 * t + 3];
     }
-    if (lane < 4) {
-        const u64 w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-        *reinterpret_cast<u64 *>(out_desc + ((size_t)frame * cap + out_idx) * 32 + 8 * lane) = w;
-    }
-    if (lane == 0) {
-        orbx_kp kp;
-        float fx = (float)x, fy = (float)y;
-        if (level != 0) { fx = ORB_FMUL(fx, lv.scale); fy = ORB_FMUL(fy, lv.scale); }
-        kp.x = fx; kp.y = fy; kp.size = lv.scale; kp.angle = ang; kp.response = (float)rec.y;
-        kp.octave = level; kp.class_id = -1;
-        out_kp[(size_t)frame * cap + out_idx] = kp;
+#pragma unroll
+    for (int k = 0; k < DP_K; ++k) {
+        if (!live[k] || (dbg & 128)) continue;
+        const OrbxLevel &lv = levels->lv[level[k]];
+        const float a = ang[k].y, bb = ang[k].z;
+        const uint8_t *center = &patch[wv][k][18 * DP_W + 19 + (((int)(rec[k].x & 0xFFFF) - 19) & 15)];
+        u64 bits[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r0 = orb_round_f(ORB_FADD(ORB_FMUL(px0[j], bb), ORB_FMUL(py0[j], a)));
+            const int c0 = orb_round_f(ORB_FSUB(ORB_FMUL(px0[j], a), ORB_FMUL(py0[j], bb)));
+            const int r1 = orb_round_f(ORB_FADD(ORB_FMUL(px1[j], bb), ORB_FMUL(py1[j], a)));
+            const int c1 = orb_round_f(ORB_FSUB(ORB_FMUL(px1[j], a), ORB_FMUL(py1[j], bb)));
+            const int t0 = center[r0 * DP_W + c0], t1 = center[r1 * DP_W + c1];
+            bits[j] = __ballot(t0 < t1);
+        }
+        if (lane < 4 && !(dbg & 64)) {
+            const u64 w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+            *reinterpret_cast<u64 *>(out_desc + ((size_t)frame * cap + out_idx[k]) * 32 + 8 * lane) = w;
+        }
+        if (lane == 0 && !(dbg & 64)) {
+            const int x = rec[k].x & 0xFFFF, y = rec[k].x >> 16;
+            orbx_kp kp;
+            float fx = (float)x, fy = (float)y;
+            if (level[k] != 0) { fx = ORB_FMUL(fx, lv.scale); fy = ORB_FMUL(fy, lv.scale); }
+            kp.x = fx; kp.y = fy; kp.size = lv.scale; kp.angle = ang[k].x; kp.response = (float)rec[k].y;
+            kp.octave = level[k]; kp.class_id = -1;
+            out_kp[(size_t)frame * cap + out_idx[k]] = kp;
+        }
     }
 }
 
@@ -1439,7 +1540,9 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
                              uint8_t *out_desc, int cap, int32_t *out_n, int n_frames)
 {
-    dim3 grid((levels.kcap_total + 3) / 4, n_frames);
-    hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, b, u_max, out_kp,
-                       out_desc, cap, out_n);
+    const int pf_o = (levels.kcap_total + 15) / 16, pf_d = (levels.kcap_total + 4 * DP_K - 1) / (4 * DP_K);
+    hipLaunchKernelGGL(k_orient, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, b,
+                       u_max, pf_o, n_frames);
+    hipLaunchKernelGGL(k_orient_desc, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, d_levels, b, out_kp,
+                       out_desc, cap, out_n, orbx_debug_flags, pf_d, n_frames);
 }
