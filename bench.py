@@ -25,6 +25,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# integer VALU issue ceiling measured on MI355X with tools/microbench/valu_peak.hip (xor + v_bcnt mix, 2048 x 256
+# threads): 557 G wave-instructions/s = 35.7 T lane-ops/s.  The Hamming brute force needs >= 16 of them per pair.
+VALU_PEAK_GWINST = 557.4
 
 
 def level_bytes(ex, w, h):
@@ -192,7 +195,21 @@ def main():
     kp_mean = float(counts.mean())
     alg, P = algorithmic_bytes(ex, W, H, int(round(kp_mean)))
     stage_gbs = {k: (alg[k] * B / (acc[k] * 1e-3) / 1e9 if acc[k] > 0 and alg[k] > 0 else None) for k in acc}
-    dominant = max(acc, key=lambda k: acc[k])
+    acc_all = dict(acc)
+    acc_all["match_best2"] = match_ms
+    alg["match_best2"] = int(2 * round(kp_mean) * 32 + round(kp_mean) * 8)
+    stage_gbs["match_best2"] = alg["match_best2"] * B / (match_ms * 1e-3) / 1e9 if match_ms > 0 else None
+    dominant = max(acc_all, key=lambda k: acc_all[k])
+    acc = acc_all
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("batch") == B and dominant in tj.get("bytes_per_launch", {}):
+                traffic = tj["bytes_per_launch"][dominant]
+        except Exception:
+            traffic = None
     fb_ms = acc["fast"] + acc["orient_desc"]
     fast_brief_gbs = 2 * P * B / (fb_ms * 1e-3) / 1e9
     pairs = float((counts.astype(np.float64) * np.roll(counts, -1)).sum())
@@ -219,13 +236,15 @@ def main():
         "stages_ms": {k: round(v, 4) for k, v in acc.items()},
         "match_ms": round(match_ms, 4),
         "match_gpairs_per_s": round(pairs / (match_ms * 1e-3) / 1e9, 2) if match_ms > 0 else None,
+        "match_frac_of_valu_popcount_peak": round((pairs * 16 / 64) / (match_ms * 1e-3) / (VALU_PEAK_GWINST * 1e9), 3)
+        if match_ms > 0 else None,
         "stage_algorithmic_GBps": {k: (round(v, 1) if v else None) for k, v in stage_gbs.items()},
         "roofline": {
             "kernel": dominant, "bound": "hbm",
             "achieved": round(stage_gbs[dominant], 1) if stage_gbs[dominant] else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(stage_gbs[dominant] / HBM_PEAK_GBS, 4) if stage_gbs[dominant] else None,
-            "traffic": None,
+            "traffic": traffic,
             "algorithmic_bytes_per_launch": alg[dominant] * B,
             "launch_ms": round(acc[dominant], 4),
         },

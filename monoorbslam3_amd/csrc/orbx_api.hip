@@ -59,6 +59,11 @@ struct orbx_ctx {
     size_t sort_lds_bytes;
     // last call (for the taps)
     const uint8_t *last_l0; size_t last_l0_fs; int last_l0_pitch; int last_frames;
+    // sub-batch streams: independent frame ranges run on their own streams so that latency-bound kernels of one
+    // range overlap the issue-bound kernels of another
+    int n_sub;
+    hipStream_t sub[8];
+    hipEvent_t ev_fork, ev_join[8];
     // stage timing
     int timing;
     hipEvent_t ev[ORBX_N_STAGES + 1];
@@ -350,6 +355,16 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
         return cleanup(fail(ORBX_E_NO_DEVICE, "hipStreamCreate failed"));
     for (int i = 0; i <= ORBX_N_STAGES; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return cleanup(fail(ORBX_E_NO_DEVICE, "hipEventCreate failed"));
+    for (int i = 0; i < 8; ++i)
+        if (hipStreamCreateWithFlags(&c->sub[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
+            return cleanup(fail(ORBX_E_NO_DEVICE, "sub-stream creation failed"));
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess)
+        return cleanup(fail(ORBX_E_NO_DEVICE, "hipEventCreate failed"));
+    {
+        const char *e = getenv("ORBX_STREAMS");
+        c->n_sub = e ? std::min(std::max(atoi(e), 1), 8) : 4;
+    }
     if (hipMalloc((void **)&c->d_levels, sizeof(OrbxLevels)) != hipSuccess ||
         hipMalloc((void **)&c->d_umax, sizeof(int) * 16) != hipSuccess ||
         hipMalloc((void **)&c->d_taps, sizeof(int) * 8) != hipSuccess)
@@ -391,6 +406,11 @@ extern "C" void orbx_destroy(orbx_t *c)
         if (c->d_ytap[l]) (void)hipFree(c->d_ytap[l]);
     }
     for (int i = 0; i <= ORBX_N_STAGES; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 8; ++i) {
+        if (c->sub[i]) { (void)hipStreamSynchronize(c->sub[i]); (void)hipStreamDestroy(c->sub[i]); }
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -430,13 +450,29 @@ extern "C" int orbx_max_keypoints(const orbx_t *c, int w0, int h0)
 // ------------------------------------------------------------------------------------------------
 // the pipeline
 // ------------------------------------------------------------------------------------------------
-static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs, int l0_pitch, int n_frames,
-                   orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n)
+// the same arenas, seen from frame f0 on
+static OrbxBuffers offset_buffers(const OrbxBuffers &a, int f0, int kcap_total)
+{
+    OrbxBuffers b = a;
+    const size_t f = (size_t)f0;
+    b.img_arena += f * a.img_frame_stride;
+    b.cand += f * a.cand_frame_stride; b.pnode += f * a.cand_frame_stride; b.pcode += f * a.cand_frame_stride;
+    b.cand_count += f * ORBX_MAX_LEVELS; b.sel_count += f * ORBX_MAX_LEVELS;
+    const size_t n = f * a.node_frame_stride;
+    b.bnd0 += n; b.bnd1 += n; b.cnt0 += n; b.cnt1 += n; b.rank += n; b.node_of_rank += n; b.newpos += n; b.best += n;
+    b.childcnt += 4 * n; b.childpos += 4 * n;
+    b.sel += f * kcap_total; b.kp_ang += f * kcap_total;
+    return b;
+}
+
+static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs, int l0_pitch, int f0, int n_frames,
+                   orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n, bool t)
 {
     const OrbxLevels &LV = c->levels;
     const int L = LV.n_levels;
-    OrbxBuffers &b = c->buf;
-    const bool t = c->timing != 0;
+    const OrbxBuffers b = offset_buffers(c->buf, f0, LV.kcap_total);
+    d_l0 += (size_t)f0 * l0_fs;
+    d_kp += (size_t)f0 * cap; d_desc += (size_t)f0 * cap * 32; d_n += f0;
     if (t) HIP_TRY(hipEventRecord(c->ev[0], s));
     HIP_TRY(hipMemsetAsync(b.cand_count, 0, sizeof(int) * ORBX_MAX_LEVELS * n_frames, s));
     auto raw = [&](int l, const uint8_t **p, size_t *fs, int *pitch) {
@@ -461,7 +497,26 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames);
     if (t) { HIP_TRY(hipEventRecord(c->ev[5], s)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+
+// whole batch on one stream, or split into frame ranges on the handle's sub-streams (forked from and joined
+// back into `s` with events, so the caller still sees one in-order stream)
+static int enqueue_batch(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs, int l0_pitch, int n_frames,
+                         orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n)
+{
     c->last_l0 = d_l0; c->last_l0_fs = l0_fs; c->last_l0_pitch = l0_pitch; c->last_frames = n_frames;
+    const int ns = c->timing ? 1 : std::min(c->n_sub, n_frames / 8);
+    if (ns <= 1) return enqueue(c, s, d_l0, l0_fs, l0_pitch, 0, n_frames, d_kp, d_desc, cap, d_n, c->timing != 0);
+    HIP_TRY(hipEventRecord(c->ev_fork, s));
+    for (int i = 0; i < ns; ++i) {
+        const int f0 = (int)((long long)n_frames * i / ns), f1 = (int)((long long)n_frames * (i + 1) / ns);
+        HIP_TRY(hipStreamWaitEvent(c->sub[i], c->ev_fork, 0));
+        int rc = enqueue(c, c->sub[i], d_l0, l0_fs, l0_pitch, f0, f1 - f0, d_kp, d_desc, cap, d_n, false);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(c->ev_join[i], c->sub[i]));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_join[i], 0));
+    }
     return ORBX_OK;
 }
 
@@ -473,8 +528,8 @@ extern "C" int orbx_extract_batch_device(orbx_t *c, const uint8_t *d_imgs, int n
     if (n_frames < 1 || width < 1 || height < 1 || stride < width || cap < 1) return fail(ORBX_E_ARG, "bad size");
     int rc = ensure_geometry(c, width, height, n_frames, 0);
     if (rc) return rc;
-    return enqueue(c, stream ? (hipStream_t)stream : c->stream, d_imgs, frame_stride, stride, n_frames, d_kp, d_desc,
-                   cap, d_n);
+    return enqueue_batch(c, stream ? (hipStream_t)stream : c->stream, d_imgs, frame_stride, stride, n_frames, d_kp,
+                         d_desc, cap, d_n);
 }
 
 extern "C" int orbx_synchronize(orbx_t *c)
@@ -503,8 +558,8 @@ extern "C" int orbx_extract_batch(orbx_t *c, const uint8_t *imgs, int n_frames, 
     for (int f = 0; f < n_frames; ++f)
         HIP_TRY(hipMemcpy2DAsync(c->d_l0_stage + (size_t)f * c->l0_stage_fs, c->l0_stage_pitch,
                                  imgs + (size_t)f * frame_stride, stride, width, height, hipMemcpyHostToDevice, s));
-    rc = enqueue(c, s, c->d_l0_stage, c->l0_stage_fs, (int)c->l0_stage_pitch, n_frames, c->d_out_kp, c->d_out_desc,
-                 scap, c->d_out_n);
+    rc = enqueue_batch(c, s, c->d_l0_stage, c->l0_stage_fs, (int)c->l0_stage_pitch, n_frames, c->d_out_kp,
+                       c->d_out_desc, scap, c->d_out_n);
     if (rc) return rc;
     std::vector<int32_t> counts(n_frames);
     HIP_TRY(hipMemcpyAsync(counts.data(), c->d_out_n, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, s));

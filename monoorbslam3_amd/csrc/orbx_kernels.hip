@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
             const u16x2 cv = __builtin_bit_cast(u16x2, cc[i]);
             const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w0h, w0l, sel[i])), cv, 0u, false);
             const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1h, w1l, sel[i])), cv, 0u, false);
-            const int v = (((b0[r] * (r0 >> 4)) >> 16) + ((b1[r] * (r1 >> 4)) >> 16) + 2) >> 2;
+            const int v = (((int)__umul24((uint32_t)b0[r], (uint32_t)(r0 >> 4)) >> 16) +
+                           ((int)__umul24((uint32_t)b1[r], (uint32_t)(r1 >> 4)) >> 16) + 2) >> 2;
             packed |= (uint32_t)(v & 255) << (8 * i);
         }
         // rows of the arena are 64-byte aligned and padded, so the dword store is always in bounds
@@ -640,7 +641,72 @@ __device__ __forceinline__ void blur_hrow(uint32_t d0, uint32_t d1, uint32_t d2,
 // 7x7 Gaussian as a register sliding window: a thread owns 4 adjacent columns and walks down 32 output
 // rows.  Per input row it loads 12 bytes, forms the four horizontal sums with v_alignbyte + v_dot4_u32_u8
 // and keeps the last seven rows of sums in registers (ring unrolled by 7, so slots are compile-time);
-// every row after the sixth emits one output dword = sat8((sum k_j * H_j + 2^15) >> 16).  No LDS, no barrier.
+// every row after the sixth emits one output dword = sat8((sum k_j * H_j + 2^15) >> 16) with 24-bit
+// multiply-adds (H < 2^16).  No LDS, no barrier.  BORDER = false is the straight-line interior path; waves
+// that touch the left/right image edge take the BORDER = true instantiation (wave-uniform choice).
+// one v_mad_u32_u24 (the compiler otherwise splits the 7-tap sum into 24-bit multiplies plus an add tree)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+template <bool BORDER>
+__device__ __forceinline__ void blur_strip(const uint8_t *__restrict__ S, int pitch, int w, int h, uint8_t *__restrict__ D,
+                                           int dpitch, int x, int ys, int ye, const uint32_t k[7], uint32_t K0,
+                                           uint32_t K1, bool clamp16)
+{
+    uint32_t hq[7][4];
+    auto load_row = [&](int rr, uint32_t o[4]) {
+        const uint8_t *row = S + (size_t)reflect101(rr, h) * pitch;
+        uint32_t d0, d1, d2;
+        if (!BORDER) {
+            d0 = reinterpret_cast<const UnalignedU32 *>(row + x - 4)->v;
+            d1 = reinterpret_cast<const UnalignedU32 *>(row + x)->v;
+            d2 = reinterpret_cast<const UnalignedU32 *>(row + x + 4)->v;
+        } else { // BORDER_REFLECT_101 on the columns
+            d0 = d1 = d2 = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                d0 |= (uint32_t)row[reflect101(x - 4 + b, w)] << (8 * b);
+                d1 |= (uint32_t)row[reflect101(x + b, w)] << (8 * b);
+                d2 |= (uint32_t)row[reflect101(x + 4 + b, w)] << (8 * b);
+            }
+        }
+        blur_hrow(d0, d1, d2, K0, K1, o);
+        if (clamp16) { // only the sum-257 tap set can exceed 16 bits
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = min(o[i], 65535u);
+        }
+    };
+    // input row n (level row ys-3+n) goes to slot n%7; from n = 6 on, output row ys+n-6 is complete:
+    // its rows y-3 .. y+3 sit in slots (n+1)%7 .. (n+7)%7.  One unrolled-by-7 loop, no separate priming code.
+    const int n_rows = ye - ys + 6;
+    for (int n0 = 0; n0 < n_rows; n0 += 7) {
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            const int n = n0 + s;
+            if (n < n_rows) {
+                load_row(ys - 3 + n, hq[s]);
+                if (n >= 6) {
+                    const int y = ys + n - 6;
+                    uint32_t r[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint32_t acc = 32768u;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) acc = mad_u24(k[j], hq[(s + 1 + j) % 7][i], acc);
+                        r[i] = min(acc >> 16, 255u);
+                    }
+                    // rows of the arena are padded to a multiple of 64 bytes: the dword store stays inside the row
+                    *reinterpret_cast<uint32_t *>(D + (size_t)y * dpitch + x) = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_blur_cols(FastSrc src, const OrbxLevels *__restrict__ levels,
                                                    const BlurTile *__restrict__ tiles, uint8_t *__restrict__ arena,
                                                    size_t arena_fs, const int *__restrict__ taps)
@@ -656,54 +722,42 @@ __global__ __launch_bounds__(256) void k_blur_cols(FastSrc src, const OrbxLevels
     const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level];
     uint8_t *D = arena + (size_t)frame * arena_fs + lv.blur_off;
     uint32_t k[7];
+    uint32_t ksum = 0;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) k[i] = (uint32_t)taps[i];
+    for (int i = 0; i < 7; ++i) { k[i] = (uint32_t)taps[i]; ksum += k[i]; }
     const uint32_t K0 = k[0] | (k[1] << 8) | (k[2] << 16) | (k[3] << 24), K1 = k[4] | (k[5] << 8) | (k[6] << 16);
-    const bool interior = x >= 4 && x + 8 <= w; // all 12 bytes inside the row
-    uint32_t hq[7][4];
+    // column groups that touch the left / right image edge are produced by k_blur_edges (reflected columns)
+    if (!(x >= 4 && x + 8 <= w)) return;
+    blur_strip<false>(S, pitch, w, h, D, lv.pitch, x, ys, ye, k, K0, K1, ksum > 256);
+}
 
-    auto load_row = [&](int rr, uint32_t o[4]) {
-        const uint8_t *row = S + (size_t)reflect101(rr, h) * pitch;
-        uint32_t d0, d1, d2;
-        if (interior) {
-            d0 = reinterpret_cast<const UnalignedU32 *>(row + x - 4)->v;
-            d1 = reinterpret_cast<const UnalignedU32 *>(row + x)->v;
-            d2 = reinterpret_cast<const UnalignedU32 *>(row + x + 4)->v;
-        } else { // BORDER_REFLECT_101 on the columns
-            d0 = d1 = d2 = 0;
+// The (at most three) 4-column groups per row that need BORDER_REFLECT_101 on the columns: x = 0 and the
+// groups with x + 8 > w.  One lane = one group x 8 output rows; a few thousand lanes per batch.
+#define BE_ROWS 8
+__global__ __launch_bounds__(64) void k_blur_edges(FastSrc src, const OrbxLevels *__restrict__ levels,
+                                                   uint8_t *__restrict__ arena, size_t arena_fs,
+                                                   const int *__restrict__ taps)
+{
+    const int frame = blockIdx.y, level = blockIdx.z;
+    const OrbxLevel &lv = levels->lv[level];
+    const int w = lv.w, h = lv.h, pitch = src.pitch[level];
+    const int task = blockIdx.x * 64 + threadIdx.x;
+    const int strip = task / 3, which = task - 3 * strip;
+    const int ys = strip * BE_ROWS;
+    if (ys >= h) return;
+    const int last = ((w - 1) >> 2) << 2; // x of the last group
+    const int x = which == 0 ? 0 : which == 1 ? last : last - 4;
+    if (x < 0 || (x >= 4 && x + 8 <= w)) return;  // interior after all (or no such group)
+    if (which != 0 && x == 0) return;            // already covered by which == 0
+    if (which == 2 && last - 4 == 0) return;
+    const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level];
+    uint8_t *D = arena + (size_t)frame * arena_fs + lv.blur_off;
+    uint32_t k[7];
+    uint32_t ksum = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                d0 |= (uint32_t)row[reflect101(x - 4 + b, w)] << (8 * b);
-                d1 |= (uint32_t)row[reflect101(x + b, w)] << (8 * b);
-                d2 |= (uint32_t)row[reflect101(x + 4 + b, w)] << (8 * b);
-            }
-        }
-        blur_hrow(d0, d1, d2, K0, K1, o);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = min(o[i], 65535u);
-    };
-    // prime the ring with input rows ys-3 .. ys+2 in slots 0..5
-#pragma unroll
-    for (int s = 0; s < 6; ++s) load_row(ys - 3 + s, hq[s]);
-    for (int y0 = ys; y0 < ye; y0 += 7) {
-#pragma unroll
-        for (int s = 0; s < 7; ++s) {
-            const int y = y0 + s; // output row; its newest input row y+3 goes to slot (6+s)%7
-            if (y < ye) {
-                load_row(y + 3, hq[(6 + s) % 7]);
-                uint32_t r[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint32_t acc = 32768u;
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) acc += k[j] * hq[(s + j) % 7][i]; // oldest row y-3 sits in slot s%7
-                    r[i] = min(acc >> 16, 255u);
-                }
-                // rows of the arena are padded to a multiple of 64 bytes: the dword store stays inside the row
-                *reinterpret_cast<uint32_t *>(D + (size_t)y * lv.pitch + x) = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
-            }
-        }
-    }
+    for (int i = 0; i < 7; ++i) { k[i] = (uint32_t)taps[i]; ksum += k[i]; }
+    const uint32_t K0 = k[0] | (k[1] << 8) | (k[2] << 16) | (k[3] << 24), K1 = k[4] | (k[5] << 8) | (k[6] << 16);
+    blur_strip<true>(S, pitch, w, h, D, lv.pitch, x, ys, min(ys + BE_ROWS, h), k, K0, K1, ksum > 256);
 }
 
 void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
@@ -719,6 +773,11 @@ void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pit
     }
     hipLaunchKernelGGL(k_blur_cols, dim3(n_tiles, n_frames), dim3(256), 0, s, src, d_levels,
                        reinterpret_cast<const BlurTile *>(d_tiles), b.img_arena, b.img_frame_stride, taps7);
+    int max_h = 1;
+    for (int l = 0; l < levels.n_levels; ++l) max_h = levels.lv[l].h > max_h ? levels.lv[l].h : max_h;
+    const int tasks = 3 * ((max_h + BE_ROWS - 1) / BE_ROWS);
+    hipLaunchKernelGGL(k_blur_edges, dim3((tasks + 63) / 64, n_frames, levels.n_levels), dim3(64), 0, s, src, d_levels,
+                       b.img_arena, b.img_frame_stride, taps7);
 }
 
 int orbx_build_blur_tiles(const OrbxLevels &levels, uint16_t *out /* 4 per tile, or NULL to count */)
