@@ -87,6 +87,26 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t *__restric
 // v_bcnt_u32_b32 (accumulating) + a branch-free (best, second) update.  Partial results merge
 // exactly like the sequential strict-'<' scan of ORBMatcher.cpp:155-161: best = smallest
 // (distance, index) key, second = 2nd smallest distance.
+// D = popcount(x) + acc in one instruction
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ uint32_t bcnt0(uint32_t x)
+{
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(x));
+    return d;
+}
+// median of three = the second smallest
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 #define B2_ROWS 8
 #define B2_CHUNK 128
 __global__ __launch_bounds__(256) void k_best2(const uint8_t *__restrict__ a, size_t a_stride,
@@ -116,9 +136,10 @@ __global__ __launch_bounds__(256) void k_best2(const uint8_t *__restrict__ a, si
         for (int w = 0; w < 8; ++w) ar[r][w] = __builtin_amdgcn_readfirstlane(pa[w]);
     }
     const uint32_t SENT = (256u << 23) | 0x7FFFFFu;
-    uint32_t k1[B2_ROWS], s2[B2_ROWS];
+    // the two smallest (distance << 23 | index) keys seen so far: k1 <= k2
+    uint32_t k1[B2_ROWS], k2[B2_ROWS];
 #pragma unroll
-    for (int r = 0; r < B2_ROWS; ++r) { k1[r] = SENT; s2[r] = 256; }
+    for (int r = 0; r < B2_ROWS; ++r) { k1[r] = SENT; k2[r] = SENT; }
 
     const int n_chunks = (nb + B2_CHUNK - 1) / B2_CHUNK;
     auto stage = [&](int chunk, int buf) {
@@ -132,35 +153,39 @@ __global__ __launch_bounds__(256) void k_best2(const uint8_t *__restrict__ a, si
     for (int c = 0; c < n_chunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < n_chunks) stage(c + 1, buf ^ 1);
+        // full chunks without a candidate mask skip the per-pair validity select (wave-uniform choice)
+        const bool all_valid = !ok && (c + 1) * B2_CHUNK <= nb;
 #pragma unroll
         for (int h = 0; h < B2_CHUNK / 64; ++h) {
             const int jl = h * 64 + lane, j = c * B2_CHUNK + jl;
             const uint4 lo = sb[buf][0][jl], hi = sb[buf][1][jl];
-            const bool valid = j < nb && (!ok || ok[j]);
+            const bool valid = all_valid || (j < nb && (!ok || ok[j]));
 #pragma unroll
             for (int r = 0; r < B2_ROWS; ++r) {
-                uint32_t d = __popc(lo.x ^ ar[r][0]);
-                d += __popc(lo.y ^ ar[r][1]); d += __popc(lo.z ^ ar[r][2]); d += __popc(lo.w ^ ar[r][3]);
-                d += __popc(hi.x ^ ar[r][4]); d += __popc(hi.y ^ ar[r][5]); d += __popc(hi.z ^ ar[r][6]);
-                d += __popc(hi.w ^ ar[r][7]);
-                const uint32_t k = valid ? ((d << 23) | (uint32_t)j) : SENT;
-                const uint32_t mn = min(k, k1[r]), mx = max(k, k1[r]);
-                k1[r] = mn;
-                s2[r] = min(s2[r], mx >> 23);
+                // 8 x (xor, accumulate-popcount): one dependent v_bcnt chain per pair, no add tree
+                uint32_t d = bcnt0(lo.x ^ ar[r][0]);
+                d = bcnt_acc(lo.y ^ ar[r][1], d); d = bcnt_acc(lo.z ^ ar[r][2], d); d = bcnt_acc(lo.w ^ ar[r][3], d);
+                d = bcnt_acc(hi.x ^ ar[r][4], d); d = bcnt_acc(hi.y ^ ar[r][5], d); d = bcnt_acc(hi.z ^ ar[r][6], d);
+                d = bcnt_acc(hi.w ^ ar[r][7], d);
+                uint32_t k = (d << 23) | (uint32_t)j;
+                if (!all_valid) k = valid ? k : SENT;
+                k2[r] = med3_u32(k, k1[r], k2[r]); // two smallest of {k, k1, k2}
+                k1[r] = min(k, k1[r]);
             }
         }
         __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < B2_ROWS; ++r) {
-        uint32_t kk = k1[r], ss = s2[r];
+        uint32_t kk = k1[r], k2r = k2[r];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t ok1 = __shfl_xor(kk, o), os2 = __shfl_xor(ss, o);
-            const uint32_t mn = min(kk, ok1), mx = max(kk, ok1);
-            ss = min(min(ss, os2), mx >> 23);
-            kk = mn;
+            const uint32_t ok1 = __shfl_xor(kk, o), ok2 = __shfl_xor(k2r, o);
+            // two smallest of {kk, k2r, ok1, ok2} with kk <= k2r and ok1 <= ok2
+            k2r = min(min(k2r, ok2), max(kk, ok1));
+            kk = min(kk, ok1);
         }
+        const uint32_t ss = k2r >> 23;
         const int row = row0 + r;
         if (lane == 0 && row < na_max) {
             const size_t orow = (size_t)p * a_stride + row;
