@@ -98,6 +98,30 @@ int orbm_search_for_initialization(orbm_t *h, float nn_ratio, int check_orientat
                                    int img_w, int img_h, float *prematched_xy, int32_t *matches12,
                                    int window_size, int *n_matches);
 
+/* ORBMatcher::SearchByProjection(lastFrame, curFrame, th) and (lastKF, curFrame, th)
+ * (modules/ORB/ORBMatcher.cpp:203-274 and :276-348 -- the two bodies are the same loop).  The caller (shim)
+ * keeps the camera / pose maths: for every feature i of the last frame it passes q_ok[i] = 1 iff the feature has
+ * a live MapPoint whose projection is in front of the camera and inside the image (:213-224), the projection
+ * q_xy, the radius th * key_points[i].size, the octave (window levels octave-1 .. octave+1, :226-229), the
+ * MapPoint descriptor and the key-point angle.  frame_mp (in/out): -1 where curFrame->map_points[j] is null,
+ * any other value = occupied; matched entries are set to the query index i (:245).  kps2 = orbx_kp records. */
+int orbm_search_by_projection_frame(orbm_t *h, int check_orientation,
+                                    const uint8_t *q_desc, const float *q_xy, const float *q_radius,
+                                    const int32_t *q_octave, const float *q_angle, const uint8_t *q_ok, int nq,
+                                    const void *kps2, const uint8_t *desc2, int n2, int img_w, int img_h,
+                                    int32_t *frame_mp, int *n_matches);
+
+/* ORBMatcher::SearchByProjection(frame, mapPoints, th) (modules/ORB/ORBMatcher.cpp:350-415).  q_ok[i] = 1 iff
+ * mp->track_in_view && !mp->isBad() (:355); q_xy = (track_proj_x, track_proj_y); q_radius = the radius computed at
+ * :362-365; q_level = track_scale_level (window levels level-1 .. level, :367-369).  frame_mp (in/out): -1 where
+ * frame->map_points[j] is null OR bad (such slots may be taken, :383), anything else = occupied by a good point;
+ * matched entries are set to the query index.  counters[3] = {numOutViewAndBad, fail1, fail2} (:353, :403, :408). */
+int orbm_search_by_projection_points(orbm_t *h, float nn_ratio,
+                                     const uint8_t *q_desc, const float *q_xy, const float *q_radius,
+                                     const int32_t *q_level, const uint8_t *q_ok, int nq,
+                                     const void *kps2, const uint8_t *desc2, int n2, int img_w, int img_h,
+                                     int32_t *frame_mp, int *n_matches, int32_t *counters);
+
 /* ORBMatcher::ComputeThreeMaxima (modules/ORB/ORBMatcher.cpp:594-622) on bin sizes */
 void orbm_three_maxima(const int32_t *hist_sizes, int n_bins, int *ind1, int *ind2, int *ind3);
 

@@ -2,10 +2,11 @@
 //
 // Same class, constructor and method signatures as the reference (modules/ORB/ORBMatcher.h:12-52) for the
 // routines on the north-star path: DescriptorDistance, SearchForInitialization, SearchByBow and
-// SearchForTriangulation.  The Hamming brute force runs in HIP (include/orbm.h); the side effects on
+// SearchForTriangulation, and (inside the reference tree, where Camera / Pose exist) the three const
+// SearchByProjection overloads.  The Hamming brute force runs in HIP (include/orbm.h); the side effects on
 // Frame::map_points / matches12 are applied here so that the reference's objects stay the owners.
-// The three SearchByProjection overloads and the static fuse variant are "next" rows: they
-// keep the reference's own implementation until their wrappers land.
+// The static fuse SearchByProjection(keyFrame, mapPoints, Map*, th) (ORBMatcher.cpp:524-592) rewires
+// observations and replaces MapPoints per match; it keeps the reference's own implementation.
 //
 // Build: in a real integration include the reference's BasicObject headers before this one.  For this
 // repo's checks define ORBX_SHIM_USE_REF_MIRROR to get minimal mirror types (ref_mirror.h).
@@ -104,7 +105,98 @@ namespace mono_orb_slam3 {
             return n;
         }
 
+#ifndef ORBX_SHIM_USE_REF_MIRROR
+        // The window searches need the reference's Camera / Pose / MapPoint classes, so they are only compiled inside
+        // the reference tree (not in this repo's mirror-type checks).  The projection maths is copied call for call
+        // from the reference; candidate gathering, Hamming distances and the greedy pass run behind the C ABI.
+
+        // reference ORBMatcher.h:28-30 / ORBMatcher.cpp:203-274
+        [[nodiscard]] int SearchByProjection(const std::shared_ptr<Frame> &lastFrame, const std::shared_ptr<Frame> &curFrame,
+                                             float th = 5) const {
+            return projectionFromFrame(lastFrame->num_kps, lastFrame->map_points, lastFrame->key_points, curFrame, th);
+        }
+
+        // reference ORBMatcher.h:32-33 / ORBMatcher.cpp:276-348
+        [[nodiscard]] int SearchByProjection(const std::shared_ptr<KeyFrame> &lastKF, const std::shared_ptr<Frame> &curFrame,
+                                             float th = 5) const {
+            return projectionFromFrame(lastKF->num_kps, lastKF->getMapPoints(), lastKF->key_points, curFrame, th);
+        }
+
+        // reference ORBMatcher.h:35-37 / ORBMatcher.cpp:350-415
+        [[nodiscard]] int SearchByProjection(const std::shared_ptr<Frame> &frame,
+                                             const std::vector<std::shared_ptr<MapPoint>> &mapPoints, float th = 3) const {
+            const int nq = (int) mapPoints.size(), n2 = frame->num_kps;
+            std::vector<unsigned char> desc((size_t) nq * 32, 0), ok((size_t) nq, 0);
+            std::vector<float> xy((size_t) nq * 2, 0.f), radius((size_t) nq, 0.f);
+            std::vector<int32_t> level((size_t) nq, 0);
+            for (int i = 0; i < nq; ++i) {
+                const auto &mp = mapPoints[i];
+                if (!mp->track_in_view || mp->isBad()) continue;                    // :355
+                ok[i] = 1;
+                level[i] = mp->track_scale_level;
+                float r = th;
+                if (mp->track_view_cos > 0.998) r *= 2.5f; else r *= 4.f;          // :362-364
+                radius[i] = r * ORBExtractor::getScaleFactor(level[i]);            // :365
+                xy[2 * i] = mp->track_proj_x, xy[2 * i + 1] = mp->track_proj_y;
+                const cv::Mat d = mp->getDescriptor();
+                std::memcpy(&desc[(size_t) i * 32], d.ptr(), 32);
+            }
+            const int32_t OCCUPIED = INT32_MAX;
+            std::vector<int32_t> fmp((size_t) n2);
+            for (int j = 0; j < n2; ++j)
+                fmp[j] = (frame->map_points[j] && !frame->map_points[j]->isBad()) ? OCCUPIED : -1; // :383
+            int n = 0;
+            int32_t counters[3];
+            check(orbm_search_by_projection_points(handle(), nn_ratio, desc.data(), xy.data(), radius.data(), level.data(),
+                                                   ok.data(), nq, frame->key_points.data(), rows(frame->descriptors), n2,
+                                                   imageCols(*frame), imageRows(*frame), fmp.data(), &n, counters));
+            for (int j = 0; j < n2; ++j)
+                if (fmp[j] >= 0 && fmp[j] != OCCUPIED) frame->map_points[j] = mapPoints[fmp[j]]; // :406
+            tracker_logger << titles[0] << "out view and bad " << counters[0] << ", fail1 " << counters[1] << ", fail2 "
+                           << counters[2] << "\n";                                                // :411-412
+            return n;
+        }
+#endif
+
     protected:
+#ifndef ORBX_SHIM_USE_REF_MIRROR
+        int projectionFromFrame(int nq, const std::vector<std::shared_ptr<MapPoint>> &mapPoints,
+                                const std::vector<cv::KeyPoint> &keyPoints, const std::shared_ptr<Frame> &curFrame,
+                                float th) const {
+            const Camera *camera = Camera::getCamera();
+            const Pose &Tcw = curFrame->T_cw;
+            const int n2 = curFrame->num_kps;
+            std::vector<unsigned char> desc((size_t) nq * 32, 0), ok((size_t) nq, 0);
+            std::vector<float> xy((size_t) nq * 2, 0.f), radius((size_t) nq, 0.f), angle((size_t) nq, 0.f);
+            std::vector<int32_t> octave((size_t) nq, 0);
+            for (int i = 0; i < nq; ++i) {
+                const std::shared_ptr<MapPoint> &mp = mapPoints[i];
+                if (mp == nullptr || mp->isBad()) continue;                         // :213-217
+                const Eigen::Vector3f Pc = Tcw.map(mp->getPos());                   // :219-220
+                if (Pc[2] < 0) continue;
+                const cv::Point2f p = camera->project(Pc);
+                if (!camera->isInImage(p)) continue;                                // :223-224
+                ok[i] = 1;
+                xy[2 * i] = p.x, xy[2 * i + 1] = p.y;
+                octave[i] = keyPoints[i].octave;
+                radius[i] = th * keyPoints[i].size;                                 // :228
+                angle[i] = keyPoints[i].angle;
+                const cv::Mat d = mp->getDescriptor();
+                std::memcpy(&desc[(size_t) i * 32], d.ptr(), 32);
+            }
+            const int32_t OCCUPIED = INT32_MAX;
+            std::vector<int32_t> fmp((size_t) n2);
+            for (int j = 0; j < n2; ++j) fmp[j] = curFrame->map_points[j] ? OCCUPIED : -1; // :235
+            int n = 0;
+            check(orbm_search_by_projection_frame(handle(), be_check_orientation, desc.data(), xy.data(), radius.data(),
+                                                  octave.data(), angle.data(), ok.data(), nq, curFrame->key_points.data(),
+                                                  rows(curFrame->descriptors), n2, imageCols(*curFrame), imageRows(*curFrame),
+                                                  fmp.data(), &n));
+            for (int j = 0; j < n2; ++j)
+                if (fmp[j] >= 0 && fmp[j] != OCCUPIED) curFrame->map_points[j] = mapPoints[fmp[j]]; // :245
+            return n;
+        }
+#endif
         // DBoW2::FeatureVector (an ordered map node -> feature indices) flattened for the C ABI
         struct Csr {
             std::vector<uint32_t> ids, idx;

@@ -660,3 +660,148 @@ extern "C" int orbm_search_for_initialization(orbm_t *c, float nn_ratio, int che
     *n_matches = num;
     return ORBX_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// window searches: Frame grid + getFeaturesInArea on the host, distances on the device, greedy pass on the host
+// ---------------------------------------------------------------------------------------------
+namespace {
+// Frame::grid (Frame.cpp:33-51): 40-px cells, grid[x][y] vectors filled in key-point order
+struct FrameGrid {
+    static const int G = 40;
+    int cols, rows;
+    std::vector<std::vector<int>> cell;
+    FrameGrid(const orbx_kp *kps, int n, int img_w, int img_h)
+    {
+        cols = img_w % G == 0 ? img_w / G : img_w / G + 1;
+        rows = img_h % G == 0 ? img_h / G : img_h / G + 1;
+        cell.resize((size_t)cols * rows);
+        for (int i = 0; i < n; ++i) {
+            const int x = orb_floor_f(kps[i].x), y = orb_floor_f(kps[i].y); // Frame::PosInGrid (:90-95)
+            if (x < 0 || x >= img_w || y < 0 || y >= img_h) continue;
+            cell[(size_t)(x / G) * rows + y / G].push_back(i);
+        }
+    }
+    // Frame::getFeaturesInArea (Frame.cpp:97-127), appended to `out`
+    void area(const orbx_kp *kps, float x, float y, float r, int minLevel, int maxLevel, std::vector<int32_t> &out) const
+    {
+        const int minCX = std::max(0, orb_floor_f(x - r) / G), maxCX = std::min(cols - 1, orb_floor_f(x + r) / G);
+        if (minCX > maxCX) return;
+        const int minCY = std::max(0, orb_floor_f(y - r) / G), maxCY = std::min(rows - 1, orb_floor_f(y + r) / G);
+        if (minCY > maxCY) return;
+        const bool check = minLevel > 0 || maxLevel >= 0;
+        for (int cx = minCX; cx <= maxCX; ++cx)
+            for (int cy = minCY; cy <= maxCY; ++cy)
+                for (int j : cell[(size_t)cx * rows + cy]) {
+                    if (check) {
+                        if (kps[j].octave < minLevel) continue;
+                        if (maxLevel >= 0 && kps[j].octave > maxLevel) continue;
+                    }
+                    if (fabsf(kps[j].x - x) <= r && fabsf(kps[j].y - y) <= r) out.push_back(j);
+                }
+    }
+};
+struct WindowQueries {
+    std::vector<int32_t> q_idx, c_begin, c_len, c_idx;
+};
+} // namespace
+
+extern "C" int orbm_search_by_projection_frame(orbm_t *c, int check_orientation, const uint8_t *q_desc,
+                                               const float *q_xy, const float *q_radius, const int32_t *q_octave,
+                                               const float *q_angle, const uint8_t *q_ok, int nq, const void *kps2v,
+                                               const uint8_t *desc2, int n2, int img_w, int img_h, int32_t *frame_mp,
+                                               int *n_matches)
+{
+    if (!c || !q_desc || !q_xy || !q_radius || !q_octave || !q_angle || !q_ok || !kps2v || !desc2 || !frame_mp || !n_matches)
+        return orbx_set_error(ORBX_E_ARG, "null argument");
+    *n_matches = 0;
+    if (nq <= 0 || n2 <= 0) return ORBX_OK;
+    const orbx_kp *kps2 = (const orbx_kp *)kps2v;
+    FrameGrid grid(kps2, n2, img_w, img_h);
+    WindowQueries q;
+    for (int i = 0; i < nq; ++i) {
+        if (!q_ok[i]) continue;
+        const size_t begin = q.c_idx.size();
+        grid.area(kps2, q_xy[2 * i], q_xy[2 * i + 1], q_radius[i], q_octave[i] - 1, q_octave[i] + 1, q.c_idx);
+        if (q.c_idx.size() == begin) continue; // :230
+        q.q_idx.push_back(i); q.c_begin.push_back((int32_t)begin); q.c_len.push_back((int32_t)(q.c_idx.size() - begin));
+    }
+    std::vector<uint16_t> dist;
+    int rc = hamming_lists(c, q_desc, nq, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.c_begin, q.c_idx.data(), q.c_idx.size(),
+                           q.c_idx.size(), dist);
+    if (rc) return rc;
+    RotHist rh;
+    int num = 0;
+    for (size_t k = 0; k < q.q_idx.size(); ++k) {
+        const int i = q.q_idx[k];
+        int bestDist = ORBM_TH_HIGH + 1, bestIdx2 = -1;
+        for (int t = 0; t < q.c_len[k]; ++t) {
+            const int idx2 = q.c_idx[q.c_begin[k] + t];
+            if (frame_mp[idx2] != -1) continue; // :235 -- includes points matched earlier in this call
+            const int d = dist[q.c_begin[k] + t];
+            if (d < bestDist) { bestDist = d; bestIdx2 = idx2; }
+        }
+        if (bestDist <= ORBM_TH_HIGH) { // :244
+            frame_mp[bestIdx2] = i;
+            ++num;
+            if (check_orientation) rh.add(q_angle[i], kps2[bestIdx2].angle, bestIdx2);
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        rh.keep3(&i1, &i2, &i3);
+        for (int b = 0; b < ORBM_HISTO_LENGTH; ++b) {
+            if (b == i1 || b == i2 || b == i3) continue;
+            for (int idx2 : rh.bins[b]) { frame_mp[idx2] = -1; --num; }
+        }
+    }
+    *n_matches = num;
+    return ORBX_OK;
+}
+
+extern "C" int orbm_search_by_projection_points(orbm_t *c, float nn_ratio, const uint8_t *q_desc, const float *q_xy,
+                                                const float *q_radius, const int32_t *q_level, const uint8_t *q_ok,
+                                                int nq, const void *kps2v, const uint8_t *desc2, int n2, int img_w,
+                                                int img_h, int32_t *frame_mp, int *n_matches, int32_t *counters)
+{
+    if (!c || !q_desc || !q_xy || !q_radius || !q_level || !q_ok || !kps2v || !desc2 || !frame_mp || !n_matches)
+        return orbx_set_error(ORBX_E_ARG, "null argument");
+    *n_matches = 0;
+    int n_out = 0, fail1 = 0, fail2 = 0;
+    if (counters) counters[0] = counters[1] = counters[2] = 0;
+    if (nq <= 0) return ORBX_OK;
+    const orbx_kp *kps2 = (const orbx_kp *)kps2v;
+    FrameGrid grid(kps2, std::max(n2, 0), img_w, img_h);
+    WindowQueries q;
+    for (int i = 0; i < nq; ++i) {
+        if (!q_ok[i]) { ++n_out; continue; } // :355-358
+        const size_t begin = q.c_idx.size();
+        grid.area(kps2, q_xy[2 * i], q_xy[2 * i + 1], q_radius[i], q_level[i] - 1, q_level[i], q.c_idx);
+        if (q.c_idx.size() == begin) continue; // :371
+        q.q_idx.push_back(i); q.c_begin.push_back((int32_t)begin); q.c_len.push_back((int32_t)(q.c_idx.size() - begin));
+    }
+    std::vector<uint16_t> dist;
+    int rc = hamming_lists(c, q_desc, nq, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.c_begin, q.c_idx.data(), q.c_idx.size(),
+                           q.c_idx.size(), dist);
+    if (rc) return rc;
+    int num = 0;
+    for (size_t k = 0; k < q.q_idx.size(); ++k) {
+        const int i = q.q_idx[k];
+        int bestDist = 256, bestLevel = -1, secondDist = 257, secondLevel = -1, bestIdx = -1;
+        for (int t = 0; t < q.c_len[k]; ++t) {
+            const int idx = q.c_idx[q.c_begin[k] + t];
+            if (frame_mp[idx] != -1) continue; // :383 -- a slot holding a good MapPoint (also one assigned in this call)
+            const int d = dist[q.c_begin[k] + t];
+            if (d < bestDist) { secondDist = bestDist; bestDist = d; secondLevel = bestLevel; bestLevel = kps2[idx].octave; bestIdx = idx; }
+            else if (d < secondDist) { secondDist = d; secondLevel = kps2[idx].octave; }
+        }
+        if (bestDist <= ORBM_TH_HIGH) {
+            if (bestLevel == secondLevel && (float)bestDist > nn_ratio * (float)secondDist) { ++fail1; continue; } // :402
+            frame_mp[bestIdx] = i;
+            ++num;
+        } else ++fail2;
+    }
+    if (counters) { counters[0] = n_out; counters[1] = fail1; counters[2] = fail2; }
+    *n_matches = num;
+    return ORBX_OK;
+}

@@ -46,6 +46,10 @@ def _mlib():
                                                     C.POINTER(_Fv), vp, C.POINTER(i32)]),
             "orbm_search_for_initialization": (i32, [vp, f32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32,
                                                      C.POINTER(i32)]),
+            "orbm_search_by_projection_frame": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp,
+                                                      C.POINTER(i32)]),
+            "orbm_search_by_projection_points": (i32, [vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp,
+                                                       C.POINTER(i32), vp]),
             "orbm_three_maxima": (None, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         }
         for name, (res, args) in sigs.items():
@@ -201,3 +205,41 @@ class ORBMatcher:
                                                           _vp(k1), _vp(d1), len(k1), _vp(k2), _vp(d2), len(k2), img_w,
                                                           img_h, _vp(pre), _vp(m12), windowSize, C.byref(n)))
         return n.value, m12, pre
+
+    # -- SearchByProjection(lastFrame | lastKF, curFrame, th) (ORBMatcher.cpp:203-348) ----------
+    def SearchByProjectionFrame(self, q_desc, q_xy, q_radius, q_octave, q_angle, q_ok, kps2, desc2, img_w, img_h,
+                                frame_mp):
+        """Queries = features of the last frame with their MapPoint descriptor and projected position (the camera
+        maths stays with the caller).  Returns (numMatch, frame_mp')."""
+        qd = np.ascontiguousarray(q_desc, dtype=np.uint8)
+        qx = np.ascontiguousarray(q_xy, dtype=np.float32)
+        qr = np.ascontiguousarray(q_radius, dtype=np.float32)
+        qo = np.ascontiguousarray(q_octave, dtype=np.int32)
+        qa = np.ascontiguousarray(q_angle, dtype=np.float32)
+        qk = np.ascontiguousarray(q_ok, dtype=np.uint8)
+        k2 = np.ascontiguousarray(kps2, dtype=KP_DTYPE)
+        d2 = np.ascontiguousarray(desc2, dtype=np.uint8)
+        mp = np.ascontiguousarray(frame_mp, dtype=np.int32).copy()
+        n = C.c_int()
+        _lib.check(self._L.orbm_search_by_projection_frame(self._hd._h, int(self.be_check_orientation), _vp(qd), _vp(qx),
+                                                           _vp(qr), _vp(qo), _vp(qa), _vp(qk), len(qd), _vp(k2), _vp(d2),
+                                                           len(k2), img_w, img_h, _vp(mp), C.byref(n)))
+        return n.value, mp
+
+    # -- SearchByProjection(frame, mapPoints, th) (ORBMatcher.cpp:350-415) -----------------------
+    def SearchByProjectionPoints(self, q_desc, q_xy, q_radius, q_level, q_ok, kps2, desc2, img_w, img_h, frame_mp):
+        """Returns (numMatch, frame_mp', (numOutViewAndBad, fail1, fail2))."""
+        qd = np.ascontiguousarray(q_desc, dtype=np.uint8)
+        qx = np.ascontiguousarray(q_xy, dtype=np.float32)
+        qr = np.ascontiguousarray(q_radius, dtype=np.float32)
+        ql = np.ascontiguousarray(q_level, dtype=np.int32)
+        qk = np.ascontiguousarray(q_ok, dtype=np.uint8)
+        k2 = np.ascontiguousarray(kps2, dtype=KP_DTYPE)
+        d2 = np.ascontiguousarray(desc2, dtype=np.uint8)
+        mp = np.ascontiguousarray(frame_mp, dtype=np.int32).copy()
+        cnt = np.zeros(3, np.int32)
+        n = C.c_int()
+        _lib.check(self._L.orbm_search_by_projection_points(self._hd._h, self.nn_ratio, _vp(qd), _vp(qx), _vp(qr), _vp(ql),
+                                                            _vp(qk), len(qd), _vp(k2), _vp(d2), len(k2), img_w, img_h,
+                                                            _vp(mp), C.byref(n), _vp(cnt)))
+        return n.value, mp, tuple(cnt.tolist())

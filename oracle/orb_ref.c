@@ -1014,3 +1014,77 @@ int orbref_search_for_initialization(float nn_ratio, int check_orientation,
     orbref_grid_free(g);
     return numMatches;
 }
+
+
+/* ---- SearchByProjection(lastFrame|lastKF, curFrame, th): modules/ORB/ORBMatcher.cpp:203-348 ---- */
+int orbref_search_by_projection_frame(int check_orientation, const uint8_t *q_desc, const float *q_xy,
+                                      const float *q_radius, const int32_t *q_octave, const float *q_angle,
+                                      const uint8_t *q_ok, int nq, const orbref_kp *kps2, const uint8_t *desc2, int n2,
+                                      int img_w, int img_h, int32_t *frame_mp)
+{
+    int numMatch = 0;
+    orbref_grid *g = orbref_grid_build(kps2, n2, img_w, img_h);
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (n2 ? n2 : 1));
+    rothist rh; rh_init(&rh);
+    for (int i = 0; i < nq; ++i) {
+        if (!q_ok[i]) continue; /* :213-224 */
+        int lastLevel = q_octave[i];
+        int nc = orbref_features_in_area(g, kps2, q_xy[2 * i], q_xy[2 * i + 1], q_radius[i], lastLevel - 1, lastLevel + 1, cand, n2);
+        if (nc == 0) continue;
+        int bestDist = TH_HIGH + 1, bestIdx2 = -1;
+        for (int k = 0; k < nc; ++k) {
+            int idx2 = cand[k];
+            if (frame_mp[idx2] != -1) continue; /* :235 */
+            int dist = orbref_hamming(q_desc + 32 * (size_t)i, desc2 + 32 * (size_t)idx2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = idx2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            frame_mp[bestIdx2] = i;
+            numMatch++;
+            if (check_orientation) rh_push(&rh, rot_bin(q_angle[i], kps2[bestIdx2].angle), bestIdx2);
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orbref_three_maxima(rh.n, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int b = 0; b < HISTO_LENGTH; ++b) {
+            if (b == ind1 || b == ind2 || b == ind3) continue;
+            for (int k = 0; k < rh.n[b]; ++k) { frame_mp[rh.items[b][k]] = -1; numMatch--; }
+        }
+    }
+    rh_free(&rh); free(cand); orbref_grid_free(g);
+    return numMatch;
+}
+
+/* ---- SearchByProjection(frame, mapPoints, th): modules/ORB/ORBMatcher.cpp:350-415 ---- */
+int orbref_search_by_projection_points(float nn_ratio, const uint8_t *q_desc, const float *q_xy, const float *q_radius,
+                                       const int32_t *q_level, const uint8_t *q_ok, int nq, const orbref_kp *kps2,
+                                       const uint8_t *desc2, int n2, int img_w, int img_h, int32_t *frame_mp,
+                                       int32_t *counters)
+{
+    int numMatch = 0, numOut = 0, fail1 = 0, fail2 = 0;
+    orbref_grid *g = orbref_grid_build(kps2, n2, img_w, img_h);
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (n2 ? n2 : 1));
+    for (int i = 0; i < nq; ++i) {
+        if (!q_ok[i]) { numOut++; continue; }
+        const int predictLevel = q_level[i];
+        int nc = orbref_features_in_area(g, kps2, q_xy[2 * i], q_xy[2 * i + 1], q_radius[i], predictLevel - 1, predictLevel, cand, n2);
+        if (nc == 0) continue;
+        int bestDist = 256, bestLevel = -1, secondDist = 257, secondLevel = -1, bestIdx = -1;
+        for (int k = 0; k < nc; ++k) {
+            int idx = cand[k];
+            if (frame_mp[idx] != -1) continue; /* :383 */
+            int dist = orbref_hamming(q_desc + 32 * (size_t)i, desc2 + 32 * (size_t)idx);
+            if (dist < bestDist) { secondDist = bestDist; bestDist = dist; secondLevel = bestLevel; bestLevel = kps2[idx].octave; bestIdx = idx; }
+            else if (dist < secondDist) { secondDist = dist; secondLevel = kps2[idx].octave; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == secondLevel && (float)bestDist > nn_ratio * (float)secondDist) { fail1++; continue; }
+            frame_mp[bestIdx] = i;
+            numMatch++;
+        } else fail2++;
+    }
+    if (counters) { counters[0] = numOut; counters[1] = fail1; counters[2] = fail2; }
+    free(cand); orbref_grid_free(g);
+    return numMatch;
+}

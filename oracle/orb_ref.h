@@ -148,6 +148,18 @@ int orbref_search_for_initialization(float nn_ratio, int check_orientation,
                                      float *prematched_xy /* n1*2 in/out */, int32_t *matches12,
                                      int window_size);
 
+/* SearchByProjection(lastFrame|lastKF, curFrame, th) (modules/ORB/ORBMatcher.cpp:203-348) with the camera maths
+ * done by the caller; see include/orbm.h for the argument meaning. */
+int orbref_search_by_projection_frame(int check_orientation, const uint8_t *q_desc, const float *q_xy,
+                                      const float *q_radius, const int32_t *q_octave, const float *q_angle,
+                                      const uint8_t *q_ok, int nq, const orbref_kp *kps2, const uint8_t *desc2, int n2,
+                                      int img_w, int img_h, int32_t *frame_mp);
+/* SearchByProjection(frame, mapPoints, th) (modules/ORB/ORBMatcher.cpp:350-415) */
+int orbref_search_by_projection_points(float nn_ratio, const uint8_t *q_desc, const float *q_xy, const float *q_radius,
+                                       const int32_t *q_level, const uint8_t *q_ok, int nq, const orbref_kp *kps2,
+                                       const uint8_t *desc2, int n2, int img_w, int img_h, int32_t *frame_mp,
+                                       int32_t *counters);
+
 #ifdef __cplusplus
 }
 #endif

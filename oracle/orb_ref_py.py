@@ -74,6 +74,12 @@ def lib():
         L.orbref_search_for_initialization.argtypes = [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                        C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                        C.c_void_p, C.c_void_p, C.c_int]
+        L.orbref_search_by_projection_frame.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                        C.c_int, C.c_void_p]
+        L.orbref_search_by_projection_points.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                         C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -266,3 +272,34 @@ def features_in_area(kps, img_w, img_h, x, y, r, min_level, max_level):
     n = lib().orbref_features_in_area(g, _p(kps), x, y, r, min_level, max_level, _p(out), len(out))
     lib().orbref_grid_free(g)
     return out[:n]
+
+
+def search_by_projection_frame(check_orientation, q_desc, q_xy, q_radius, q_octave, q_angle, q_ok, kps2, desc2, img_w,
+                               img_h, frame_mp):
+    qd = np.ascontiguousarray(q_desc, dtype=np.uint8)
+    qx = np.ascontiguousarray(q_xy, dtype=np.float32)
+    qr = np.ascontiguousarray(q_radius, dtype=np.float32)
+    qo = np.ascontiguousarray(q_octave, dtype=np.int32)
+    qa = np.ascontiguousarray(q_angle, dtype=np.float32)
+    qk = np.ascontiguousarray(q_ok, dtype=np.uint8)
+    k2 = np.ascontiguousarray(kps2, dtype=KP_DTYPE)
+    d2 = np.ascontiguousarray(desc2, dtype=np.uint8)
+    mp = np.ascontiguousarray(frame_mp, dtype=np.int32).copy()
+    n = lib().orbref_search_by_projection_frame(int(check_orientation), _p(qd), _p(qx), _p(qr), _p(qo), _p(qa), _p(qk),
+                                                len(qd), _p(k2), _p(d2), len(k2), img_w, img_h, _p(mp))
+    return n, mp
+
+
+def search_by_projection_points(nn_ratio, q_desc, q_xy, q_radius, q_level, q_ok, kps2, desc2, img_w, img_h, frame_mp):
+    qd = np.ascontiguousarray(q_desc, dtype=np.uint8)
+    qx = np.ascontiguousarray(q_xy, dtype=np.float32)
+    qr = np.ascontiguousarray(q_radius, dtype=np.float32)
+    ql = np.ascontiguousarray(q_level, dtype=np.int32)
+    qk = np.ascontiguousarray(q_ok, dtype=np.uint8)
+    k2 = np.ascontiguousarray(kps2, dtype=KP_DTYPE)
+    d2 = np.ascontiguousarray(desc2, dtype=np.uint8)
+    mp = np.ascontiguousarray(frame_mp, dtype=np.int32).copy()
+    cnt = np.zeros(3, np.int32)
+    n = lib().orbref_search_by_projection_points(nn_ratio, _p(qd), _p(qx), _p(qr), _p(ql), _p(qk), len(qd), _p(k2),
+                                                 _p(d2), len(k2), img_w, img_h, _p(mp), _p(cnt))
+    return n, mp, tuple(cnt.tolist())

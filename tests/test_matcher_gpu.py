@@ -142,3 +142,49 @@ def test_search_for_initialization_on_extracted_frames(oracle_mod):
         n_ref, m_ref, pre_ref = oracle_mod.search_for_initialization(0.9, ori, k1, d1, k2, d2, w, h, pre, 100)
         assert n_got == n_ref and np.array_equal(m_got, m_ref) and np.array_equal(pre_got, pre_ref)
         assert n_got > 50
+
+
+def _two_views(w=752, h=480, nf=2000):
+    from monoorbslam3_amd.extractor import ORBExtractor
+    canvas = synth.make_canvas(w + 40, h + 20, seed=909)
+    f1 = np.ascontiguousarray(canvas[5:5 + h, 10:10 + w])
+    f2 = np.ascontiguousarray(canvas[9:9 + h, 16:16 + w])
+    ex = ORBExtractor(nf, 1.2, 8, 20, 7)
+    k1, d1 = ex(f1)
+    k2, d2 = ex(f2)
+    return w, h, k1, d1, k2, d2
+
+
+@pytest.mark.parametrize("ori", [True, False])
+def test_search_by_projection_frame(oracle_mod, ori):
+    """last frame -> current frame (ORBMatcher.cpp:203-348): queries carry the (here: shifted) projections"""
+    from monoorbslam3_amd.matcher import ORBMatcher
+    w, h, k1, d1, k2, d2 = _two_views()
+    rng = np.random.RandomState(4)
+    n1, n2 = len(k1), len(k2)
+    q_xy = np.stack([k1["x"] - 6.0 + rng.normal(0, 1.5, n1), k1["y"] - 4.0 + rng.normal(0, 1.5, n1)], axis=1).astype(np.float32)
+    q_ok = (rng.uniform(size=n1) > 0.3).astype(np.uint8)
+    q_radius = (7.0 * k1["size"]).astype(np.float32)          # th * key_points[i].size
+    mp0 = np.where(rng.uniform(size=n2) > 0.95, 12345, -1).astype(np.int32)
+    m = ORBMatcher(0.9, ori)
+    got = m.SearchByProjectionFrame(d1, q_xy, q_radius, k1["octave"], k1["angle"], q_ok, k2, d2, w, h, mp0)
+    ref = oracle_mod.search_by_projection_frame(ori, d1, q_xy, q_radius, k1["octave"], k1["angle"], q_ok, k2, d2, w, h, mp0)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[0] > 100
+
+
+def test_search_by_projection_points(oracle_mod):
+    """local map points -> frame (ORBMatcher.cpp:350-415), with the level-dependent ratio test and the counters"""
+    from monoorbslam3_amd.matcher import ORBMatcher
+    w, h, k1, d1, k2, d2 = _two_views()
+    rng = np.random.RandomState(5)
+    n1, n2 = len(k1), len(k2)
+    q_xy = np.stack([k1["x"] - 6.0 + rng.normal(0, 2.0, n1), k1["y"] - 4.0 + rng.normal(0, 2.0, n1)], axis=1).astype(np.float32)
+    q_ok = (rng.uniform(size=n1) > 0.2).astype(np.uint8)
+    q_level = np.clip(k1["octave"] + rng.randint(0, 2, n1), 0, 7).astype(np.int32)
+    q_radius = (np.where(rng.uniform(size=n1) > 0.5, 2.5, 4.0) * 3.0 * (1.2 ** q_level)).astype(np.float32)
+    mp0 = np.where(rng.uniform(size=n2) > 0.9, 777, -1).astype(np.int32)
+    m = ORBMatcher(0.8, True)
+    got = m.SearchByProjectionPoints(d1, q_xy, q_radius, q_level, q_ok, k2, d2, w, h, mp0)
+    ref = oracle_mod.search_by_projection_points(0.8, d1, q_xy, q_radius, q_level, q_ok, k2, d2, w, h, mp0)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+    assert got[0] > 100 and got[2][0] == int((q_ok == 0).sum())
