@@ -107,3 +107,22 @@ def test_edge_cases(oracle_mod):
     view = big[:, 20:660]
     k, d = ex(view)
     _check_frame(ex, orc, np.ascontiguousarray(view), k, d, stages=False)
+
+
+def test_full_hd_config4(oracle_mod):
+    """BASELINE config 4 frame size (1920x1080, 2000 features): single frame, final outputs + per-level counts"""
+    w, h, nf = 1920, 1080, 2000
+    ex, orc = _mk(oracle_mod, nf, w, h)
+    img = synth.make_frames(1, w, h, seed=4321)[0]
+    kps, desc = ex(img)
+    _check_frame(ex, orc, img, kps, desc, stages=False)
+    assert ex.tap_level_counts(0).tolist() == orc.extract(img)[2]
+
+
+def test_odd_sizes_and_strides(oracle_mod):
+    """widths that are not multiples of 4 (blur / resize edge groups), tall images (nIni = 1), tiny top levels"""
+    for (w, h, nf) in ((333, 251, 300), (405, 607, 500), (130, 97, 100)):
+        ex, orc = _mk(oracle_mod, nf, w, h)
+        img = synth.make_frames(1, w, h, seed=w * 3 + h)[0]
+        kps, desc = ex(img)
+        _check_frame(ex, orc, img, kps, desc, stages=True)
