@@ -555,11 +555,26 @@ extern "C" int orbx_extract_batch(orbx_t *c, const uint8_t *imgs, int n_frames, 
     if (rc) return rc;
     const int scap = c->alloc_out_cap;
     hipStream_t s = c->stream;
-    for (int f = 0; f < n_frames; ++f)
-        HIP_TRY(hipMemcpy2DAsync(c->d_l0_stage + (size_t)f * c->l0_stage_fs, c->l0_stage_pitch,
-                                 imgs + (size_t)f * frame_stride, stride, width, height, hipMemcpyHostToDevice, s));
-    rc = enqueue_batch(c, s, c->d_l0_stage, c->l0_stage_fs, (int)c->l0_stage_pitch, n_frames, c->d_out_kp,
-                       c->d_out_desc, scap, c->d_out_n);
+    // Level 0 goes to HBM as it is laid out on the host: dense rows (stride == width, the cv::Mat::clone() case of
+    // Frame.cpp:17) are ONE linear copy (a pitched 2-D copy from pageable memory costs milliseconds); the kernels
+    // accept any level-0 pitch.  Only a genuinely strided input takes the 2-D copy.
+    size_t l0_fs = c->l0_stage_fs;
+    int l0_pitch = (int)c->l0_stage_pitch;
+    if (stride == width) {
+        l0_pitch = width;
+        l0_fs = (size_t)width * height;
+        if (frame_stride == l0_fs)
+            HIP_TRY(hipMemcpyAsync(c->d_l0_stage, imgs, l0_fs * n_frames, hipMemcpyHostToDevice, s));
+        else
+            for (int f = 0; f < n_frames; ++f)
+                HIP_TRY(hipMemcpyAsync(c->d_l0_stage + (size_t)f * l0_fs, imgs + (size_t)f * frame_stride, l0_fs,
+                                       hipMemcpyHostToDevice, s));
+    } else {
+        for (int f = 0; f < n_frames; ++f)
+            HIP_TRY(hipMemcpy2DAsync(c->d_l0_stage + (size_t)f * l0_fs, l0_pitch, imgs + (size_t)f * frame_stride, stride,
+                                     width, height, hipMemcpyHostToDevice, s));
+    }
+    rc = enqueue_batch(c, s, c->d_l0_stage, l0_fs, l0_pitch, n_frames, c->d_out_kp, c->d_out_desc, scap, c->d_out_n);
     if (rc) return rc;
     std::vector<int32_t> counts(n_frames);
     HIP_TRY(hipMemcpyAsync(counts.data(), c->d_out_n, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, s));
