@@ -1,0 +1,53 @@
+"""Python mirror of the optional local-BA linearisation kernels (include/orbba.h).
+
+One call = what g2o does for the monocular projection edges in one LM iteration of
+Optimize::localBundleAdjustment (reference modules/Backend/Optimize.cpp:892-893): residuals, analytic
+Jacobians (G2oTypes.cpp:36-47), Huber weights and the block J^T W J / -J^T W e accumulation, in double.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class _Problem(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("huber_delta", C.c_double), ("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("pose_R", C.c_void_p), ("pose_t", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p),
+                ("edge_pose", C.c_void_p), ("edge_point", C.c_void_p), ("edge_z", C.c_void_p),
+                ("edge_inv_sigma2", C.c_void_p)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("chi2", C.c_void_p), ("error", C.c_void_p), ("H_pp", C.c_void_p), ("b_p", C.c_void_p),
+                ("H_ll", C.c_void_p), ("b_l", C.c_void_p), ("H_lp", C.c_void_p), ("kernel_ms", C.c_float)]
+
+
+HUBER_MONO = float(np.sqrt(np.float32(5.991)))  # thHuberMono = sqrtf(5.991) (Optimize.cpp:857)
+
+
+def linearize(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, edge_z, edge_inv_sigma2,
+              huber_delta=HUBER_MONO, device=-1):
+    """Returns dict(chi2, error, H_pp, b_p, H_ll, b_l, H_lp, kernel_ms)."""
+    L = _lib.lib()
+    fn = L.orbba_linearize
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(_Problem), C.POINTER(_Result), C.c_int]
+    f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    R, t, P = f8(pose_R).reshape(-1, 9), f8(pose_t).reshape(-1, 3), f8(points).reshape(-1, 3)
+    fix = np.ascontiguousarray(pose_fixed, dtype=np.uint8)
+    ep = np.ascontiguousarray(edge_pose, dtype=np.int32)
+    el = np.ascontiguousarray(edge_point, dtype=np.int32)
+    z, w = f8(edge_z).reshape(-1, 2), f8(edge_inv_sigma2)
+    npz, nl, ne = len(R), len(P), len(ep)
+    out = {"chi2": np.zeros(ne), "error": np.zeros((ne, 2)), "H_pp": np.zeros((npz, 6, 6)), "b_p": np.zeros((npz, 6)),
+           "H_ll": np.zeros((nl, 3, 3)), "b_l": np.zeros((nl, 3)), "H_lp": np.zeros((ne, 3, 6))}
+    vp = lambda a: a.ctypes.data  # noqa: E731
+    prob = _Problem(cam[0], cam[1], cam[2], cam[3], huber_delta, npz, nl, ne, vp(R), vp(t), vp(fix), vp(P), vp(ep), vp(el),
+                    vp(z), vp(w))
+    res = _Result(vp(out["chi2"]), vp(out["error"]), vp(out["H_pp"]), vp(out["b_p"]), vp(out["H_ll"]), vp(out["b_l"]),
+                  vp(out["H_lp"]), 0.0)
+    _lib.check(fn(C.byref(prob), C.byref(res), device))
+    out["kernel_ms"] = float(res.kernel_ms)
+    return out

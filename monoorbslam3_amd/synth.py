@@ -116,3 +116,46 @@ def feature_vector_by_prefix(desc, bits):
     node_ids, starts = np.unique(ks, return_index=True)
     offsets = np.concatenate([starts, [len(ks)]]).astype(np.int32)
     return node_ids.astype(np.uint32), offsets, order.astype(np.uint32)
+
+
+def make_ba_problem(n_poses=20, n_points=3000, seed=DEFAULT_SEED, width=1242, height=375, n_fixed=4):
+    """BASELINE config 5: poses on a 10 m arc looking at a 20 x 20 x 10 m box of points, pinhole
+    fx = fy = 718.856, cx = 607.19, cy = 185.22; every point observed by every pose where it projects inside
+    the image; 1 px Gaussian pixel noise; octave-dependent 1/sigma^2.  Edges are grouped by point."""
+    rng = np.random.RandomState(seed + 29)
+    cam = (718.856, 718.856, 607.19, 185.22)
+    pts = np.stack([rng.uniform(-10, 10, n_points), rng.uniform(-5, 5, n_points), rng.uniform(8, 28, n_points)], 1)
+    R, t = [], []
+    for k in range(n_poses):
+        a = (k / max(n_poses - 1, 1) - 0.5) * 0.35            # yaw along the arc
+        c = np.array([10.0 * np.sin(a), 0.05 * k, 10.0 * (1 - np.cos(a))])   # camera centre
+        Rwc = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        Rcw = Rwc.T
+        R.append(Rcw)
+        t.append(-Rcw @ c)
+    R, t = np.array(R), np.array(t)
+    ep, el, z, w = [], [], [], []
+    for j in range(n_points):
+        for k in range(n_poses):
+            pc = R[k] @ pts[j] + t[k]
+            if pc[2] <= 0.5:
+                continue
+            u = cam[0] * pc[0] / pc[2] + cam[2]
+            v = cam[1] * pc[1] / pc[2] + cam[3]
+            if 0 <= u < width and 0 <= v < height:
+                octave = rng.randint(0, 8)
+                sig = np.float32(1.2) ** octave
+                ep.append(k); el.append(j)
+                z.append([u + rng.normal(0, 1.0), v + rng.normal(0, 1.0)])
+                w.append(float(np.float32(1.0) / np.float32(sig) / np.float32(sig)))
+    # perturb the estimates so that residuals and Huber outliers are non-trivial
+    pts_est = pts + rng.normal(0, 0.05, pts.shape)
+    t_est = t + rng.normal(0, 0.01, t.shape)
+    z = np.array(z)
+    bad = rng.uniform(size=len(z)) < 0.03
+    z[bad] += rng.normal(0, 12.0, (int(bad.sum()), 2))
+    fixed = np.zeros(n_poses, np.uint8)
+    fixed[:n_fixed] = 1
+    return {"cam": cam, "pose_R": R.reshape(n_poses, 9), "pose_t": t_est, "pose_fixed": fixed, "points": pts_est,
+            "edge_pose": np.array(ep, np.int32), "edge_point": np.array(el, np.int32), "edge_z": z,
+            "edge_inv_sigma2": np.array(w)}

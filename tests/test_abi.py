@@ -20,12 +20,13 @@ def built():
 def _declared(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(orb[xm]_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(orb(?:x|m|ba)_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_every_declared_symbol_is_exported(built):
     L = C.CDLL(built.LIB_PATH)
-    names = _declared("orbx.h") + _declared("orbm.h")
+    names = _declared("orbx.h") + _declared("orbm.h") + _declared("orbba.h")
+    assert "orbba_linearize" in names
     assert len(names) >= 25
     for n in names:
         assert hasattr(L, n), "liborbx.so does not export %s" % n
