@@ -188,7 +188,9 @@ static int compute_geometry(const orbx_ctx *c, int w0, int h0, Geometry *g)
             const int colsum = fullc * 15 + (remc + 1) / 2, rowsum = fullr * 15 + (remr + 1) / 2;
             v.cand_cap = colsum * rowsum;
             v.kcap = std::max(v.quota + 3, 4 * v.n_ini);
-            v.node_cap = std::max(4 * v.quota, 4 * v.n_ini) + 8;
+            // list-size bound: the first main round makes <= 4*nIni nodes; every later main round starts from
+            // size + 3*nToExpand <= quota and so ends <= quota; the final phase stops at <= quota + 2
+            v.node_cap = std::max(v.quota + 3, 4 * v.n_ini) + 8;
         } else { // level too small for the 19-px border: yields nothing (the reference misbehaves here)
             v.n_cols = v.n_rows = 0; v.n_ini = 1; v.h_x = 1; v.cand_cap = 0; v.kcap = 1; v.node_cap = 8;
         }

@@ -413,7 +413,10 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
 {
     __shared__ __align__(16) uint8_t tile[36 * FC_TP];
     __shared__ __align__(16) uint8_t score[32 * FC_SP];
-    __shared__ uint16_t queue1[ORBX_CELL * ORBX_CELL], queue2[ORBX_CELL * ORBX_CELL];
+    // queue2 aliases queue1: the 8-pair test compacts in place (a batch is read before it is written, and it is
+    // written at positions <= the ones just read)
+    __shared__ uint16_t queue1[ORBX_CELL * ORBX_CELL];
+    uint16_t *queue2 = queue1;
     __shared__ uint32_t keepers[15 * 15];
     __shared__ int s_nkeep;
 
@@ -1496,7 +1499,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, 
 // ---------------------------------------------------------------------------------------------
 #define DP_W 64 // patch pitch: four ALIGNED 16-byte loads per row starting at floor16(x-19)
 #define DP_H 37
-#define DP_K 4  // keypoints per wave: their record / patch loads are all issued before the first use
+#define DP_K 2  // keypoints per wave: their record / patch loads are all issued before the first use
 __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restrict__ levels, OrbxBuffers b,
                                                      orbx_kp *__restrict__ out_kp, uint8_t *__restrict__ out_desc,
                                                      int cap, int32_t *__restrict__ out_n, int dbg, int per_frame,
