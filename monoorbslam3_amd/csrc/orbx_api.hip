@@ -47,7 +47,6 @@ struct orbx_ctx {
     OrbxLevels *d_levels;
     OrbxTap *d_xtap[ORBX_MAX_LEVELS], *d_ytap[ORBX_MAX_LEVELS];
     int *d_umax, *d_taps;
-    uint16_t *d_fast_segs; int n_fast_segs;
     uint16_t *d_fast_cells; int n_fast_cells;
     uint16_t *d_blur_tiles; int n_blur_tiles;
     uint8_t *d_l0_stage; size_t l0_stage_fs;
@@ -282,12 +281,6 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
         c->sort_lds_bytes = g.sort_lds;
         HIP_TRY(hipMemcpy(c->d_levels, &c->levels, sizeof(OrbxLevels), hipMemcpyHostToDevice));
         {
-            const int ns = orbx_build_fast_segments(c->levels, nullptr);
-            std::vector<uint16_t> segs((size_t)std::max(ns, 1) * 4);
-            orbx_build_fast_segments(c->levels, segs.data());
-            HIP_TRY(dev_alloc(&c->d_fast_segs, segs.size()));
-            HIP_TRY(hipMemcpy(c->d_fast_segs, segs.data(), segs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-            c->n_fast_segs = ns;
             const int nc = orbx_build_fast_cells(c->levels, nullptr);
             std::vector<uint16_t> cells((size_t)std::max(nc, 1) * 4);
             orbx_build_fast_cells(c->levels, cells.data());
@@ -401,7 +394,7 @@ extern "C" void orbx_destroy(orbx_t *c)
     OrbxBuffers &b = c->buf;
     void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.pcode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
                     b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.kp_ang, b.sel_count, c->d_levels, c->d_umax, c->d_taps,
-                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n, c->d_fast_segs, c->d_fast_cells, c->d_blur_tiles};
+                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n, c->d_fast_cells, c->d_blur_tiles};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         if (c->d_xtap[l]) (void)hipFree(c->d_xtap[l]);
@@ -489,8 +482,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
                            n_frames);
     }
     if (t) HIP_TRY(hipEventRecord(c->ev[1], s));
-    orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_segs, c->n_fast_segs, c->d_fast_cells, c->n_fast_cells,
-                     n_frames);
+    orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_cells, c->n_fast_cells, n_frames);
     if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
     orbx_launch_blur(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames);
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));

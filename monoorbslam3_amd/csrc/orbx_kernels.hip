@@ -111,16 +111,6 @@ void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int sr
 // so one strength tile answers both the ini and the min threshold of a cell.
 // ---------------------------------------------------------------------------------------------
 
-#define FAST_SEG 8   // cells per strip segment (30*8 = 240 px, a multiple of 16 -> aligned segment starts)
-#define FAST_TP 256  // tile pitch in bytes: 240 + 6 used
-#define FAST_SP 256  // score-map pitch: 1 + 240 + 1 used
-#define FAST_HALF 15 // rows per chunk of the survivor queues
-#define FAST_QCAP (FAST_SEG * 30 * FAST_HALF)
-#define FAST_KCAP (FAST_SEG * 15 * 15) // at most one strict 3x3 maximum per 2x2 block of a cell
-
-struct FastSeg { // one strip segment
-    uint16_t level, cy, cx0, ncells;
-};
 struct FastSrc {
     const uint8_t *base[ORBX_MAX_LEVELS];
     size_t frame_stride[ORBX_MAX_LEVELS];
@@ -129,16 +119,6 @@ struct FastSrc {
 struct __attribute__((packed, aligned(1))) UnalignedU32 { uint32_t v; };
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void fast_load_ring(const uint8_t *t /* centre pixel in the LDS tile */, int d[16])
-{
-    const int v = t[0];
-    d[0] = v - t[3 * FAST_TP];      d[1] = v - t[3 * FAST_TP + 1];  d[2] = v - t[2 * FAST_TP + 2];
-    d[3] = v - t[FAST_TP + 3];      d[4] = v - t[3];                d[5] = v - t[-FAST_TP + 3];
-    d[6] = v - t[-2 * FAST_TP + 2]; d[7] = v - t[-3 * FAST_TP + 1]; d[8] = v - t[-3 * FAST_TP];
-    d[9] = v - t[-3 * FAST_TP - 1]; d[10] = v - t[-2 * FAST_TP - 2]; d[11] = v - t[-FAST_TP - 3];
-    d[12] = v - t[-3];              d[13] = v - t[FAST_TP - 3];     d[14] = v - t[2 * FAST_TP - 2];
-    d[15] = v - t[3 * FAST_TP - 1];
-}
 // an arc of 9 out of 16 holds one pixel of every opposite pair: exact necessary condition for S >= thr
 __device__ __forceinline__ bool fast_pairs(const int d[16], int thr)
 {
@@ -175,219 +155,19 @@ __device__ __forceinline__ s16x2 pk_bytes(uint32_t hi, uint32_t lo, uint32_t sel
     return __builtin_bit_cast(s16x2, r);
 }
 
-// One workgroup = one strip segment: up to FAST_SEG horizontally adjacent cells of one cell row of
-// one level of one frame; a single launch covers every level (segment table).
-//   1. the (30+6)-row tile goes HBM -> LDS with dword loads (segment starts are 16-byte aligned in
-//      level coordinates because 30*FAST_SEG is a multiple of 16);
-//   2. every pixel takes the 4-point compass test (any 9-arc holds two adjacent compass points),
-//      two pixels per instruction in packed 16-bit lanes; survivors are compacted into an LDS
-//      queue (popcount + wave prefix);
-//   3. queue 1 takes the exact 8-pair test, its survivors (ballot + mbcnt compaction) the exact
-//      strength, written to a u8 score map;
-//   4. strict 3x3 NMS inside each 30-px cell from the score map, keepers appended to a list.
-// Everything runs at the ini threshold first; cells left without a keeper are redone at the min
-// threshold (reference :604-607).  Both answers are exact for their cells (see SURVEY A.3).
-__global__ __launch_bounds__(256) void k_fast_strips(FastSrc src, const OrbxLevels *__restrict__ levels,
-                                                     const FastSeg *__restrict__ segs, u64 *__restrict__ cand,
-                                                     size_t cand_fs, int *__restrict__ cand_count, int dbg)
-{
-    __shared__ __align__(16) uint8_t tile[36 * FAST_TP];
-    __shared__ __align__(16) uint8_t score[32 * FAST_SP];
-    __shared__ uint16_t queue1[FAST_QCAP], queue2[FAST_QCAP];
-    __shared__ uint32_t keepers[FAST_KCAP];
-    __shared__ int s_q1n, s_q2n, s_nkeep, s_base;
-    __shared__ int s_cell_keep[FAST_SEG];
-
-    const FastSeg sg = segs[blockIdx.x];
-    const int frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int level = sg.level;
-    const OrbxLevel &lv = levels->lv[level];
-    const int x0 = ORBX_EDGE + sg.cx0 * ORBX_CELL, y0 = ORBX_EDGE + sg.cy * ORBX_CELL;
-    const int wpx = min(sg.ncells * ORBX_CELL, lv.w - ORBX_EDGE - x0); // region pixels in this segment
-    const int hpx = min(ORBX_CELL, lv.h - ORBX_EDGE - y0);
-    const int tw = wpx + 6, th = hpx + 6;
-    const int pitch = src.pitch[level];
-    const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level] + (size_t)(y0 - 3) * pitch + (x0 - 3);
-
-    for (int i = tid; i < 32 * FAST_SP / 16; i += 256) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) s_nkeep = 0;
-    if (tid < FAST_SEG) s_cell_keep[tid] = 0;
-    // ---- 1. tile load: lane = dword column, wave = row (mod 4)
-    {
-        const int dw_per_row = (tw + 3) >> 2; // <= 62
-        const int row_left = lv.w - (x0 - 3); // bytes from the tile's left edge to the end of the image row
-        const int tx = lane * 4;
-        if (lane < dw_per_row) {
-            for (int ty = wave; ty < th; ty += 4) {
-                const uint8_t *p = S + (size_t)ty * pitch + tx;
-                uint32_t v;
-                if (tx + 4 <= row_left) v = reinterpret_cast<const UnalignedU32 *>(p)->v;
-                else {
-                    v = 0;
-                    for (int k = 0; k < row_left - tx; ++k) v |= (uint32_t)p[k] << (8 * k);
-                }
-                *reinterpret_cast<uint32_t *>(&tile[ty * FAST_TP + tx]) = v;
-            }
-        }
-    }
-    if (dbg & 1) return;
-    const int runs_per_row = (wpx + 3 + 3) >> 2; // dword columns covering tile columns [0, wpx + 3)
-    const int ncells = sg.ncells;
-    uint32_t cellmask = (1u << ncells) - 1;
-    int thr = levels->ini_th;
-
-    for (int pass = 0; pass < 2; ++pass) {
-        // which of this lane's four pixels (tile columns 4*lane .. +3, region column = tile column - 3)
-        // are region pixels of a cell that is processed in this pass
-        uint32_t colmask = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int col = 4 * lane + k - 3;
-            if (col >= 0 && col < wpx && ((cellmask >> (col / ORBX_CELL)) & 1)) colmask |= 1u << k;
-        }
-        const s16x2 T = {(short)thr, (short)thr};
-        for (int r0 = 0; r0 < hpx; r0 += FAST_HALF) {
-            const int r1 = min(r0 + FAST_HALF, hpx);
-            if (tid == 0) { s_q1n = 0; s_q2n = 0; }
-            __syncthreads(); // also orders the tile load / previous chunk's score writes
-            // ---- 2. compass test
-            uint32_t mask = 0;
-            if (colmask && lane < runs_per_row) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int r = r0 + wave + 4 * it;
-                    if (r < r1) {
-                        const uint8_t *row = &tile[(r + 3) * FAST_TP + 4 * lane];
-                        const uint32_t cm = lane > 0 ? *reinterpret_cast<const uint32_t *>(row - 4) : 0u;
-                        const uint32_t c0 = *reinterpret_cast<const uint32_t *>(row);
-                        const uint32_t cp = *reinterpret_cast<const uint32_t *>(row + 4);
-                        const uint32_t up = *reinterpret_cast<const uint32_t *>(row - 3 * FAST_TP);
-                        const uint32_t dn = *reinterpret_cast<const uint32_t *>(row + 3 * FAST_TP);
-                        uint32_t bits = 0;
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) { // pixels (0,1) then (2,3)
-                            const s16x2 V = pk_bytes(0, c0, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));
-                            const s16x2 dE = V - pk_bytes(cp, c0, h ? PERM_SEL(5, 6) : PERM_SEL(3, 4)); // (+3, 0)
-                            const s16x2 dW = V - pk_bytes(c0, cm, h ? PERM_SEL(3, 4) : PERM_SEL(1, 2)); // (-3, 0)
-                            const s16x2 dS = V - pk_bytes(0, dn, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));  // (0, +3)
-                            const s16x2 dN = V - pk_bytes(0, up, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));  // (0, -3)
-                            const s16x2 hi = __builtin_elementwise_min(__builtin_elementwise_max(dS, dN),
-                                                                       __builtin_elementwise_max(dE, dW));
-                            const s16x2 lo = __builtin_elementwise_max(__builtin_elementwise_min(dS, dN),
-                                                                       __builtin_elementwise_min(dE, dW));
-                            const s16x2 m = __builtin_elementwise_max(hi, -lo) - T; // > 0 <=> passes
-                            bits |= (uint32_t)(m.x > 0) << (2 * h);
-                            bits |= (uint32_t)(m.y > 0) << (2 * h + 1);
-                        }
-                        mask |= (bits & colmask) << (4 * it);
-                    }
-                }
-            }
-            {
-                const int cnt = __popc(mask);
-                int incl = cnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int y = __shfl_up(incl, o);
-                    if (lane >= o) incl += y;
-                }
-                const int wave_total = __shfl(incl, 63);
-                int base = 0;
-                if (lane == 63 && wave_total) base = atomicAdd(&s_q1n, wave_total);
-                base = __shfl(base, 63);
-                int slot = base + incl - cnt;
-                uint32_t m = mask;
-                while (m) {
-                    const int b = __ffs(m) - 1;
-                    m &= m - 1;
-                    const int r = r0 + wave + 4 * (b >> 2);
-                    queue1[slot++] = (uint16_t)((r << 8) | (4 * lane + (b & 3) - 3));
-                }
-            }
-            __syncthreads();
-            // ---- 3a. exact 8-pair test on queue 1 -> queue 2
-            const int q1n = (dbg & 2) ? 0 : s_q1n;
-            for (int i0 = 0; i0 < q1n; i0 += 256) {
-                const int i = i0 + tid;
-                bool ok = false;
-                int e = 0;
-                if (i < q1n) {
-                    e = queue1[i];
-                    int d[16];
-                    fast_load_ring(&tile[((e >> 8) + 3) * FAST_TP + (e & 255) + 3], d);
-                    ok = fast_pairs(d, thr);
-                }
-                const u64 mk = __ballot(ok);
-                if (mk) {
-                    const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&s_q2n, (int)__popcll(mk));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (ok) queue2[base + pre] = (uint16_t)e;
-                }
-            }
-            __syncthreads();
-            // ---- 3b. exact strength of the survivors
-            const int q2n = (dbg & 4) ? 0 : s_q2n;
-            for (int i = tid; i < q2n; i += 256) {
-                const int e = queue2[i], r = e >> 8, col = e & 255;
-                int d[16];
-                fast_load_ring(&tile[(r + 3) * FAST_TP + col + 3], d);
-                const int sc = fast_score(d);
-                if (sc >= thr) score[(r + 1) * FAST_SP + col + 1] = (uint8_t)sc;
-            }
-        }
-        __syncthreads();
-        // ---- 4. NMS inside each cell, straight from the score map: lane = dword column, wave = row (mod 4)
-        if (lane <= (wpx + 1) >> 2 && !(dbg & 8)) {
-            for (int r = wave; r < hpx; r += 4) {
-                const uint32_t wd = *reinterpret_cast<const uint32_t *>(&score[(r + 1) * FAST_SP + 4 * lane]);
-                if (wd == 0) continue;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int sc = (wd >> (8 * k)) & 255;
-                    const int col = 4 * lane + k - 1;
-                    if (sc == 0 || col < 0 || col >= wpx) continue;
-                    const int cell = col / ORBX_CELL, xin = col - cell * ORBX_CELL;
-                    if (!((cellmask >> cell) & 1)) continue;
-                    const uint8_t *sp = &score[(r + 1) * FAST_SP + col + 1];
-                    const bool l = xin != 0, rr = xin != ORBX_CELL - 1; // neighbours in the adjacent cell count as 0
-                    const bool keep = sc > sp[-FAST_SP] && sc > sp[FAST_SP] &&
-                                      (!l || (sc > sp[-1] && sc > sp[-FAST_SP - 1] && sc > sp[FAST_SP - 1])) &&
-                                      (!rr || (sc > sp[1] && sc > sp[-FAST_SP + 1] && sc > sp[FAST_SP + 1]));
-                    if (keep) {
-                        keepers[atomicAdd(&s_nkeep, 1)] = (uint32_t)r | ((uint32_t)col << 8) | ((uint32_t)sc << 16);
-                        atomicAdd(&s_cell_keep[cell], 1);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // cells without a keeper are redone at the min threshold (reference :604-607)
-        uint32_t empty = 0;
-        for (int c = 0; c < ncells; ++c) empty |= (uint32_t)(s_cell_keep[c] == 0) << c;
-        if (pass == 1 || empty == 0) break;
-        cellmask = empty;
-        thr = levels->min_th;
-    }
-    // ---- emission
-    const int nk = s_nkeep;
-    if (nk == 0) return;
-    if (tid == 0) s_base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], nk);
-    __syncthreads();
-    u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + s_base;
-    for (int i = tid; i < nk; i += 256) {
-        const uint32_t e = keepers[i];
-        const uint32_t x = sg.cx0 * ORBX_CELL + ((e >> 8) & 255), y = sg.cy * ORBX_CELL + (e & 255);
-        out[i] = (u64)(x | (y << 16)) | ((u64)(e >> 16) << 32);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// One WAVE per cell: the same pipeline as k_fast_strips, but a 64-thread workgroup owns one 30x30
-// cell end to end, so no phase waits for other waves and up to ~20 independent waves per CU hide
-// each other's LDS / L2 latency.  The tile rows overlap with the neighbour cells' (36x36 bytes per
-// 30x30 cell, served by L2).
+// One WAVE per cell: a 64-thread workgroup owns one 30x30 cell end to end, so no phase waits for
+// other waves and ~25 independent waves per CU hide each other's LDS / L2 latency (a 256-thread
+// "strip of 8 cells" version of the same pipeline was 1.8x slower).  One launch covers all levels.
+//   1. the 36x40 tile goes L2 -> LDS with 64-bit loads (rows overlap with the neighbour cells');
+//   2. every pixel takes the 4-point compass test (any 9-arc holds two adjacent compass points), two
+//      pixels per instruction in packed 16-bit lanes; survivors are compacted into an LDS queue
+//      (popcount + wave prefix);
+//   3. the queue takes the exact 8-pair test (ballot + mbcnt compaction in place), its survivors the
+//      exact strength, written to a u8 score map;
+//   4. strict 3x3 NMS inside the cell from the score map, keepers appended to a list.
+// Everything runs at the ini threshold first; a cell left without a keeper is redone at the min
+// threshold (reference :604-607).  Both answers are exact for their cells (SURVEY A.3).
 // ---------------------------------------------------------------------------------------------
 #define FC_TP 40 // tile pitch; tile column tc <-> level x = x0 - 4 + tc, region columns tc in [4, 4 + cw)
 #define FC_SP 40 // score-map pitch; score column = tc - 3, so the cell occupies columns 1..cw
@@ -572,46 +352,19 @@ int orbx_build_fast_cells(const OrbxLevels &levels, uint16_t *out /* 4 per cell,
     return n;
 }
 
-int orbx_debug_flags = 0; // timing experiments only (tools/phase_timing.py); 0 in production
-extern "C" void orbx_debug_set_flags(int f) { orbx_debug_flags = f; }
-
 void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
-                      const OrbxLevels &levels, const OrbxBuffers &b, const void *d_segs, int n_segs, const void *d_cells,
-                      int n_cells, int n_frames)
+                      const OrbxLevels &levels, const OrbxBuffers &b, const void *d_cells, int n_cells, int n_frames)
 {
-    if (n_segs <= 0) return;
+    if (n_cells <= 0) return;
     FastSrc src;
     for (int l = 0; l < levels.n_levels; ++l) {
         src.base[l] = l == 0 ? l0 : b.img_arena + levels.lv[l].raw_off;
         src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
         src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
     }
-    if (orbx_debug_flags & 16)
-        hipLaunchKernelGGL(k_fast_strips, dim3(n_segs, n_frames), dim3(256), 0, s, src, d_levels,
-                           reinterpret_cast<const FastSeg *>(d_segs), b.cand, b.cand_frame_stride, b.cand_count,
-                           orbx_debug_flags);
-    else
-        hipLaunchKernelGGL(k_fast_cells_wave, dim3(orbx_xcd_grid(n_cells, n_frames)), dim3(64), 0, s, src, d_levels,
-                           reinterpret_cast<const FastCell *>(d_cells), b.cand, b.cand_frame_stride, b.cand_count, n_cells,
-                           n_frames);
-}
-
-// host side: segment table for the current geometry (4 x uint16 per segment)
-int orbx_build_fast_segments(const OrbxLevels &levels, uint16_t *out /* 4 per segment, or NULL to count */)
-{
-    int n = 0;
-    for (int l = 0; l < levels.n_levels; ++l) {
-        const OrbxLevel &v = levels.lv[l];
-        for (int cy = 0; cy < v.n_rows; ++cy)
-            for (int cx0 = 0; cx0 < v.n_cols; cx0 += FAST_SEG) {
-                if (out) {
-                    out[4 * n + 0] = (uint16_t)l; out[4 * n + 1] = (uint16_t)cy; out[4 * n + 2] = (uint16_t)cx0;
-                    out[4 * n + 3] = (uint16_t)((v.n_cols - cx0) < FAST_SEG ? (v.n_cols - cx0) : FAST_SEG);
-                }
-                ++n;
-            }
-    }
-    return n;
+    hipLaunchKernelGGL(k_fast_cells_wave, dim3(orbx_xcd_grid(n_cells, n_frames)), dim3(64), 0, s, src, d_levels,
+                       reinterpret_cast<const FastCell *>(d_cells), b.cand, b.cand_frame_stride, b.cand_count, n_cells,
+                       n_frames);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1415,23 +1168,26 @@ void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLev
 }
 
 // ---------------------------------------------------------------------------------------------
-// Orientation: intensity centroid on the raw level (:18-42), 16 lanes per keypoint, 16 keypoints per
-// workgroup.  A lane takes four (patch row, left/right half) tasks: one unaligned 128-bit load each,
+// Orientation: intensity centroid on the raw level (:18-42), OR_LANES lanes per keypoint, OR_KP keypoints
+// per workgroup.  A lane takes OR_TASKS (patch row, left/right half) tasks: one unaligned 128-bit load each,
 // bytes outside the circular patch masked off, v_dot4_u32_u8 for sum(|u|*I) and v_sad_u8 for sum(I).
-// After a 16-lane shuffle reduction the moments go through LDS to 16 lanes that evaluate fastAtan2 and
+// After a shuffle reduction inside each group the moments go through LDS to OR_KP lanes that evaluate fastAtan2 and
 // the double-precision sin/cos once per keypoint (one lane per keypoint instead of one wave).
 // ---------------------------------------------------------------------------------------------
+#define OR_LANES 8                 // lanes per keypoint
+#define OR_KP (256 / OR_LANES)     // keypoints per workgroup
+#define OR_TASKS (64 / OR_LANES)   // (row, half) tasks per lane
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, size_t l0_fs, int l0_pitch,
                                                 const OrbxLevels *__restrict__ levels, OrbxBuffers b,
                                                 const int *__restrict__ u_max, int per_frame, int n_frames)
 {
-    __shared__ int s_m[16][2];
+    __shared__ int s_m[OR_KP][2];
     int frame, blk;
     if (!xcd_remap(per_frame, n_frames, &frame, &blk)) return;
-    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    const int tid = threadIdx.x, sub = tid & (OR_LANES - 1), grp = tid / OR_LANES;
     const int L = levels->n_levels;
     const int *cnts = b.sel_count + frame * ORBX_MAX_LEVELS;
-    const int slot = blk * 16 + grp;
+    const int slot = blk * OR_KP + grp;
     bool live = slot < levels->kcap_total;
     int level = 0;
     for (int l = 1; l < L; ++l) level += live && slot >= levels->lv[l].kp_off;
@@ -1444,18 +1200,18 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, 
         const uint8_t *raw = level == 0 ? l0 + (size_t)frame * l0_fs : b.img_arena + (size_t)frame * b.img_frame_stride + lv.raw_off;
         const int rpitch = level == 0 ? l0_pitch : lv.pitch;
         struct __attribute__((packed, aligned(1))) U128 { uint32_t w[4]; };
-        U128 q[4];
-        int vv[4], dd[4];
+        U128 q[OR_TASKS];
+        int vv[OR_TASKS], dd[OR_TASKS];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { // task t = sub + 16k: row v = t/2 - 15, half = t & 1 (tasks 62, 63 are idle)
-            const int t = sub + 16 * k, v = min(t >> 1, 2 * ORBX_HALF_PATCH) - ORBX_HALF_PATCH;
+        for (int k = 0; k < OR_TASKS; ++k) { // task t = sub + OR_LANES*k: row v = t/2 - 15, half = t & 1 (tasks 62, 63 are idle)
+            const int t = sub + OR_LANES * k, v = min(t >> 1, 2 * ORBX_HALF_PATCH) - ORBX_HALF_PATCH;
             vv[k] = v;
             dd[k] = t < 2 * (2 * ORBX_HALF_PATCH + 1) ? u_max[v < 0 ? -v : v] : -1;
             q[k] = *reinterpret_cast<const U128 *>(raw + (size_t)(y + v) * rpitch + x + ((t & 1) ? 0 : -16));
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int half = (sub + 16 * k) & 1, d = dd[k];
+        for (int k = 0; k < OR_TASKS; ++k) {
+            const int half = (sub + OR_LANES * k) & 1, d = dd[k];
             uint32_t ssum = 0, wsum = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -1475,14 +1231,14 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, 
         }
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
+    for (int o = OR_LANES / 2; o > 0; o >>= 1) {
         m10 += __shfl_xor(m10, o);
         m01 += __shfl_xor(m01, o);
     }
     if (sub == 0) { s_m[grp][0] = m10; s_m[grp][1] = m01; }
     __syncthreads();
-    if (tid < 16) {
-        const int s2 = blk * 16 + tid;
+    if (tid < OR_KP) {
+        const int s2 = blk * OR_KP + tid;
         if (s2 < levels->kcap_total) {
             const float ang = orb_fast_atan2((float)s_m[tid][1], (float)s_m[tid][0]);
             float cs, sn;
@@ -1502,8 +1258,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, 
 #define DP_K 2  // keypoints per wave: their record / patch loads are all issued before the first use
 __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restrict__ levels, OrbxBuffers b,
                                                      orbx_kp *__restrict__ out_kp, uint8_t *__restrict__ out_desc,
-                                                     int cap, int32_t *__restrict__ out_n, int dbg, int per_frame,
-                                                     int n_frames)
+                                                     int cap, int32_t *__restrict__ out_n, int per_frame, int n_frames)
 {
     // the 37x37 neighbourhood of each keypoint is staged row by row (coalesced, ~45 cache lines) and the
     // 512 rotated samples are byte gathers from LDS instead of ~250 scattered cache-line touches
@@ -1544,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
     }
 #pragma unroll
     for (int k = 0; k < DP_K; ++k) {
-        if (live[k] && !(dbg & 32)) {
+        if (live[k]) {
             const OrbxLevel &lv = levels->lv[level[k]];
             const int x = rec[k].x & 0xFFFF, y = rec[k].x >> 16, pitch = lv.pitch;
             // arena rows are 64-byte aligned, so one shift (x-19)&15 serves the whole patch: the rows go to LDS
@@ -1568,7 +1323,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
     }
 #pragma unroll
     for (int k = 0; k < DP_K; ++k) {
-        if (!live[k] || (dbg & 128)) continue;
+        if (!live[k]) continue;
         const OrbxLevel &lv = levels->lv[level[k]];
         const float a = ang[k].y, bb = ang[k].z;
         const uint8_t *center = &patch[wv][k][18 * DP_W + 19 + (((int)(rec[k].x & 0xFFFF) - 19) & 15)];
@@ -1582,11 +1337,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
             const int t0 = center[r0 * DP_W + c0], t1 = center[r1 * DP_W + c1];
             bits[j] = __ballot(t0 < t1);
         }
-        if (lane < 4 && !(dbg & 64)) {
+        if (lane < 4) {
             const u64 w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
             *reinterpret_cast<u64 *>(out_desc + ((size_t)frame * cap + out_idx[k]) * 32 + 8 * lane) = w;
         }
-        if (lane == 0 && !(dbg & 64)) {
+        if (lane == 0) {
             const int x = rec[k].x & 0xFFFF, y = rec[k].x >> 16;
             orbx_kp kp;
             float fx = (float)x, fy = (float)y;
@@ -1602,9 +1357,9 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
                              uint8_t *out_desc, int cap, int32_t *out_n, int n_frames)
 {
-    const int pf_o = (levels.kcap_total + 15) / 16, pf_d = (levels.kcap_total + 4 * DP_K - 1) / (4 * DP_K);
+    const int pf_o = (levels.kcap_total + OR_KP - 1) / OR_KP, pf_d = (levels.kcap_total + 4 * DP_K - 1) / (4 * DP_K);
     hipLaunchKernelGGL(k_orient, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, b,
                        u_max, pf_o, n_frames);
     hipLaunchKernelGGL(k_orient_desc, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, d_levels, b, out_kp,
-                       out_desc, cap, out_n, orbx_debug_flags, pf_d, n_frames);
+                       out_desc, cap, out_n, pf_d, n_frames);
 }
