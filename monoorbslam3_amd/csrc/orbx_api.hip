@@ -236,7 +236,9 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
                       g.node_fs > c->alloc_node_fs || g.l0_fs > c->alloc_l0_fs ||
                       g.levels.kcap_total > c->alloc_kcap_total;
     if (grow) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        // arenas are about to be replaced: nothing enqueued earlier (on the handle's streams or the caller's) may
+        // still be using them
+        HIP_TRY(hipDeviceSynchronize());
         const int B = std::max(batch, c->alloc_batch);
         const size_t img_fs = std::max(g.img_fs, c->alloc_img_fs), cand_fs = std::max(g.cand_fs, c->alloc_cand_fs);
         const size_t node_fs = std::max(g.node_fs, c->alloc_node_fs), l0_fs = std::max(g.l0_fs, c->alloc_l0_fs);
@@ -266,7 +268,7 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
         c->alloc_out_cap = 0; // host-API output staging is per (batch, cap)
     }
     if (out_cap > 0 && (out_cap > c->alloc_out_cap || grow)) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipDeviceSynchronize());
         const int cap = std::max(out_cap, c->alloc_out_cap);
         HIP_TRY(dev_alloc(&c->d_out_kp, (size_t)cap * c->alloc_batch));
         HIP_TRY(dev_alloc(&c->d_out_desc, (size_t)cap * 32 * c->alloc_batch));
@@ -274,7 +276,7 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
         c->alloc_out_cap = cap;
     }
     if (!same) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipDeviceSynchronize()); // the level / tap / cell tables below are read by in-flight kernels
         c->levels = g.levels;
         c->cur_w = w0; c->cur_h = h0;
         c->l0_stage_pitch = g.l0_pitch;

@@ -126,3 +126,57 @@ def test_odd_sizes_and_strides(oracle_mod):
         img = synth.make_frames(1, w, h, seed=w * 3 + h)[0]
         kps, desc = ex(img)
         _check_frame(ex, orc, img, kps, desc, stages=True)
+
+
+@pytest.mark.parametrize("nf,sf,levels,ini,mn", [(800, 1.5, 4, 30, 10), (1200, 1.1, 12, 12, 5), (600, 1.2, 8, 7, 20),
+                                                 (500, 1.2, 1, 20, 7)])
+def test_other_constructor_arguments(oracle_mod, nf, sf, levels, ini, mn):
+    """pyramid depth / scale / thresholds other than the yaml defaults (incl. min threshold above ini, one level)"""
+    w, h = 640, 360
+    ex, orc = _mk(oracle_mod, nf, w, h, ini=ini, mn=mn, n_levels=levels, sf=sf)
+    assert ex.features_per_level().tolist() == orc.quotas()
+    assert np.array_equal(ex.getScaleFactors(), orc.scale_factors())
+    img = synth.make_frames(1, w, h, seed=levels * 17 + ini)[0]
+    kps, desc = ex(img)
+    _check_frame(ex, orc, img, kps, desc, stages=True)
+
+
+def test_blur_tap_variant_and_handle_reuse(oracle_mod):
+    """the plain-rounded (sum 257) Gaussian tap set, and one handle used for several frame sizes in turn"""
+    from monoorbslam3_amd.extractor import ORBExtractor
+    ex = ORBExtractor(700, 1.2, 8, 20, 7, blur_variant=1)
+    orc = oracle_mod.Oracle(700, 1.2, 8, 20, 7, blur_variant=1)
+    for (w, h) in ((480, 270), (800, 300), (480, 270)):
+        img = synth.make_frames(1, w, h, seed=w)[0]
+        kps, desc = ex(img)
+        _check_frame(ex, orc, img, kps, desc, stages=True)
+
+
+def test_batch_device_pointers_and_determinism(oracle_mod):
+    """HBM-resident batch API (the bench path): two runs give identical bytes, and they match the oracle"""
+    import torch
+    from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
+    w, h, nf, B = 752, 480, 1000, 24
+    imgs = synth.make_frames(B, w, h, seed=31)
+    ex = ORBExtractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    cap = ex.max_keypoints(w, h)
+    d_img = torch.from_numpy(imgs).cuda()
+    outs = []
+    for _ in range(2):
+        d_kp = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+        ex.synchronize()
+        outs.append((d_n.cpu().numpy(), d_kp.cpu().numpy(), d_desc.cpu().numpy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    orc = oracle_mod.Oracle(nf, 1.2, 8, 20, 7)
+    n, kp, desc = outs[0]
+    for f in (0, 7, B - 1):
+        ok, od, _ = orc.extract(imgs[f])
+        assert n[f] == len(ok)
+        got = kp[f, :n[f]].copy().view(KP_DTYPE).reshape(-1)
+        for fld in ("x", "y", "angle", "response", "octave"):
+            assert np.array_equal(got[fld], ok[fld]), fld
+        assert np.array_equal(desc[f, :n[f]], od)
