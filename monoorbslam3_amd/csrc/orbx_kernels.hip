@@ -26,7 +26,7 @@ __device__ __forceinline__ bool xcd_remap(int per_frame, int n_frames, int *fram
 }
 static inline unsigned orbx_xcd_grid(int per_frame, int n_frames) { return 8u * (unsigned)((n_frames + 7) / 8) * (unsigned)per_frame; }
 
-__constant__ int8_t c_pattern[ORB_PATTERN_POINTS * 2] = {ORB_PATTERN_INT8_LIST};
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[ORB_PATTERN_POINTS * 2] = {ORB_PATTERN_INT8_LIST};
 
 // ---------------------------------------------------------------------------------------------
 // Pyramid: fixed-point bilinear (11-bit taps), 4 output pixels per thread
@@ -1273,6 +1273,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
         for (int l = 0; l < L; ++l) tot += cnts[l];
         out_n[frame] = tot;
     }
+    // this lane's four sampling pairs (the same for every keypoint); loaded first so that their latency
+    // overlaps the record / patch loads below
+    uint32_t pat[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pat[j] = reinterpret_cast<const uint32_t *>(c_pattern)[lane + 64 * j];
     bool live[DP_K];
     int level[DP_K], out_idx[DP_K];
     uint2 rec[DP_K];
@@ -1313,13 +1318,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
         }
     }
     __syncthreads();
-    // this lane's four sampling pairs (the same for every keypoint)
     float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int t = lane + 64 * j;
-        px0[j] = (float)c_pattern[4 * t]; py0[j] = (float)c_pattern[4 * t + 1];
-        px1[j] = (float)c_pattern[4 * t + 2]; py1[j] = (float)c_pattern[4 * t + 3];
+        px0[j] = (float)(int8_t)(pat[j] & 255); py0[j] = (float)(int8_t)((pat[j] >> 8) & 255);
+        px1[j] = (float)(int8_t)((pat[j] >> 16) & 255); py1[j] = (float)(int8_t)(pat[j] >> 24);
     }
 #pragma unroll
     for (int k = 0; k < DP_K; ++k) {
