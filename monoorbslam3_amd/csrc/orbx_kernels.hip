@@ -414,6 +414,12 @@ __device__ __forceinline__ void blur_strip(const uint8_t *__restrict__ S, int pi
                                            uint32_t K1, bool clamp16)
 {
     uint32_t hq[7][4];
+    // BORDER_REFLECT_101 column indices of the 12 bytes x-4 .. x+7: the same for every row
+    int cidx[12];
+    if (BORDER) {
+#pragma unroll
+        for (int b = 0; b < 12; ++b) cidx[b] = reflect101(x - 4 + b, w);
+    }
     auto load_row = [&](int rr, uint32_t o[4]) {
         const uint8_t *row = S + (size_t)reflect101(rr, h) * pitch;
         uint32_t d0, d1, d2;
@@ -421,13 +427,13 @@ __device__ __forceinline__ void blur_strip(const uint8_t *__restrict__ S, int pi
             d0 = reinterpret_cast<const UnalignedU32 *>(row + x - 4)->v;
             d1 = reinterpret_cast<const UnalignedU32 *>(row + x)->v;
             d2 = reinterpret_cast<const UnalignedU32 *>(row + x + 4)->v;
-        } else { // BORDER_REFLECT_101 on the columns
+        } else {
             d0 = d1 = d2 = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                d0 |= (uint32_t)row[reflect101(x - 4 + b, w)] << (8 * b);
-                d1 |= (uint32_t)row[reflect101(x + b, w)] << (8 * b);
-                d2 |= (uint32_t)row[reflect101(x + 4 + b, w)] << (8 * b);
+                d0 |= (uint32_t)row[cidx[b]] << (8 * b);
+                d1 |= (uint32_t)row[cidx[4 + b]] << (8 * b);
+                d2 |= (uint32_t)row[cidx[8 + b]] << (8 * b);
             }
         }
         blur_hrow(d0, d1, d2, K0, K1, o);
