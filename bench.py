@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="time extraction only")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo + --share-device rehearses the N>1 control flow on a 1-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank computes on cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,12 +94,18 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")  # gloo rehearsal: collectives on host copies
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from monoorbslam3_amd import synth
     from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
@@ -152,7 +161,10 @@ def main():
         if not args.no_match:
             match()
         if world > 1:
-            gather_records(d_n, d_kp, d_desc)
+            if args.backend == "nccl":
+                gather_records(d_n, d_kp, d_desc)
+            else:
+                gather_records(d_n.to(coll_dev), d_kp.to(coll_dev), d_desc.to(coll_dev))
 
     def sync():
         torch.cuda.synchronize()
@@ -169,7 +181,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fps = world * B * args.steps / dt

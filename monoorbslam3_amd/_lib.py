@@ -35,6 +35,12 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)" % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64; if liborbx.so (linked against /opt/rocm) is loaded first, the process
+    # ends up with two HIP runtimes and the second one sees no device.  Importing torch first makes both share one.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # a pure C/C++ consumer without torch is fine
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     sigs = {
