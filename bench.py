@@ -111,7 +111,7 @@ def main():
     from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
     from monoorbslam3_amd.matcher import MatcherHandle, _mlib
     from monoorbslam3_amd import _lib
-    from monoorbslam3_amd.dist import gather_records
+    from monoorbslam3_amd.dist import gather_records_to_root, pack_records
 
     W, H, B, NF = args.width, args.height, args.batch, args.features
     # ---- synthetic resident batch: a few dozen distinct frames, replicated with per-copy noise
@@ -127,44 +127,69 @@ def main():
         frames = (frames.to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8).contiguous()
     ex = ORBExtractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
     cap = ex.max_keypoints(W, H)
-    d_kp = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
-    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
-    d_bidx = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-    d_bd = torch.zeros((B, cap), dtype=torch.int16, device=dev)
-    d_sd = torch.zeros((B, cap), dtype=torch.int16, device=dev)
+    # two output sets: the best-2 match of batch k runs on its own stream while batch k+1 is being extracted
+    NBUF = 2
+    d_kp = [torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+    d_desc = [torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev) for _ in range(NBUF)]
+    d_n = [torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(NBUF)]
+    d_bidx = [torch.zeros((B, cap), dtype=torch.int32, device=dev) for _ in range(NBUF)]
+    d_bd = [torch.zeros((B, cap), dtype=torch.int16, device=dev) for _ in range(NBUF)]
+    d_sd = [torch.zeros((B, cap), dtype=torch.int16, device=dev) for _ in range(NBUF)]
     mh = MatcherHandle(device=local_rank)
     ML = _mlib()
-    # a dedicated non-default stream: the C ABI treats a NULL stream as "the handle's own stream", and the
-    # RCCL gather below must be ordered behind the extraction kernels on the same stream
+    # dedicated non-default streams: the C ABI treats a NULL stream as "the handle's own stream", and the RCCL
+    # gather below must be ordered behind the kernels it depends on
     torch.cuda.synchronize()
     side = torch.cuda.Stream(device=dev)
+    mstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(side)
     stream = side.cuda_stream
-    assert stream != 0
+    assert stream != 0 and mstream.cuda_stream != 0
+    ev_extracted = [torch.cuda.Event() for _ in range(NBUF)]
+    ev_matched = [torch.cuda.Event() for _ in range(NBUF)]
+    ev_gathered = [torch.cuda.Event() for _ in range(NBUF)]
+    step_no = [0]
+    # N > 1: one gather of the fixed-capacity records to rank 0 per step, on its own stream so that the xGMI
+    # transfer of batch k overlaps the extraction of batch k+1 (everything is drained before the clock stops)
+    cstream = torch.cuda.Stream(device=dev) if world > 1 else None
+    recv = None
+    if world > 1 and rank == 0:
+        nbytes = pack_records(d_n[0], d_kp[0], d_desc[0]).numel()
+        recv = [[torch.empty(nbytes, dtype=torch.uint8, device=coll_dev) for _ in range(world)] for _ in range(NBUF)]
 
-    def match():
+    def match(i, st):
         # frame f against frame f+1 (B-1 problems), and the last frame against frame 0
         if B > 1:
-            _lib.check(ML.orbm_best2_device(mh._h, B - 1, d_desc.data_ptr(), cap, d_n.data_ptr(), cap,
-                                            d_desc.data_ptr() + cap * 32, cap, d_n.data_ptr() + 4, cap, None, None,
-                                            d_bidx.data_ptr(), d_bd.data_ptr(), d_sd.data_ptr(), stream))
-        _lib.check(ML.orbm_best2_device(mh._h, 1, d_desc.data_ptr() + (B - 1) * cap * 32, cap,
-                                        d_n.data_ptr() + 4 * (B - 1), cap, d_desc.data_ptr(), cap, d_n.data_ptr(), cap,
-                                        None, None, d_bidx.data_ptr() + 4 * (B - 1) * cap,
-                                        d_bd.data_ptr() + 2 * (B - 1) * cap, d_sd.data_ptr() + 2 * (B - 1) * cap,
-                                        stream))
+            _lib.check(ML.orbm_best2_device(mh._h, B - 1, d_desc[i].data_ptr(), cap, d_n[i].data_ptr(), cap,
+                                            d_desc[i].data_ptr() + cap * 32, cap, d_n[i].data_ptr() + 4, cap, None, None,
+                                            d_bidx[i].data_ptr(), d_bd[i].data_ptr(), d_sd[i].data_ptr(), st))
+        _lib.check(ML.orbm_best2_device(mh._h, 1, d_desc[i].data_ptr() + (B - 1) * cap * 32, cap,
+                                        d_n[i].data_ptr() + 4 * (B - 1), cap, d_desc[i].data_ptr(), cap, d_n[i].data_ptr(),
+                                        cap, None, None, d_bidx[i].data_ptr() + 4 * (B - 1) * cap,
+                                        d_bd[i].data_ptr() + 2 * (B - 1) * cap, d_sd[i].data_ptr() + 2 * (B - 1) * cap, st))
 
     def step():
-        ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, d_kp.data_ptr(), d_desc.data_ptr(), cap,
-                                d_n.data_ptr(), stream)
-        if not args.no_match:
-            match()
+        i = step_no[0] % NBUF
+        step_no[0] += 1
+        side.wait_event(ev_matched[i])          # buffer set i is free once its previous match ...
         if world > 1:
-            if args.backend == "nccl":
-                gather_records(d_n, d_kp, d_desc)
-            else:
-                gather_records(d_n.to(coll_dev), d_kp.to(coll_dev), d_desc.to(coll_dev))
+            side.wait_event(ev_gathered[i])     # ... and its previous gather have finished
+        ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, d_kp[i].data_ptr(), d_desc[i].data_ptr(), cap,
+                                d_n[i].data_ptr(), stream)
+        ev_extracted[i].record(side)
+        if not args.no_match:
+            mstream.wait_event(ev_extracted[i])
+            match(i, mstream.cuda_stream)
+        ev_matched[i].record(mstream)
+        if world > 1:
+            cstream.wait_event(ev_extracted[i])
+            with torch.cuda.stream(cstream):
+                if args.backend == "nccl":
+                    gather_records_to_root(d_n[i], d_kp[i], d_desc[i], recv[i] if rank == 0 else None)
+                else:  # rehearsal on a 1-GPU box: host copies through gloo
+                    gather_records_to_root(d_n[i].to(coll_dev), d_kp[i].to(coll_dev), d_desc[i].to(coll_dev),
+                                           recv[i] if rank == 0 else None)
+                ev_gathered[i].record(cstream)
 
     def sync():
         torch.cuda.synchronize()
@@ -193,17 +218,17 @@ def main():
     ev_m0, ev_m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     match_ms = 0.0
     for _ in range(n_prof):
-        ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, d_kp.data_ptr(), d_desc.data_ptr(), cap,
-                                d_n.data_ptr(), stream)
+        ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, d_kp[0].data_ptr(), d_desc[0].data_ptr(), cap,
+                                d_n[0].data_ptr(), stream)
         for k, v in ex.stage_times_ms().items():
             acc[k] = acc.get(k, 0.0) + v / n_prof
         ev_m0.record()
-        match()
+        match(0, stream)
         ev_m1.record()
         torch.cuda.synchronize()
         match_ms += ev_m0.elapsed_time(ev_m1) / n_prof
     ex.set_stage_timing(False)
-    counts = d_n.cpu().numpy()
+    counts = d_n[0].cpu().numpy()
     kp_mean = float(counts.mean())
     alg, P = algorithmic_bytes(ex, W, H, int(round(kp_mean)))
     stage_gbs = {k: (alg[k] * B / (acc[k] * 1e-3) / 1e9 if acc[k] > 0 and alg[k] > 0 else None) for k in acc}
@@ -243,7 +268,7 @@ def main():
                                "2000x2000 Hamming best-2 per frame" if (W, H, NF) == (1242, 375, 2000) else
                                "%dx%d, %d feat" % (W, H, NF),
                    "frames_per_gpu_per_step": B, "width": W, "height": H, "n_features": NF,
-                   "match": not args.no_match, "parallelism": "frames sharded 1 batch/GPU, all-gather of records"},
+                   "match": not args.no_match, "parallelism": "frames sharded 1 batch/GPU, one gather of records to rank 0 per step"},
         "keypoints_per_frame": round(kp_mean, 1),
         "stages_ms": {k: round(v, 4) for k, v in acc.items()},
         "match_ms": round(match_ms, 4),

@@ -48,6 +48,35 @@ def gather_records(counts, kps, desc, group=None):
     return g_counts, g_kps, g_desc
 
 
+def pack_records(counts, kps, desc):
+    """One contiguous uint8 payload per rank: counts | keypoints | descriptors (fixed capacity)."""
+    assert kps.dtype == torch.uint8 and desc.dtype == torch.uint8 and counts.dtype == torch.int32
+    return torch.cat([counts.view(torch.uint8).reshape(-1), kps.reshape(-1), desc.reshape(-1)])
+
+
+def unpack_records(payload, b, cap):
+    n0 = b * 4
+    n1 = n0 + b * cap * KP_BYTES
+    return (payload[:n0].contiguous().view(torch.int32), payload[n0:n1].reshape(b, cap, KP_BYTES),
+            payload[n1:].reshape(b, cap, DESC_BYTES))
+
+
+def gather_records_to_root(counts, kps, desc, recv=None, dst=0, group=None):
+    """The batch-of-frames exchange: ONE gather of every rank's fixed-capacity records to `dst`
+    (RCCL: grouped send/recv, each peer over its own xGMI link; no ring, no reduction).
+    `recv` (root only) is an optional preallocated list of world payload tensors.  Returns the list on the
+    root, None elsewhere."""
+    world = dist.get_world_size(group)
+    payload = pack_records(counts, kps, desc)
+    if dist.get_rank(group) == dst:
+        if recv is None:
+            recv = [torch.empty_like(payload) for _ in range(world)]
+        dist.gather(payload, gather_list=recv, dst=dst, group=group)
+        return recv
+    dist.gather(payload, gather_list=None, dst=dst, group=group)
+    return None
+
+
 def extract_sharded(frames, extract_fn, cap, group=None, device="cpu"):
     """Shard a global batch, run `extract_fn` on the local frames, gather everything everywhere.
 

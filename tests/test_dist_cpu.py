@@ -40,6 +40,44 @@ def _worker(rank, world, port, n_frames, q):
     dist.destroy_process_group()
 
 
+def _worker_root(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.RandomState(100 + rank)
+    frames = rng.randint(0, 256, (3, 4, 6)).astype(np.uint8)
+    counts, kps, desc = _fake_extract(frames)
+    got = D.gather_records_to_root(counts, kps, desc, dst=0)
+    if rank == 0:
+        out = []
+        for r in range(world):
+            c, k, d = D.unpack_records(got[r], 3, CAP)
+            out.append((c.numpy().tobytes(), k.numpy().tobytes(), d.numpy().tobytes()))
+        q.put(out)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_to_root_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_root, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        rng = np.random.RandomState(100 + r)
+        frames = rng.randint(0, 256, (3, 4, 6)).astype(np.uint8)
+        c, k, d = _fake_extract(frames)
+        assert got[r] == (c.numpy().tobytes(), k.numpy().tobytes(), d.numpy().tobytes())
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
