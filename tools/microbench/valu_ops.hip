@@ -45,6 +45,28 @@
 #define A_CVTI(i) "v_cvt_i32_f32 %" #i ", %" #i "\n"
 #define A_RNDNE(i) "v_rndne_f32 %" #i ", %" #i "\n"
 
+#define A_MAXF(i) "v_max_f32 %" #i ", %" #i ", %8\n"
+#define A_SUBF(i) "v_sub_f32 %" #i ", %" #i ", %8\n"
+#define A_MIN3F(i) "v_min3_f32 %" #i ", %" #i ", %8, %9\n"
+#define A_MED3F(i) "v_med3_f32 %" #i ", %" #i ", %8, %9\n"
+#define A_CVTUB(i) "v_cvt_f32_ubyte1 %" #i ", %" #i "\n"
+#define A_CVTFU(i) "v_cvt_f32_u32 %" #i ", %" #i "\n"
+#define A_MULF(i) "v_mul_f32 %" #i ", %" #i ", %8\n"
+#define A_MAXI(i) "v_max_i32 %" #i ", %" #i ", %8\n"
+#define A_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n"
+#define A_LSHR(i) "v_lshrrev_b32 %" #i ", 3, %" #i "\n"
+#define A_SUBI(i) "v_sub_u32 %" #i ", %" #i ", %8\n"
+KERNEL(max_f32, A_MAXF)
+KERNEL(sub_f32, A_SUBF)
+KERNEL(min3_f32, A_MIN3F)
+KERNEL(med3_f32, A_MED3F)
+KERNEL(cvt_f32_ubyte1, A_CVTUB)
+KERNEL(cvt_f32_u32, A_CVTFU)
+KERNEL(mul_f32, A_MULF)
+KERNEL(max_i32, A_MAXI)
+KERNEL(and_b32, A_AND)
+KERNEL(lshrrev, A_LSHR)
+KERNEL(sub_u32, A_SUBI)
 KERNEL(xor, A_XOR)
 KERNEL(add, A_ADD)
 KERNEL(bcnt, A_BCNT)
@@ -98,5 +120,8 @@ int main()
     run("v_pk_sub_i16", k_pk_sub_i16); run("v_pk_max_i16", k_pk_max_i16); run("v_pk_min_u16", k_pk_min_u16);
     run("v_cndmask_b32", k_cndmask); run("v_fma_f32", k_fma_f32); run("v_bfe_u32", k_bfe); run("v_add3_u32", k_add3);
     run("v_cvt_i32_f32", k_cvt_i32_f32); run("v_rndne_f32", k_rndne);
+    run("v_max_f32", k_max_f32); run("v_sub_f32", k_sub_f32); run("v_min3_f32", k_min3_f32); run("v_med3_f32", k_med3_f32);
+    run("v_cvt_f32_ubyte1", k_cvt_f32_ubyte1); run("v_cvt_f32_u32", k_cvt_f32_u32); run("v_mul_f32", k_mul_f32);
+    run("v_max_i32", k_max_i32); run("v_and_b32", k_and_b32); run("v_lshrrev_b32", k_lshrrev); run("v_sub_u32", k_sub_u32);
     return 0;
 }
