@@ -581,6 +581,86 @@ def test_features_in_area(O):
         assert sorted(got.tolist()) == ref
 
 
+def test_search_by_projection_models(O):
+    """window searches (ORBMatcher.cpp:203-415) against literal Python loops over features_in_area"""
+    rng = np.random.RandomState(12)
+    n1, n2, w, h = 300, 400, 640, 480
+    k2 = np.zeros(n2, O.KP_DTYPE)
+    k2["x"] = rng.uniform(0, w, n2).astype(np.float32)
+    k2["y"] = rng.uniform(0, h, n2).astype(np.float32)
+    k2["octave"] = rng.randint(0, 8, n2)
+    k2["angle"] = rng.uniform(0, 360, n2).astype(np.float32)
+    d2 = rng.randint(0, 256, (n2, 32)).astype(np.uint8)
+    src = rng.randint(0, n2, n1)
+    flips = np.packbits(rng.uniform(size=(n1, 256)) < 0.08, axis=1, bitorder="little")
+    d1 = d2[src] ^ flips
+    q_xy = np.stack([k2["x"][src] + rng.normal(0, 2, n1), k2["y"][src] + rng.normal(0, 2, n1)], 1).astype(np.float32)
+    q_lvl = np.clip(k2["octave"][src] + rng.randint(-1, 2, n1), 0, 7).astype(np.int32)
+    q_ang = rng.uniform(0, 360, n1).astype(np.float32)
+    q_ok = (rng.uniform(size=n1) > 0.2).astype(np.uint8)
+    q_r = (6.0 * 1.2 ** q_lvl).astype(np.float32)
+    mp0 = np.where(rng.uniform(size=n2) > 0.9, 5555, -1).astype(np.int32)
+
+    # frame -> frame
+    for ori in (False, True):
+        n_got, mp_got = O.search_by_projection_frame(ori, d1, q_xy, q_r, q_lvl, q_ang, q_ok, k2, d2, w, h, mp0)
+        mp = mp0.copy()
+        num, hist = 0, [[] for _ in range(30)]
+        for i in range(n1):
+            if not q_ok[i]:
+                continue
+            cand = O.features_in_area(k2, w, h, float(q_xy[i, 0]), float(q_xy[i, 1]), float(q_r[i]), int(q_lvl[i]) - 1, int(q_lvl[i]) + 1)
+            best, bi = 101, -1
+            for j in cand:
+                if mp[j] != -1:
+                    continue
+                dd = _ham(d1[i], d2[j])
+                if dd < best:
+                    best, bi = dd, j
+            if best <= 100:
+                mp[bi] = i
+                num += 1
+                if ori:
+                    hist[_rot_bin(q_ang[i], k2["angle"][bi])].append(bi)
+        if ori:
+            i1, i2, i3 = O.three_maxima([len(x) for x in hist])
+            for b in range(30):
+                if b not in (i1, i2, i3):
+                    for j in hist[b]:
+                        mp[j] = -1
+                        num -= 1
+        assert n_got == num and np.array_equal(mp_got, mp) and num > 50
+
+    # points -> frame
+    n_got, mp_got, cnt = O.search_by_projection_points(0.8, d1, q_xy, q_r, q_lvl, q_ok, k2, d2, w, h, mp0)
+    mp = mp0.copy()
+    num = f1 = f2 = 0
+    for i in range(n1):
+        if not q_ok[i]:
+            continue
+        cand = O.features_in_area(k2, w, h, float(q_xy[i, 0]), float(q_xy[i, 1]), float(q_r[i]), int(q_lvl[i]) - 1, int(q_lvl[i]))
+        if len(cand) == 0:
+            continue
+        best, bl, second, sl, bi = 256, -1, 257, -1, -1
+        for j in cand:
+            if mp[j] != -1:
+                continue
+            dd = _ham(d1[i], d2[j])
+            if dd < best:
+                second, best, sl, bl, bi = best, dd, bl, int(k2["octave"][j]), j
+            elif dd < second:
+                second, sl = dd, int(k2["octave"][j])
+        if best <= 100:
+            if bl == sl and np.float32(best) > np.float32(0.8) * np.float32(second):
+                f1 += 1
+                continue
+            mp[bi] = i
+            num += 1
+        else:
+            f2 += 1
+    assert n_got == num and np.array_equal(mp_got, mp) and cnt == (int((q_ok == 0).sum()), f1, f2) and num > 50
+
+
 # ---------------------------------------------------------------- committed golden fixtures
 def test_golden_extract_fixture(O):
     """oracle output on a committed small frame (fixture generated by tools/gen_golden.py FROM THE ORACLE;
