@@ -223,9 +223,10 @@ struct DevBuf {
     hipError_t need(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
+        const size_t old_cap = cap;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
-        const size_t want = std::max(bytes, (size_t)4096);
+        const size_t want = std::max(std::max(bytes, (size_t)4096), 2 * old_cap); // geometric growth: hipFree is costly
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;
