@@ -214,6 +214,50 @@ __global__ __launch_bounds__(256) void k_hamming_lists(const uint8_t *__restrict
     for (int t = lane; t < n; t += 64) out[ob + t] = (uint16_t)ham256(da, load_desc(b + (size_t)c_idx[cb + t] * 32));
 }
 
+// The K smallest (distance << 16 | position-in-list) keys of every query's candidate list, one wave per query.
+// Candidates whose byte in `cand_free` is 0 are not considered.  Lists longer than 65535 are not supported here
+// (the caller falls back to the full distance lists).  Missing entries are 0xFFFFFFFF.
+#define TOPK 4
+__global__ __launch_bounds__(256) void k_topk_lists(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                                                    const int32_t *__restrict__ q_idx,
+                                                    const int32_t *__restrict__ c_begin,
+                                                    const int32_t *__restrict__ c_len, int n_queries,
+                                                    const int32_t *__restrict__ c_idx,
+                                                    const uint8_t *__restrict__ cand_free, uint32_t *__restrict__ out)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= n_queries) return;
+    const Desc256 da = load_desc(a + (size_t)q_idx[q] * 32);
+    const int cb = c_begin[q], n = c_len[q];
+    uint32_t k[TOPK];
+#pragma unroll
+    for (int i = 0; i < TOPK; ++i) k[i] = 0xFFFFFFFFu;
+    for (int t = lane; t < n; t += 64) {
+        const int j = c_idx[cb + t];
+        if (cand_free && !cand_free[j]) continue;
+        uint32_t v = ((uint32_t)ham256(da, load_desc(b + (size_t)j * 32)) << 16) | (uint32_t)t;
+#pragma unroll
+        for (int i = 0; i < TOPK; ++i) { // sorted insertion
+            const uint32_t lo = min(k[i], v);
+            v = max(k[i], v);
+            k[i] = lo;
+        }
+    }
+    // wave merge: TOPK rounds of "global minimum, owner pops its head"
+#pragma unroll
+    for (int r = 0; r < TOPK; ++r) {
+        uint32_t m = k[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+        if (lane == 0) out[(size_t)q * TOPK + r] = m;
+        if (k[0] == m && m != 0xFFFFFFFFu) { // keys are unique (position), so exactly one lane owns the minimum
+#pragma unroll
+            for (int i = 0; i + 1 < TOPK; ++i) k[i] = k[i + 1];
+            k[TOPK - 1] = 0xFFFFFFFFu;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------
@@ -384,6 +428,57 @@ static int hamming_lists(orbm_ctx *c, const uint8_t *a, int na, const uint8_t *b
     return ORBX_OK;
 }
 
+// top-K keys per query (see k_topk_lists); `cand_free` has nb bytes (1 = candidate may be used), may be NULL
+static int topk_lists(orbm_ctx *c, const uint8_t *a, int na, const uint8_t *b, int nb, const std::vector<int32_t> &q_idx,
+                      const std::vector<int32_t> &c_begin, const std::vector<int32_t> &c_len, const int32_t *c_idx,
+                      size_t n_cidx, const uint8_t *cand_free, std::vector<uint32_t> &out)
+{
+    const int nq = (int)q_idx.size();
+    out.assign((size_t)nq * TOPK, 0xFFFFFFFFu);
+    if (nq == 0 || n_cidx == 0) return ORBX_OK;
+    M_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    M_TRY(c->a.need((size_t)na * 32));
+    M_TRY(c->b.need((size_t)nb * 32));
+    M_TRY(c->q_idx.need((size_t)nq * 4));
+    M_TRY(c->c_begin.need((size_t)nq * 4));
+    M_TRY(c->c_len.need((size_t)nq * 4));
+    M_TRY(c->c_idx.need(n_cidx * 4));
+    M_TRY(c->out.need((size_t)nq * TOPK * 4));
+    M_TRY(hipMemcpyAsync(c->a.p, a, (size_t)na * 32, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->b.p, b, (size_t)nb * 32, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->q_idx.p, q_idx.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->c_begin.p, c_begin.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->c_len.p, c_len.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->c_idx.p, c_idx, n_cidx * 4, hipMemcpyHostToDevice, s));
+    const uint8_t *d_free = nullptr;
+    if (cand_free) {
+        M_TRY(c->col_ok.need((size_t)nb));
+        M_TRY(hipMemcpyAsync(c->col_ok.p, cand_free, (size_t)nb, hipMemcpyHostToDevice, s));
+        d_free = (const uint8_t *)c->col_ok.p;
+    }
+    hipLaunchKernelGGL(k_topk_lists, dim3((nq + 3) / 4), dim3(256), 0, s, (const uint8_t *)c->a.p, (const uint8_t *)c->b.p,
+                       (const int32_t *)c->q_idx.p, (const int32_t *)c->c_begin.p, (const int32_t *)c->c_len.p, nq,
+                       (const int32_t *)c->c_idx.p, d_free, (uint32_t *)c->out.p);
+    M_TRY(hipGetLastError());
+    M_TRY(hipMemcpyAsync(out.data(), c->out.p, (size_t)nq * TOPK * 4, hipMemcpyDeviceToHost, s));
+    M_TRY(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+// 256-bit Hamming distance on the host: only for the rare rows whose device top-K was used up by earlier matches
+static inline int ham256_host(const uint8_t *x, const uint8_t *y)
+{
+    int d = 0;
+    for (int i = 0; i < 4; ++i) {
+        unsigned long long u, v;
+        memcpy(&u, x + 8 * i, 8);
+        memcpy(&v, y + 8 * i, 8);
+        d += __builtin_popcountll(u ^ v);
+    }
+    return d;
+}
+
 extern "C" int orbm_hamming_csr(orbm_t *c, const uint8_t *a, int na, const uint8_t *b, int nb, const int32_t *q_idx,
                                 const int32_t *off, int n_queries, const int32_t *c_idx, uint16_t *out)
 {
@@ -487,24 +582,56 @@ extern "C" int orbm_search_by_bow(orbm_t *c, float nn_ratio, int check_orientati
     shared_nodes(fv1, fv2, nodes);
     NodeQueries q;
     build_node_queries(fv1, fv2, nodes, kf_mp_ok, nullptr, q);
+    // The device returns, per key-frame feature, the TOPK closest candidates of its node among the frame features
+    // that are free when the call starts.  The reference's sequential loop only ever needs the two closest
+    // candidates that are STILL free (:150-161); they are the first two unmatched entries of that sorted list.
+    // Only if earlier matches of this call used up the list is the row recomputed on the host.
+    bool long_list = false;
+    for (int len : q.c_len) long_list = long_list || len > 65535;
+    std::vector<uint8_t> free0((size_t)n2);
+    for (int j = 0; j < n2; ++j) free0[j] = frame_mp[j] == -1;
+    std::vector<uint32_t> topk;
     std::vector<uint16_t> dist;
-    int rc = hamming_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.out_begin,
-                           reinterpret_cast<const int32_t *>(fv2->indices), (size_t)fv2->offsets[fv2->n_nodes], q.n_out,
-                           dist);
+    int rc;
+    if (!long_list)
+        rc = topk_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, reinterpret_cast<const int32_t *>(fv2->indices),
+                        (size_t)fv2->offsets[fv2->n_nodes], free0.data(), topk);
+    else
+        rc = hamming_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.out_begin,
+                           reinterpret_cast<const int32_t *>(fv2->indices), (size_t)fv2->offsets[fv2->n_nodes], q.n_out, dist);
     if (rc) return rc;
     RotHist rh;
     int num = 0;
     for (size_t k = 0; k < q.q_idx.size(); ++k) {
         const int idx1 = q.q_idx[k];
         const uint32_t *cand = fv2->indices + q.c_begin[k];
-        const uint16_t *d = dist.data() + q.out_begin[k];
         int bestDist = 256, secondDist = 256, bestIdx2 = -1;
-        for (int t = 0; t < q.c_len[k]; ++t) {
-            const int idx2 = (int)cand[t];
-            if (frame_mp[idx2] != -1) continue; // :150 -- includes features matched earlier in this call
-            const int dd = d[t];
-            if (dd < bestDist) { secondDist = bestDist; bestDist = dd; bestIdx2 = idx2; }
-            else if (dd < secondDist) secondDist = dd;
+        bool resolved = false;
+        if (!long_list) {
+            int found = 0;
+            bool exhausted = false; // saw the end-of-list sentinel: no further free candidate exists
+            for (int r = 0; r < TOPK && found < 2; ++r) {
+                const uint32_t key = topk[k * TOPK + r];
+                if (key == 0xFFFFFFFFu) { exhausted = true; break; }
+                const int idx2 = (int)cand[key & 0xFFFF], dd = (int)(key >> 16);
+                if (frame_mp[idx2] != -1) continue; // taken by an earlier match of this call (:150)
+                if (found == 0) { if (dd < 256) { bestDist = dd; bestIdx2 = idx2; } }
+                else secondDist = std::min(dd, 256);
+                ++found;
+            }
+            // decided if both were seen, if the list ended, or if the best already fails the threshold (:164)
+            resolved = found == 2 || exhausted || (found == 1 && bestDist > ORBM_TH_LOW);
+        }
+        if (!resolved) {
+            bestDist = 256; secondDist = 256; bestIdx2 = -1;
+            for (int t = 0; t < q.c_len[k]; ++t) {
+                const int idx2 = (int)cand[t];
+                if (frame_mp[idx2] != -1) continue; // :150 -- includes features matched earlier in this call
+                const int dd = long_list ? (int)dist[q.out_begin[k] + t]
+                                         : ham256_host(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                if (dd < bestDist) { secondDist = bestDist; bestDist = dd; bestIdx2 = idx2; }
+                else if (dd < secondDist) secondDist = dd;
+            }
         }
         if (bestDist <= ORBM_TH_LOW && (float)bestDist < nn_ratio * (float)secondDist) { // :164
             frame_mp[bestIdx2] = idx1;
@@ -538,10 +665,21 @@ extern "C" int orbm_search_for_triangulation(orbm_t *c, int check_orientation, c
     shared_nodes(fv1, fv2, nodes);
     NodeQueries q;
     build_node_queries(fv1, fv2, nodes, nullptr, has_mp1, q); // :452
+    // Same scheme as orbm_search_by_bow: the device returns the TOPK closest initially-eligible candidates per feature,
+    // the sequential pass takes the first one not matched earlier in this call (:466-:476 keeps only the best).
+    bool long_list = false;
+    for (int len : q.c_len) long_list = long_list || len > 65535;
+    std::vector<uint8_t> free0((size_t)n2);
+    for (int j = 0; j < n2; ++j) free0[j] = !has_mp2[j];
+    std::vector<uint32_t> topk;
     std::vector<uint16_t> dist;
-    int rc = hamming_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.out_begin,
-                           reinterpret_cast<const int32_t *>(fv2->indices), (size_t)fv2->offsets[fv2->n_nodes], q.n_out,
-                           dist);
+    int rc;
+    if (!long_list)
+        rc = topk_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, reinterpret_cast<const int32_t *>(fv2->indices),
+                        (size_t)fv2->offsets[fv2->n_nodes], free0.data(), topk);
+    else
+        rc = hamming_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.out_begin,
+                           reinterpret_cast<const int32_t *>(fv2->indices), (size_t)fv2->offsets[fv2->n_nodes], q.n_out, dist);
     if (rc) return rc;
     std::vector<uint8_t> matched2(n2, 0);
     RotHist rh;
@@ -549,12 +687,27 @@ extern "C" int orbm_search_for_triangulation(orbm_t *c, int check_orientation, c
     for (size_t k = 0; k < q.q_idx.size(); ++k) {
         const int idx1 = q.q_idx[k];
         const uint32_t *cand = fv2->indices + q.c_begin[k];
-        const uint16_t *d = dist.data() + q.out_begin[k];
         int bestDist = ORBM_TH_LOW, bestIdx2 = -1;
-        for (int t = 0; t < q.c_len[k]; ++t) {
-            const int idx2 = (int)cand[t];
-            if (matched2[idx2] || has_mp2[idx2]) continue; // :466
-            if (d[t] < bestDist) { bestIdx2 = idx2; bestDist = d[t]; }
+        bool resolved = false;
+        if (!long_list) {
+            for (int r = 0; r < TOPK; ++r) {
+                const uint32_t key = topk[k * TOPK + r];
+                if (key == 0xFFFFFFFFu) { resolved = true; break; }
+                const int idx2 = (int)cand[key & 0xFFFF], dd = (int)(key >> 16);
+                if (matched2[idx2]) continue; // :466 -- matched earlier in this call
+                if (dd < bestDist) { bestIdx2 = idx2; bestDist = dd; }
+                resolved = true;
+                break;
+            }
+        }
+        if (!resolved) {
+            for (int t = 0; t < q.c_len[k]; ++t) {
+                const int idx2 = (int)cand[t];
+                if (matched2[idx2] || has_mp2[idx2]) continue; // :466
+                const int dd = long_list ? (int)dist[q.out_begin[k] + t]
+                                         : ham256_host(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                if (dd < bestDist) { bestIdx2 = idx2; bestDist = dd; }
+            }
         }
         if (bestIdx2 > 0) { // :484 -- feature 0 of key frame 2 is never accepted
             matches12[idx1] = bestIdx2;

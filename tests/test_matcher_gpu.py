@@ -124,6 +124,59 @@ def test_search_for_triangulation(oracle_mod, bits, check_ori):
     assert (m_got == 0).sum() == 0  # reference quirk: index 0 is never matched (ORBMatcher.cpp:484)
 
 
+def _clustered_pair(seed, n_centres=40, per_a=15, per_b=6, flip=3):
+    """Many near-duplicate descriptors: several key-frame features compete for the same few frame features, so the
+    sequential 'already matched' rule (ORBMatcher.cpp:150 / :466) decides most rows and the device top-K runs dry."""
+    rng = np.random.RandomState(seed)
+    cen = rng.randint(0, 256, size=(n_centres, 32)).astype(np.uint8)
+
+    def copies(k):
+        out = np.repeat(cen, k, axis=0)
+        for row in out:
+            for bit in rng.choice(256, size=rng.randint(0, flip + 1), replace=False):
+                row[bit >> 3] ^= 1 << (bit & 7)
+        return out[rng.permutation(len(out))]
+
+    return np.ascontiguousarray(copies(per_a)), np.ascontiguousarray(copies(per_b))
+
+
+@pytest.mark.parametrize("bits", [0, 2])
+@pytest.mark.parametrize("check_ori", [False, True])
+def test_search_by_bow_collisions(oracle_mod, bits, check_ori):
+    from monoorbslam3_amd.matcher import ORBMatcher
+    a, b = _clustered_pair(31 + bits)
+    rng = np.random.RandomState(5)
+    ang1 = rng.uniform(0, 360, len(a)).astype(np.float32)
+    ang2 = rng.uniform(0, 360, len(b)).astype(np.float32)
+    ok = np.ones(len(a), np.uint8)
+    mp0 = np.where(rng.uniform(size=len(b)) > 0.9, 3, -1).astype(np.int32)
+    fv1 = synth.feature_vector_by_prefix(a, bits)
+    fv2 = synth.feature_vector_by_prefix(b, bits)
+    m = ORBMatcher(0.99, check_ori)
+    n_got, mp_got = m.SearchByBow(a, ang1, ok, fv1, b, ang2, mp0, fv2)
+    n_ref, mp_ref = oracle_mod.search_by_bow(0.99, check_ori, a, ang1, ok, fv1, b, ang2, mp0, fv2)
+    assert n_got == n_ref and np.array_equal(mp_got, mp_ref)
+    assert n_got > 10
+
+
+@pytest.mark.parametrize("bits", [0, 2])
+def test_search_for_triangulation_collisions(oracle_mod, bits):
+    from monoorbslam3_amd.matcher import ORBMatcher
+    a, b = _clustered_pair(77 + bits)
+    rng = np.random.RandomState(6)
+    ang1 = rng.uniform(0, 360, len(a)).astype(np.float32)
+    ang2 = rng.uniform(0, 360, len(b)).astype(np.float32)
+    h1 = np.zeros(len(a), np.uint8)
+    h2 = (rng.uniform(size=len(b)) > 0.85).astype(np.uint8)
+    fv1 = synth.feature_vector_by_prefix(a, bits)
+    fv2 = synth.feature_vector_by_prefix(b, bits)
+    m = ORBMatcher(0.6, False)
+    n_got, m_got = m.SearchForTriangulation(a, ang1, h1, fv1, b, ang2, h2, fv2)
+    n_ref, m_ref = oracle_mod.search_for_triangulation(False, a, ang1, h1, fv1, b, ang2, h2, fv2)
+    assert n_got == n_ref and np.array_equal(m_got, m_ref)
+    assert n_got > 100  # every frame feature without a map point ends up taken
+
+
 def test_search_for_initialization_on_extracted_frames(oracle_mod):
     """two shifted views of one scene through the GPU extractor, then the initialisation matcher"""
     from monoorbslam3_amd.extractor import ORBExtractor
