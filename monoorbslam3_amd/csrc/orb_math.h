@@ -26,6 +26,7 @@
 #define ORB_DMUL(a, b) __dmul_rn((a), (b))
 #define ORB_DADD(a, b) __dadd_rn((a), (b))
 #define ORB_DSUB(a, b) __dsub_rn((a), (b))
+#define ORB_DDIV(a, b) __ddiv_rn((a), (b))
 #else
 #define ORB_FMUL(a, b) ((a) * (b))
 #define ORB_FADD(a, b) ((a) + (b))
@@ -34,6 +35,7 @@
 #define ORB_DMUL(a, b) ((a) * (b))
 #define ORB_DADD(a, b) ((a) + (b))
 #define ORB_DSUB(a, b) ((a) - (b))
+#define ORB_DDIV(a, b) ((a) / (b))
 #endif
 
 // cvRound(float): round half to even (SSE cvtss2si under the default MXCSR)

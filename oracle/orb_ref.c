@@ -906,6 +906,40 @@ int orbref_search_for_triangulation(int check_orientation,
     return numMatch;
 }
 
+/* ---- Frame post-processing: Frame.cpp:24-28, Pinhole.cpp:55-83, Fisheye.cpp:110-117 ---- */
+void orbref_undistort_point(const orbref_camera *cam, float u_f, float v_f, float *xu, float *yu)
+{
+    double k[12] = {0};
+    for (int i = 0; i < cam->n_dist && i < 12; ++i) k[i] = (double)cam->dist[i];
+    const double fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy, ifx = 1. / fx, ify = 1. / fy;
+    const double u = u_f, v = v_f;
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    /* RR = P(:, 0:3) * I with P = K: the zero entries of K still take part in the sums */
+    const double xx = fx * x + 0. * y + cx, yy = 0. * x + fy * y + cy, ww = 1. / (0. * x + 0. * y + 1.);
+    *xu = (float)(xx * ww);
+    *yu = (float)(yy * ww);
+}
+
+void orbref_frame_post(const orbref_camera *cam, orbref_kp *raw, int n, orbref_kp *un)
+{
+    for (int i = 0; i < n; ++i) {
+        if (cam->size_scale) raw[i].size *= cam->size_scale[(size_t)(int)raw[i].y * cam->width + (int)raw[i].x];
+        un[i] = raw[i];
+        if (cam->undistort && cam->n_dist > 0 && cam->dist[0] != 0.f)
+            orbref_undistort_point(cam, raw[i].x, raw[i].y, &un[i].x, &un[i].y);
+    }
+}
+
 /* ---- Frame grid: modules/BasicObject/Frame.cpp:33-51, :90-127 (GRID_SIZE 40) ---- */
 #define GRID_SIZE 40
 orbref_grid *orbref_grid_build(const orbref_kp *kps, int n, int img_w, int img_h)

@@ -140,6 +140,25 @@ void orbref_grid_free(orbref_grid *g);
 int orbref_features_in_area(const orbref_grid *g, const orbref_kp *kps, float x, float y, float r,
                             int min_level, int max_level, int32_t *out, int cap);
 
+/* ---- Frame post-processing: modules/BasicObject/Frame.cpp:24-28 ---------------------------------------------------
+ * kp.size *= camera->uncertainty(kp.pt) (Pinhole.cpp:55-57: 1; Fisheye.cpp:110-112: scale_mat(y,x) with the float
+ * coordinates truncated by the implicit int conversion), then camera->undistortKeyPoints (Pinhole.cpp:59-83:
+ * copy when dist[0] == 0, else cv::undistortPoints(pts, K, dist, R = I, P = K); Fisheye.cpp:114-117: copy).
+ * cv::undistortPoints is OpenCV's (calib3d/undistort.dispatch.cpp, 4.2): double arithmetic, FIVE fixed-point
+ * iterations (TermCriteria(MAX_ITER, 5, 0.01) -- only the count is used), early exit when icdist < 0, result
+ * cast to float.  Restated from the published algorithm; unpinned against OpenCV like the rest of this file. */
+typedef struct orbref_camera {
+    int32_t width, height;
+    float fx, fy, cx, cy;
+    int32_t n_dist;    /* 0..12 coefficients in OpenCV order k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4 */
+    float dist[12];
+    int32_t undistort; /* 1 = Pinhole (RAD_TAN), 0 = Fisheye (key points are copied) */
+    const float *size_scale; /* NULL, or height*width floats (Fisheye::scale_mat) */
+} orbref_camera;
+void orbref_undistort_point(const orbref_camera *cam, float u, float v, float *xu, float *yu);
+/* raw (in/out: size scaled), un (out: copy of raw with pt undistorted) */
+void orbref_frame_post(const orbref_camera *cam, orbref_kp *raw, int n, orbref_kp *un);
+
 /* SearchForInitialization (modules/ORB/ORBMatcher.cpp:33-116) */
 int orbref_search_for_initialization(float nn_ratio, int check_orientation,
                                      const orbref_kp *kps1, const uint8_t *desc1, int n1,

@@ -30,6 +30,12 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 CAND_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4")])
 
 
+class Camera(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("n_dist", C.c_int32), ("dist", C.c_float * 12), ("undistort", C.c_int32),
+                ("size_scale", C.c_void_p)]
+
+
 class Fv(C.Structure):
     _fields_ = [("n_nodes", C.c_int), ("node_ids", C.c_void_p), ("offsets", C.c_void_p), ("indices", C.c_void_p)]
 
@@ -63,6 +69,7 @@ def lib():
         L.orbref_ic_angle.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orbref_brief.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
         L.orbref_grid_build.restype = C.c_void_p
+        L.orbref_frame_post.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_int, C.c_void_p]
         L.orbref_grid_free.argtypes = [C.c_void_p]
         L.orbref_features_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int,
                                               C.c_int, C.c_void_p, C.c_int]
@@ -272,6 +279,32 @@ def features_in_area(kps, img_w, img_h, x, y, r, min_level, max_level):
     n = lib().orbref_features_in_area(g, _p(kps), x, y, r, min_level, max_level, _p(out), len(out))
     lib().orbref_grid_free(g)
     return out[:n]
+
+
+def frame_post(width, height, fx, fy, cx, cy, dist, kps, undistort=True, size_scale=None):
+    """Frame.cpp:24-51: returns (raw with scaled size, undistorted, cell_start, cell_items)."""
+    cam = Camera(width=width, height=height, fx=fx, fy=fy, cx=cx, cy=cy, n_dist=len(dist), undistort=int(undistort))
+    for i, v in enumerate(dist):
+        cam.dist[i] = v
+    if size_scale is not None:
+        size_scale = np.ascontiguousarray(size_scale, dtype=np.float32)
+        assert size_scale.shape == (height, width)
+        cam.size_scale = size_scale.ctypes.data
+    raw = np.ascontiguousarray(kps, dtype=KP_DTYPE).copy()
+    un = np.zeros_like(raw)
+    L = lib()
+    L.orbref_frame_post(C.byref(cam), _p(raw), len(raw), _p(un))
+
+    class _Grid(C.Structure):
+        _fields_ = [("cols", C.c_int), ("rows", C.c_int), ("img_w", C.c_int), ("img_h", C.c_int),
+                    ("cell_start", C.POINTER(C.c_int32)), ("cell_items", C.POINTER(C.c_int32))]
+    g = L.orbref_grid_build(_p(un), len(un), width, height)
+    gs = C.cast(g, C.POINTER(_Grid)).contents
+    nc = gs.cols * gs.rows
+    start = np.ctypeslib.as_array(gs.cell_start, (nc + 1,)).copy()
+    items = np.ctypeslib.as_array(gs.cell_items, (max(len(un), 1),))[: start[-1]].copy()
+    L.orbref_grid_free(g)
+    return raw, un, start, items
 
 
 def search_by_projection_frame(check_orientation, q_desc, q_xy, q_radius, q_octave, q_angle, q_ok, kps2, desc2, img_w,
