@@ -159,3 +159,63 @@ def make_ba_problem(n_poses=20, n_points=3000, seed=DEFAULT_SEED, width=1242, he
     return {"cam": cam, "pose_R": R.reshape(n_poses, 9), "pose_t": t_est, "pose_fixed": fixed, "points": pts_est,
             "edge_pose": np.array(ep, np.int32), "edge_point": np.array(el, np.int32), "edge_z": z,
             "edge_inv_sigma2": np.array(w)}
+
+
+def make_vocabulary(k=10, L=4, seed=DEFAULT_SEED, p_early_leaf=0.02, p_stop=0.02, flip_bits=40, shuffle=True):
+    """Synthetic DBoW2 vocabulary tree in loadFromTextFile's node order (TemplatedVocabulary.h:1376-1417): node 0 is the
+    root; every node's parent has a smaller id.  A child descriptor is its parent's with `flip_bits` random bits flipped
+    (so a descent is decided by real distances); a few inner nodes end early as leaves (k-means clusters that ran out of
+    points) and a few words have weight 0 ("stopped").  With shuffle=True the ids of a level are permuted, so children
+    are NOT contiguous in id order.  Returns dict(k, L, scoring, weighting, parent, is_leaf, desc, weight)."""
+    rng = np.random.RandomState(seed + 41)
+    parent, leaf, desc = [np.zeros(1, np.int64)], [np.zeros(1, bool)], [np.zeros((1, 32), np.uint8)]
+    prev_ids, prev_desc, next_id = np.zeros(1, np.int64), rng.randint(0, 256, (1, 32)).astype(np.uint8), 1
+    for level in range(1, L + 1):
+        n = len(prev_ids) * k
+        par = np.repeat(prev_ids, k)
+        d = np.repeat(prev_desc, k, axis=0)
+        flips = np.zeros((n, 256), bool)
+        cols = rng.randint(0, 256, (n, flip_bits if level > 1 else 128))
+        flips[np.arange(n)[:, None], cols] = True
+        d = d ^ np.packbits(flips, axis=1, bitorder="little")
+        if shuffle:
+            order = rng.permutation(n)
+            par, d = par[order], d[order]
+        ids = np.arange(next_id, next_id + n)
+        next_id += n
+        is_leaf = np.full(n, level == L) | (rng.uniform(size=n) < p_early_leaf if level >= 2 else False)
+        parent.append(par); leaf.append(is_leaf); desc.append(d)
+        keep = ~is_leaf
+        prev_ids, prev_desc = ids[keep], d[keep]
+    parent = np.concatenate(parent).astype(np.int32)
+    is_leaf = np.concatenate(leaf).astype(np.uint8)
+    desc = np.ascontiguousarray(np.concatenate(desc))
+    # weights as a text file would hold them: 6 significant digits (ostream default, :1447), idf-like magnitudes
+    weight = np.array([float("%.6g" % v) for v in rng.uniform(0.5, 12.0, len(parent))])
+    weight[(rng.uniform(size=len(parent)) < p_stop) & (is_leaf > 0)] = 0.0
+    weight[0] = 0.0
+    return dict(k=k, L=L, scoring=0, weighting=0, parent=parent, is_leaf=is_leaf, desc=desc, weight=weight)
+
+
+def write_vocabulary_text(voc, path, trailing_newline=True):
+    """TemplatedVocabulary::saveToTextFile's format (:1429-1447): 'k L  scoring weighting' then per node
+    'parent is_leaf d0 ... d31  weight'."""
+    with open(path, "w") as f:
+        f.write("%d %d  %d %d\n" % (voc["k"], voc["L"], voc["scoring"], voc["weighting"]))
+        lines = []
+        for i in range(1, len(voc["parent"])):
+            lines.append("%d %d %s  %.6g" % (voc["parent"][i], 1 if voc["is_leaf"][i] else 0,
+                                            " ".join(str(int(b)) for b in voc["desc"][i]), voc["weight"][i]))
+        f.write("\n".join(lines))
+        if trailing_newline:
+            f.write("\n")
+
+
+def make_descriptors_near_words(voc, n, seed=DEFAULT_SEED, flip_bits=25):
+    """n descriptors, each a random leaf's descriptor with `flip_bits` bits flipped."""
+    rng = np.random.RandomState(seed + 43)
+    leaves = np.flatnonzero(voc["is_leaf"])
+    d = voc["desc"][rng.choice(leaves, n)].copy()
+    flips = np.zeros((n, 256), bool)
+    flips[np.arange(n)[:, None], rng.randint(0, 256, (n, flip_bits))] = True
+    return np.ascontiguousarray(d ^ np.packbits(flips, axis=1, bitorder="little"))

@@ -940,6 +940,126 @@ void orbref_frame_post(const orbref_camera *cam, orbref_kp *raw, int n, orbref_k
     }
 }
 
+/* ---- DBoW2 vocabulary transform (TemplatedVocabulary.h:1127-1259) ---- */
+struct orbref_voc {
+    int k, L, scoring, weighting, n_nodes, n_words;
+    int32_t *child_start; /* n_nodes + 1 */
+    int32_t *child;       /* n_nodes - 1, children of node p in ascending id */
+    uint32_t *word_id;
+    double *weight;
+    uint8_t *desc;
+};
+
+orbref_voc *orbref_voc_build(int k, int L, int scoring, int weighting, int n_nodes, const int32_t *parent,
+                             const uint8_t *is_leaf, const uint8_t *desc, const double *weight)
+{
+    orbref_voc *v = (orbref_voc *)calloc(1, sizeof *v);
+    v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting; v->n_nodes = n_nodes;
+    v->child_start = (int32_t *)calloc((size_t)n_nodes + 1, 4);
+    v->child = (int32_t *)malloc(4 * (size_t)(n_nodes > 1 ? n_nodes - 1 : 1));
+    v->word_id = (uint32_t *)calloc((size_t)n_nodes, 4); /* Node(): word_id(0), weight(0) */
+    v->weight = (double *)calloc((size_t)n_nodes, 8);
+    v->desc = (uint8_t *)calloc((size_t)n_nodes, 32);
+    for (int i = 1; i < n_nodes; ++i) v->child_start[parent[i] + 1]++;
+    for (int i = 0; i < n_nodes; ++i) v->child_start[i + 1] += v->child_start[i];
+    int32_t *fill = (int32_t *)calloc((size_t)n_nodes, 4);
+    for (int i = 1; i < n_nodes; ++i) { /* :1393 push_back in file order */
+        v->child[v->child_start[parent[i]] + fill[parent[i]]++] = i;
+        memcpy(v->desc + 32 * (size_t)i, desc + 32 * (size_t)i, 32);
+        v->weight[i] = weight[i];
+        if (is_leaf[i]) v->word_id[i] = (uint32_t)v->n_words++; /* :1408-1414 */
+    }
+    free(fill);
+    return v;
+}
+void orbref_voc_free(orbref_voc *v)
+{
+    if (!v) return;
+    free(v->child_start); free(v->child); free(v->word_id); free(v->weight); free(v->desc); free(v);
+}
+int orbref_voc_n_words(const orbref_voc *v) { return v->n_words; }
+
+void orbref_voc_transform_feature(const orbref_voc *v, const uint8_t *f, int levelsup, uint32_t *word, double *weight,
+                                  uint32_t *nid)
+{
+    const int nid_level = v->L - levelsup;
+    if (nid_level <= 0 && nid) *nid = 0; /* :1228 */
+    int final_id = 0, current_level = 0;
+    do {
+        ++current_level;
+        const int b = v->child_start[final_id], e = v->child_start[final_id + 1];
+        final_id = v->child[b];
+        double best_d = (double)orbref_hamming(f, v->desc + 32 * (size_t)final_id);
+        for (int c = b + 1; c < e; ++c) {
+            const int id = v->child[c];
+            const double d = (double)orbref_hamming(f, v->desc + 32 * (size_t)id);
+            if (d < best_d) { best_d = d; final_id = id; }
+        }
+        if (nid && current_level == nid_level) *nid = (uint32_t)final_id;
+    } while (v->child_start[final_id] != v->child_start[final_id + 1]); /* !isLeaf() */
+    *word = v->word_id[final_id];
+    *weight = v->weight[final_id];
+}
+
+void orbref_voc_transform(const orbref_voc *v, const uint8_t *desc, int n, int levelsup, uint32_t *bow_ids,
+                          double *bow_vals, int *n_words_out, uint32_t *fv_nodes, int32_t *fv_off, uint32_t *fv_idx,
+                          int *n_fv)
+{
+    *n_words_out = 0; *n_fv = 0; fv_off[0] = 0;
+    if (v->n_words == 0) return; /* empty() (:1133) */
+    /* the two std::maps as sorted arrays; FeatureVector values as per-node growing lists */
+    int nb = 0, nf = 0;
+    uint32_t **lists = (uint32_t **)calloc((size_t)(n ? n : 1), sizeof *lists);
+    int *len = (int *)calloc((size_t)(n ? n : 1), sizeof *len);
+    const int accumulate = v->weighting == 0 || v->weighting == 1; /* TF_IDF, TF (:1142) vs IDF, BINARY (:1171) */
+    for (int i = 0; i < n; ++i) {
+        uint32_t id = 0, nid = 0xFFFFFFFFu; /* nid is uninitialised in the reference; marked here */
+        double w = 0;
+        orbref_voc_transform_feature(v, desc + 32 * (size_t)i, levelsup, &id, &w, &nid);
+        if (!(w > 0)) continue; /* stopped word (:1157) */
+        int p = 0;
+        while (p < nb && bow_ids[p] < id) ++p; /* lower_bound */
+        if (p < nb && bow_ids[p] == id) {
+            if (accumulate) bow_vals[p] += w; /* addWeight; addIfNotExist keeps the first */
+        } else {
+            memmove(bow_ids + p + 1, bow_ids + p, 4 * (size_t)(nb - p));
+            memmove(bow_vals + p + 1, bow_vals + p, 8 * (size_t)(nb - p));
+            bow_ids[p] = id; bow_vals[p] = w; ++nb;
+        }
+        p = 0;
+        while (p < nf && fv_nodes[p] < nid) ++p;
+        if (!(p < nf && fv_nodes[p] == nid)) {
+            memmove(fv_nodes + p + 1, fv_nodes + p, 4 * (size_t)(nf - p));
+            memmove(lists + p + 1, lists + p, sizeof *lists * (size_t)(nf - p));
+            memmove(len + p + 1, len + p, sizeof *len * (size_t)(nf - p));
+            fv_nodes[p] = nid; lists[p] = (uint32_t *)malloc(4 * (size_t)n); len[p] = 0; ++nf;
+        }
+        lists[p][len[p]++] = (uint32_t)i;
+    }
+    const int must = v->scoring != 5;          /* DotProductScoring is the only one that does not normalise */
+    const int l2 = v->scoring == 1;            /* L2Scoring; every other normalising scorer uses L1 */
+    if (accumulate && nb > 0 && !must) {       /* :1164-1170 */
+        const double nd = (double)nb;
+        for (int p = 0; p < nb; ++p) bow_vals[p] /= nd;
+    }
+    if (must) {                                /* BowVector::normalize (BowVector.cpp:62-90) */
+        double norm = 0.0;
+        if (!l2) for (int p = 0; p < nb; ++p) norm += fabs(bow_vals[p]);
+        else { for (int p = 0; p < nb; ++p) norm += bow_vals[p] * bow_vals[p]; norm = sqrt(norm); }
+        if (norm > 0.0) for (int p = 0; p < nb; ++p) bow_vals[p] /= norm;
+    }
+    int t = 0;
+    for (int p = 0; p < nf; ++p) {
+        fv_off[p] = t;
+        memcpy(fv_idx + t, lists[p], 4 * (size_t)len[p]);
+        t += len[p];
+        free(lists[p]);
+    }
+    fv_off[nf] = t;
+    free(lists); free(len);
+    *n_words_out = nb; *n_fv = nf;
+}
+
 /* ---- Frame grid: modules/BasicObject/Frame.cpp:33-51, :90-127 (GRID_SIZE 40) ---- */
 #define GRID_SIZE 40
 orbref_grid *orbref_grid_build(const orbref_kp *kps, int n, int img_w, int img_h)

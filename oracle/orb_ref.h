@@ -159,6 +159,27 @@ void orbref_undistort_point(const orbref_camera *cam, float u, float v, float *x
 /* raw (in/out: size scaled), un (out: copy of raw with pt undistorted) */
 void orbref_frame_post(const orbref_camera *cam, orbref_kp *raw, int n, orbref_kp *un);
 
+/* ---- DBoW2 vocabulary transform: thirdParty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1259 (called with levelsup = 4
+ * from Frame::computeBow, modules/BasicObject/Frame.cpp:168-178), BowVector.cpp:32-90, FeatureVector.cpp:31-45,
+ * FORB.cpp:81-101, ScoringObject.h:73-92.  Nodes are given in the order loadFromTextFile (:1338-1420) creates them:
+ * node 0 = root, node i = line i of the text file; children of a node in ascending id (push_back order, :1393);
+ * word ids count the lines flagged as leaves, in file order (:1408-1414). */
+typedef struct orbref_voc orbref_voc;
+orbref_voc *orbref_voc_build(int k, int L, int scoring, int weighting, int n_nodes, const int32_t *parent,
+                             const uint8_t *is_leaf, const uint8_t *desc, const double *weight);
+void orbref_voc_free(orbref_voc *v);
+int orbref_voc_n_words(const orbref_voc *v);
+/* transform(feature, word_id, weight, &nid, levelsup) (:1218-1259).  *nid is left untouched when the descent ends
+ * above level L - levelsup (the reference leaves it uninitialised there). */
+void orbref_voc_transform_feature(const orbref_voc *v, const uint8_t *desc, int levelsup, uint32_t *word, double *weight,
+                                  uint32_t *nid);
+/* transform(features, BowVector, FeatureVector, levelsup) (:1127-1201).  Outputs are the two std::maps flattened in
+ * key order: bow_ids/bow_vals [n_words_out]; fv_nodes [n_fv], fv_off [n_fv + 1], fv_idx [fv_off[n_fv]].
+ * All arrays need room for n entries (fv_off n + 1). */
+void orbref_voc_transform(const orbref_voc *v, const uint8_t *desc, int n, int levelsup, uint32_t *bow_ids,
+                          double *bow_vals, int *n_words_out, uint32_t *fv_nodes, int32_t *fv_off, uint32_t *fv_idx,
+                          int *n_fv);
+
 /* SearchForInitialization (modules/ORB/ORBMatcher.cpp:33-116) */
 int orbref_search_for_initialization(float nn_ratio, int check_orientation,
                                      const orbref_kp *kps1, const uint8_t *desc1, int n1,

@@ -69,6 +69,13 @@ def lib():
         L.orbref_ic_angle.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orbref_brief.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
         L.orbref_grid_build.restype = C.c_void_p
+        L.orbref_voc_build.restype = C.c_void_p
+        L.orbref_voc_build.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+        L.orbref_voc_free.argtypes = [C.c_void_p]
+        L.orbref_voc_n_words.argtypes = [C.c_void_p]
+        L.orbref_voc_transform_feature.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orbref_voc_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
         L.orbref_frame_post.argtypes = [C.POINTER(Camera), C.c_void_p, C.c_int, C.c_void_p]
         L.orbref_grid_free.argtypes = [C.c_void_p]
         L.orbref_features_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int,
@@ -336,3 +343,57 @@ def search_by_projection_points(nn_ratio, q_desc, q_xy, q_radius, q_level, q_ok,
     n = lib().orbref_search_by_projection_points(nn_ratio, _p(qd), _p(qx), _p(qr), _p(ql), _p(qk), len(qd), _p(k2),
                                                  _p(d2), len(k2), img_w, img_h, _p(mp), _p(cnt))
     return n, mp, tuple(cnt.tolist())
+
+
+def parse_vocabulary_text(path):
+    """TemplatedVocabulary::loadFromTextFile (:1338-1420) in Python; the trailing empty line does not become a node
+    (the reference turns it into a phantom root child with an uninitialised descriptor -- see include/orbv.h)."""
+    with open(path) as f:
+        k, L, scoring, weighting = (int(t) for t in f.readline().split())
+        parent, leaf, desc, weight = [0], [0], [[0] * 32], [0.0]
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            parent.append(int(t[0])); leaf.append(1 if int(t[1]) > 0 else 0)
+            desc.append([int(v) & 255 for v in t[2:34]]); weight.append(float(t[34]))
+    return dict(k=k, L=L, scoring=scoring, weighting=weighting, parent=np.array(parent, np.int32),
+                is_leaf=np.array(leaf, np.uint8), desc=np.array(desc, np.uint8), weight=np.array(weight, np.float64))
+
+
+class Vocabulary:
+    """DBoW2 vocabulary restatement (TemplatedVocabulary.h:1127-1259)."""
+
+    def __init__(self, voc):
+        self.voc = voc
+        self._keep = [np.ascontiguousarray(voc["parent"], dtype=np.int32), np.ascontiguousarray(voc["is_leaf"], dtype=np.uint8),
+                      np.ascontiguousarray(voc["desc"], dtype=np.uint8), np.ascontiguousarray(voc["weight"], dtype=np.float64)]
+        self.h = lib().orbref_voc_build(voc["k"], voc["L"], voc["scoring"], voc["weighting"], len(self._keep[0]),
+                                        *[_p(a) for a in self._keep])
+        self.n_words = lib().orbref_voc_n_words(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orbref_voc_free(self.h)
+            self.h = None
+
+    def transform_features(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        n = len(desc)
+        word, node, w = np.zeros(n, np.uint32), np.full(n, 0xFFFFFFFF, np.uint32), np.zeros(n, np.float64)
+        for i in range(n):
+            lib().orbref_voc_transform_feature(self.h, desc[i].ctypes.data, levelsup, word[i:].ctypes.data,
+                                               w[i:].ctypes.data, node[i:].ctypes.data)
+        return word, node, w
+
+    def transform(self, desc, levelsup=4):
+        """returns (bow_ids, bow_vals, (fv_nodes, fv_off, fv_idx))"""
+        desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        n = len(desc)
+        m = max(n, 1)
+        bi, bv = np.zeros(m, np.uint32), np.zeros(m, np.float64)
+        fn, fo, fi = np.zeros(m, np.uint32), np.zeros(m + 1, np.int32), np.zeros(m, np.uint32)
+        nw, nf = C.c_int(), C.c_int()
+        lib().orbref_voc_transform(self.h, _p(desc), n, levelsup, _p(bi), _p(bv), C.addressof(nw), _p(fn), _p(fo), _p(fi),
+                                   C.addressof(nf))
+        return bi[: nw.value], bv[: nw.value], (fn[: nf.value], fo[: nf.value + 1], fi[: fo[nf.value]])

@@ -25,7 +25,7 @@ def _declared(header):
 
 def test_every_declared_symbol_is_exported(built):
     L = C.CDLL(built.LIB_PATH)
-    names = _declared("orbx.h") + _declared("orbm.h") + _declared("orbba.h") + _declared("orbf.h")
+    names = _declared("orbx.h") + _declared("orbm.h") + _declared("orbba.h") + _declared("orbf.h") + _declared("orbv.h")
     assert "orbba_linearize" in names
     assert len(names) >= 25
     for n in names:

@@ -1,0 +1,261 @@
+"""Bag-of-words assignment (DBoW2 TemplatedVocabulary::transform, Frame::computeBow): oracle KATs and a literal
+Python model on the CPU, HIP-vs-oracle parity (bit-exact, including the double BowVector values) on the GPU."""
+import numpy as np
+import pytest
+
+from monoorbslam3_amd import synth
+
+NO_NODE = 0xFFFFFFFF
+
+
+def _bits(*ones):
+    d = np.zeros(32, np.uint8)
+    for b in ones:
+        d[b >> 3] |= 1 << (b & 7)
+    return d
+
+
+def _tiny(scoring=0, weighting=0):
+    """k = 2, L = 2.  root -> A(1), B(2);  A -> A0(3, leaf w=2), A1(4, leaf w=0 = stopped);  B(2) is an early leaf."""
+    desc = np.stack([_bits(), _bits(0, 1, 2, 3), _bits(200, 201, 202, 203), _bits(0, 1, 2, 3, 4), _bits(0, 1, 2, 3, 60, 61)])
+    return dict(k=2, L=2, scoring=scoring, weighting=weighting, parent=np.array([0, 0, 0, 1, 1], np.int32),
+                is_leaf=np.array([0, 0, 1, 1, 1], np.uint8), desc=desc, weight=np.array([0, 0.7, 1.5, 2.0, 0.0]))
+
+
+def test_oracle_tiny_tree(oracle_mod):
+    V = oracle_mod.Vocabulary(_tiny())
+    assert V.n_words == 3  # words numbered in file order: B=0, A0=1, A1=2
+    feats = np.stack([_bits(0, 1, 2, 3, 4),      # -> A -> A0
+                      _bits(0, 1, 2, 3, 60, 61),  # -> A -> A1 (stopped)
+                      _bits(200, 201),            # -> B, a leaf at level 1
+                      _bits(0, 1, 2, 3, 4, 5),    # -> A -> A0
+                      _bits(100)])                # equidistant from A and B (5 vs 5): the first child (A) keeps the tie
+    word, node, w = V.transform_features(feats, levelsup=0)  # nid level = 2
+    assert list(word) == [1, 2, 0, 1, 1] and list(w) == [2.0, 0.0, 1.5, 2.0, 2.0]
+    assert list(node) == [3, 4, NO_NODE, 3, 3]  # B ends above level 2: the reference leaves nid uninitialised
+    _, node1, _ = V.transform_features(feats, levelsup=1)
+    assert list(node1) == [1, 1, 2, 1, 1]
+    _, node2, _ = V.transform_features(feats, levelsup=2)
+    assert list(node2) == [0] * 5  # nid_level <= 0 -> root (:1228)
+    bi, bv, (fn, fo, fi) = V.transform(feats, levelsup=1)
+    assert list(bi) == [0, 1] and np.allclose(bv, [1.5 / 7.5, 6.0 / 7.5]) and bv[1] == ((2.0 + 2.0) + 2.0) / (1.5 + 6.0)
+    assert list(fn) == [1, 2] and list(fo) == [0, 3, 4] and list(fi) == [0, 3, 4, 2]  # feature 1 is stopped
+
+
+@pytest.mark.parametrize("scoring,weighting,expect", [
+    (1, 0, [1.5 / np.sqrt(1.5 ** 2 + 36), 6 / np.sqrt(1.5 ** 2 + 36)]),  # L2
+    (5, 0, [1.5 / 2, 6.0 / 2]),    # DOT_PRODUCT: no norm, TF-IDF divides by v.size() (:1164-1170)
+    (5, 2, [1.5, 2.0]),            # IDF: addIfNotExist, nothing else
+    (0, 3, [1.5 / 3.5, 2 / 3.5]),  # BINARY + L1
+])
+def test_oracle_scoring_variants(oracle_mod, scoring, weighting, expect):
+    V = oracle_mod.Vocabulary(_tiny(scoring, weighting))
+    feats = np.stack([_bits(0, 1, 2, 3, 4), _bits(200, 201), _bits(0, 1, 2, 3, 4, 5), _bits(100)])
+    bi, bv, _ = V.transform(feats, levelsup=1)
+    assert list(bi) == [0, 1] and np.allclose(bv, expect, rtol=1e-15)
+
+
+def _model_transform(voc, desc, levelsup):
+    """transform() with Python dicts standing in for the std::maps (TemplatedVocabulary.h:1127-1259)."""
+    children = {}
+    word_id, n_words = {}, 0
+    for i in range(1, len(voc["parent"])):
+        children.setdefault(int(voc["parent"][i]), []).append(i)
+        if voc["is_leaf"][i]:
+            word_id[i] = n_words
+            n_words += 1
+    bow, fv = {}, {}
+    accumulate = voc["weighting"] in (0, 1)
+    for i_feature, f in enumerate(desc):
+        nid_level = voc["L"] - levelsup
+        nid = 0 if nid_level <= 0 else NO_NODE
+        final, level = 0, 0
+        while True:
+            level += 1
+            nodes = children[final]
+            d = [int(np.unpackbits(f ^ voc["desc"][c]).sum()) for c in nodes]
+            final = nodes[int(np.argmin(d))]  # argmin returns the first minimum = strict '<' scan
+            if level == nid_level:
+                nid = final
+            if final not in children:
+                break
+        w = float(voc["weight"][final])
+        if w > 0:
+            wid = word_id.get(final, 0)
+            if wid in bow:
+                if accumulate:
+                    bow[wid] += w
+            else:
+                bow[wid] = w
+            fv.setdefault(nid, []).append(i_feature)
+    keys = sorted(bow)
+    vals = [bow[k] for k in keys]
+    must, l2 = voc["scoring"] != 5, voc["scoring"] == 1
+    if accumulate and keys and not must:
+        vals = [v / float(len(keys)) for v in vals]
+    if must:
+        norm = 0.0
+        for v in vals:
+            norm += v * v if l2 else abs(v)
+        if l2:
+            norm = float(np.sqrt(norm))
+        if norm > 0:
+            vals = [v / norm for v in vals]
+    return keys, vals, {k: fv[k] for k in sorted(fv)}
+
+
+@pytest.mark.parametrize("scoring,weighting,levelsup", [(0, 0, 2), (1, 1, 1), (5, 0, 3), (2, 3, 0)])
+def test_oracle_matches_literal_model(oracle_mod, scoring, weighting, levelsup):
+    voc = synth.make_vocabulary(5, 3, seed=3, p_early_leaf=0.1, p_stop=0.1)
+    voc["scoring"], voc["weighting"] = scoring, weighting
+    desc = synth.make_descriptors_near_words(voc, 300, seed=4)
+    bi, bv, (fn, fo, fi) = oracle_mod.Vocabulary(voc).transform(desc, levelsup)
+    keys, vals, fv = _model_transform(voc, desc, levelsup)
+    assert list(bi) == keys and list(bv) == vals  # doubles: identical, not merely close
+    assert list(fn) == list(fv)
+    for r, node in enumerate(fn):
+        assert list(fi[fo[r]:fo[r + 1]]) == fv[int(node)]
+
+
+def test_text_format_round_trip(oracle_mod, tmp_path):
+    voc = synth.make_vocabulary(4, 3, seed=5)
+    for nl in (True, False):
+        path = tmp_path / ("voc%d.txt" % nl)
+        synth.write_vocabulary_text(voc, str(path), trailing_newline=nl)
+        back = oracle_mod.parse_vocabulary_text(str(path))
+        assert all(np.array_equal(voc[k], back[k]) for k in ("parent", "is_leaf", "desc", "weight"))
+        assert (back["k"], back["L"], back["scoring"], back["weighting"]) == (4, 3, 0, 0)
+
+
+# ------------------------------------------------------------------------------------------------------------- GPU
+def _same_transform(got, want):
+    (gi, gv, (gn, go, gx)), (wi, wv, (wn, wo, wx)) = got, want
+    assert np.array_equal(gi, wi) and gv.tobytes() == wv.tobytes()
+    assert np.array_equal(gn, wn) and np.array_equal(go, wo) and np.array_equal(gx, wx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scoring,weighting", [(0, 0), (1, 1), (5, 0), (5, 2), (3, 3)])
+def test_transform_parity(oracle_mod, scoring, weighting):
+    from monoorbslam3_amd.vocabulary import ORBVocabulary
+    voc = synth.make_vocabulary(10, 4, seed=7)
+    voc["scoring"], voc["weighting"] = scoring, weighting
+    V, R = ORBVocabulary.from_arrays(voc), oracle_mod.Vocabulary(voc)
+    assert V.n_words == R.n_words and V.n_nodes == len(voc["parent"])
+    desc = synth.make_descriptors_near_words(voc, 2100, seed=8)
+    for levelsup in (4, 2, 1, 0):
+        _same_transform(V.transform(desc, levelsup), R.transform(desc, levelsup))
+    for n in (0, 1, 2, 5, 257):
+        _same_transform(V.transform(desc[:n], 2), R.transform(desc[:n], 2))
+
+
+@pytest.mark.gpu
+def test_transform_many_features_and_heavy_collisions(oracle_mod):
+    """8192 features (the LDS sort's limit) on a tiny tree: a handful of words, thousands of features each."""
+    from monoorbslam3_amd.vocabulary import ORBVocabulary
+    voc = synth.make_vocabulary(3, 2, seed=9, p_early_leaf=0.3)
+    V, R = ORBVocabulary.from_arrays(voc), oracle_mod.Vocabulary(voc)
+    desc = np.random.RandomState(1).randint(0, 256, (8192, 32)).astype(np.uint8)
+    _same_transform(V.transform(desc, 1), R.transform(desc, 1))
+    with pytest.raises(Exception):
+        V.transform(np.zeros((8193, 32), np.uint8), 1)
+
+
+@pytest.mark.gpu
+def test_load_text_matches_python_parse(oracle_mod, tmp_path):
+    from monoorbslam3_amd.vocabulary import ORBVocabulary
+    voc = synth.make_vocabulary(6, 3, seed=10)
+    voc["scoring"], voc["weighting"] = 1, 2
+    for nl in (True, False):
+        path = tmp_path / ("v%d.txt" % nl)
+        synth.write_vocabulary_text(voc, str(path), trailing_newline=nl)
+        V = ORBVocabulary.load_text(path)
+        got, want = V.nodes(), oracle_mod.parse_vocabulary_text(str(path))
+        assert (V.k, V.L, V.scoring, V.weighting) == (6, 3, 1, 2)
+        assert all(np.array_equal(got[k], want[k]) for k in ("parent", "is_leaf", "desc", "weight"))
+        desc = synth.make_descriptors_near_words(voc, 500, seed=2)
+        _same_transform(V.transform(desc), oracle_mod.Vocabulary(want).transform(desc))
+    bad = tmp_path / "bad.txt"
+    bad.write_text("10 6 0 0\n0 0 1 2 3\n")
+    with pytest.raises(Exception, match="malformed"):
+        ORBVocabulary.load_text(bad)
+    bad.write_text("30 6 0 0\n")
+    with pytest.raises(Exception, match="not a correct text file"):
+        ORBVocabulary.load_text(bad)
+    with pytest.raises(Exception, match="cannot open"):
+        ORBVocabulary.load_text(tmp_path / "missing.txt")
+
+
+@pytest.mark.gpu
+def test_batch_transform_feeds_search_by_bow(oracle_mod):
+    """extract -> computeBow -> SearchByBow with the descriptors never leaving the GPU between the first two steps."""
+    import torch
+    from monoorbslam3_amd.extractor import ORBExtractor
+    from monoorbslam3_amd.matcher import ORBMatcher
+    from monoorbslam3_amd.vocabulary import ORBVocabulary
+    B, W, H = 4, 752, 480
+    frames = synth.make_frames(B, W, H, seed=31)
+    frames[1] = np.roll(frames[0], 3, axis=1)  # a shifted copy, so that frames 0 and 1 really match
+    ex = ORBExtractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
+    cap = ex.max_keypoints(W, H)
+    d_img = torch.from_numpy(frames).cuda()
+    kp = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    ex.extract_batch_device(d_img.data_ptr(), B, W, H, W, W * H, kp.data_ptr(), desc.data_ptr(), cap, n.data_ptr(),
+                            s.cuda_stream)
+    voc = synth.make_vocabulary(10, 4, seed=12, flip_bits=60)
+    V, R = ORBVocabulary.from_arrays(voc), oracle_mod.Vocabulary(voc)
+    bow_ids = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    bow_vals = torch.zeros((B, cap), dtype=torch.float64, device="cuda")
+    fv_nodes = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    fv_off = torch.zeros((B, cap + 1), dtype=torch.int32, device="cuda")
+    fv_idx = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    n_words = torch.zeros(B, dtype=torch.int32, device="cuda")
+    n_fv = torch.zeros(B, dtype=torch.int32, device="cuda")
+    V.transform_device(B, desc.data_ptr(), n.data_ptr(), cap, 2, bow_ids.data_ptr(), bow_vals.data_ptr(), n_words.data_ptr(),
+                       fv_nodes.data_ptr(), fv_off.data_ptr(), fv_idx.data_ptr(), n_fv.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    n_h, nw, nf = n.cpu().numpy(), n_words.cpu().numpy(), n_fv.cpu().numpy()
+    fvs, descs = [], []
+    for f in range(B):
+        d = desc[f, : n_h[f]].cpu().numpy()
+        wi, wv, (wn, wo, wx) = R.transform(d, 2)
+        assert nw[f] == len(wi) and nf[f] == len(wn)
+        assert np.array_equal(bow_ids[f, : nw[f]].cpu().numpy().view(np.uint32), wi)
+        assert bow_vals[f, : nw[f]].cpu().numpy().tobytes() == wv.tobytes()
+        assert np.array_equal(fv_nodes[f, : nf[f]].cpu().numpy().view(np.uint32), wn)
+        assert np.array_equal(fv_off[f, : nf[f] + 1].cpu().numpy(), wo)
+        assert np.array_equal(fv_idx[f, : wo[-1]].cpu().numpy().view(np.uint32), wx)
+        fvs.append((wn, wo, wx))
+        descs.append(d)
+    # the CSR FeatureVector is what SearchByBow consumes
+    ang = [kp[f, : n_h[f]].cpu().numpy().view(oracle_mod.KP_DTYPE).reshape(-1)["angle"].copy() for f in range(2)]
+    ok = np.ones(n_h[0], np.uint8)
+    mp0 = np.full(n_h[1], -1, np.int32)
+    got = ORBMatcher(0.7, True).SearchByBow(descs[0], ang[0], ok, fvs[0], descs[1], ang[1], mp0, fvs[1])
+    want = oracle_mod.search_by_bow(0.7, True, descs[0], ang[0], ok, fvs[0], descs[1], ang[1], mp0, fvs[1])
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and got[0] > 50
+
+
+@pytest.mark.gpu
+def test_transform_features_device(oracle_mod):
+    import torch
+    from monoorbslam3_amd.vocabulary import ORBVocabulary
+    voc = synth.make_vocabulary(10, 4, seed=13, p_early_leaf=0.2)
+    V, R = ORBVocabulary.from_arrays(voc), oracle_mod.Vocabulary(voc)
+    desc = synth.make_descriptors_near_words(voc, 3000, seed=14)
+    d = torch.from_numpy(desc).cuda()
+    word = torch.zeros(3000, dtype=torch.int32, device="cuda")
+    node = torch.zeros(3000, dtype=torch.int32, device="cuda")
+    w = torch.zeros(3000, dtype=torch.float64, device="cuda")
+    for levelsup in (3, 1):
+        V.transform_features_device(d.data_ptr(), 3000, levelsup, word.data_ptr(), node.data_ptr(), w.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        rw, rn, rwt = R.transform_features(desc, levelsup)
+        assert np.array_equal(word.cpu().numpy().view(np.uint32), rw)
+        assert np.array_equal(node.cpu().numpy().view(np.uint32), rn)
+        assert np.array_equal(w.cpu().numpy(), rwt)
+    assert (rn == NO_NODE).sum() > 0  # early leaves above the node level occur in this tree
