@@ -62,7 +62,10 @@ class FramePost:
 
     def close(self):
         if getattr(self, "_h", None):
-            _L().orbf_destroy(self._h)
+            try:
+                _L().orbf_destroy(self._h)
+            except TypeError:  # interpreter shutdown: module globals are already gone
+                pass
             self._h = None
 
     __del__ = close

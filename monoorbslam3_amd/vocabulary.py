@@ -67,7 +67,10 @@ class ORBVocabulary:
 
     def close(self):
         if getattr(self, "_h", None):
-            _L().orbv_destroy(self._h)
+            try:
+                _L().orbv_destroy(self._h)
+            except TypeError:  # interpreter shutdown: module globals are already gone
+                pass
             self._h = None
 
     __del__ = close

@@ -374,7 +374,10 @@ class Vocabulary:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orbref_voc_free(self.h)
+            try:
+                lib().orbref_voc_free(self.h)
+            except TypeError:  # interpreter shutdown
+                pass
             self.h = None
 
     def transform_features(self, desc, levelsup=4):
