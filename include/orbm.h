@@ -122,6 +122,15 @@ int orbm_search_by_projection_points(orbm_t *h, float nn_ratio,
                                      const void *kps2, const uint8_t *desc2, int n2, int img_w, int img_h,
                                      int32_t *frame_mp, int *n_matches, int32_t *counters);
 
+/* MapPoint::computeDescriptor (modules/BasicObject/MapPoint.cpp:103-152) for n_groups map points at once.
+ * Group g = the descriptors desc[off[g] .. off[g+1]) of one point's observations (the caller skips bad key frames,
+ * :115-120).  best_idx[g] = index inside the group of the descriptor with the least median Hamming distance to the
+ * group (median = sorted row[(N-1)/2], self distance 0 included; first index on ties, :138-146); -1 for an empty
+ * group (the reference returns without touching the descriptor, :122).  At most 1024 observations per point. */
+int orbm_distinctive_descriptors(orbm_t *h, const uint8_t *desc, const int32_t *off, int n_groups, int32_t *best_idx);
+int orbm_distinctive_descriptors_device(orbm_t *h, const uint8_t *d_desc, const int32_t *d_off, int n_groups,
+                                        int32_t *d_best_idx, void *stream);
+
 /* ORBMatcher::ComputeThreeMaxima (modules/ORB/ORBMatcher.cpp:594-622) on bin sizes */
 void orbm_three_maxima(const int32_t *hist_sizes, int n_bins, int *ind1, int *ind2, int *ind3);
 

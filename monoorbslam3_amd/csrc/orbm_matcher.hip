@@ -258,6 +258,41 @@ __global__ __launch_bounds__(256) void k_topk_lists(const uint8_t *__restrict__ 
     }
 }
 
+// MapPoint::computeDescriptor (modules/BasicObject/MapPoint.cpp:103-152) for many map points at once: group g holds
+// the descriptors [off[g], off[g+1]) of one point's observations; the result is the index (inside the group) of the
+// descriptor with the least median distance to all of them (self included, distance 0), first one on ties
+// (`median < bestMedian` from 256, :141-146).  median = sorted row[(N-1)/2] (:143).
+// One wave per group.  The k-th smallest of a row is found without sorting: distances live in 0..256, so a 9-step
+// bisection on the value with a counting pass per step gives it; the group's descriptors sit in LDS.
+#define MEDOID_MAX 1024
+__global__ __launch_bounds__(64) void k_medoid(const uint8_t *__restrict__ desc, const int32_t *__restrict__ off,
+                                               int n_groups, int32_t *__restrict__ best_idx)
+{
+    __shared__ Desc256 sd[MEDOID_MAX];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int b = off[g], n = min(off[g + 1] - b, MEDOID_MAX);
+    if (n <= 0) { if (lane == 0) best_idx[g] = -1; return; }
+    for (int i = lane; i < n; i += 64) sd[i] = load_desc(desc + (size_t)(b + i) * 32);
+    __syncthreads();
+    const int kth = (n - 1) / 2;
+    uint32_t bestkey = 0xFFFFFFFFu; // (median << 16 | row): the minimum is the least median, first row on ties
+    for (int i = lane; i < n; i += 64) {
+        const Desc256 di = sd[i];
+        int lo = 0, hi = 256; // smallest v with #{j : d_ij <= v} > kth
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < n; ++j) cnt += ham256(di, sd[j]) <= mid;
+            if (cnt > kth) hi = mid; else lo = mid + 1;
+        }
+        bestkey = min(bestkey, ((uint32_t)lo << 16) | (uint32_t)i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bestkey = min(bestkey, (uint32_t)__shfl_xor((int)bestkey, o));
+    // bestMedian starts at 256 with a strict '<': a median of 256 never replaces index 0 (:138-146)
+    if (lane == 0) best_idx[g] = (bestkey >> 16) >= 256 ? 0 : (int32_t)(bestkey & 0xFFFF);
+}
+
 // ---------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------
@@ -498,6 +533,47 @@ extern "C" int orbm_hamming_csr(orbm_t *c, const uint8_t *a, int na, const uint8
 // ---------------------------------------------------------------------------------------------
 // host-side greedy passes over device-computed distances
 // ---------------------------------------------------------------------------------------------
+extern "C" int orbm_distinctive_descriptors_device(orbm_t *c, const uint8_t *d_desc, const int32_t *d_off, int n_groups,
+                                                   int32_t *d_best_idx, void *stream)
+{
+    if (!c || !d_desc || !d_off || !d_best_idx) return orbx_set_error(ORBX_E_ARG, "null argument");
+    if (n_groups < 0) return orbx_set_error(ORBX_E_ARG, "negative group count");
+    if (n_groups == 0) return ORBX_OK;
+    M_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipLaunchKernelGGL(k_medoid, dim3(n_groups), dim3(64), 0, s, d_desc, d_off, n_groups, d_best_idx);
+    M_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+
+extern "C" int orbm_distinctive_descriptors(orbm_t *c, const uint8_t *desc, const int32_t *off, int n_groups,
+                                            int32_t *best_idx)
+{
+    if (!c || !off || !best_idx) return orbx_set_error(ORBX_E_ARG, "null argument");
+    if (n_groups < 0) return orbx_set_error(ORBX_E_ARG, "negative group count");
+    if (n_groups == 0) return ORBX_OK;
+    const int total = off[n_groups];
+    for (int g = 0; g < n_groups; ++g) {
+        if (off[g + 1] < off[g] || off[g] < 0) return orbx_set_error(ORBX_E_ARG, "group offsets must be non-decreasing");
+        if (off[g + 1] - off[g] > MEDOID_MAX)
+            return orbx_set_error(ORBX_E_UNSUPPORTED, "more than 1024 observations of one map point");
+    }
+    if (total > 0 && !desc) return orbx_set_error(ORBX_E_ARG, "null descriptors");
+    M_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    M_TRY(c->a.need((size_t)std::max(total, 1) * 32));
+    M_TRY(c->c_begin.need((size_t)(n_groups + 1) * 4));
+    M_TRY(c->bidx.need((size_t)n_groups * 4));
+    if (total > 0) M_TRY(hipMemcpyAsync(c->a.p, desc, (size_t)total * 32, hipMemcpyHostToDevice, s));
+    M_TRY(hipMemcpyAsync(c->c_begin.p, off, (size_t)(n_groups + 1) * 4, hipMemcpyHostToDevice, s));
+    int rc = orbm_distinctive_descriptors_device(c, (const uint8_t *)c->a.p, (const int32_t *)c->c_begin.p, n_groups,
+                                                 (int32_t *)c->bidx.p, s);
+    if (rc) return rc;
+    M_TRY(hipMemcpyAsync(best_idx, c->bidx.p, (size_t)n_groups * 4, hipMemcpyDeviceToHost, s));
+    M_TRY(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
 extern "C" void orbm_three_maxima(const int32_t *h, int n_bins, int *ind1, int *ind2, int *ind3)
 {
     // ORBMatcher.cpp:594-622 (callers initialise the three indices to -1)

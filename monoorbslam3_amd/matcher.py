@@ -50,6 +50,8 @@ def _mlib():
                                                       C.POINTER(i32)]),
             "orbm_search_by_projection_points": (i32, [vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp,
                                                        C.POINTER(i32), vp]),
+            "orbm_distinctive_descriptors": (i32, [vp, vp, vp, i32, vp]),
+            "orbm_distinctive_descriptors_device": (i32, [vp, vp, vp, i32, vp, vp]),
             "orbm_three_maxima": (None, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         }
         for name, (res, args) in sigs.items():
@@ -150,6 +152,17 @@ class ORBMatcher:
         out = np.zeros(int(off[-1]) if len(off) else 0, np.uint16)
         _lib.check(hd._L.orbm_hamming_csr(hd._h, _vp(a), len(a), _vp(b), len(b), _vp(q_idx), _vp(off), len(q_idx),
                                           _vp(c_idx), _vp(out)))
+        return out
+
+    @staticmethod
+    def ComputeDistinctiveDescriptors(desc, off, handle=None):
+        """MapPoint::computeDescriptor (MapPoint.cpp:103-152) for many map points: desc[off[g]:off[g+1]] are the
+        observations of point g; returns the index (inside its group) of each point's new descriptor, -1 if none."""
+        hd = handle or _handle()
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        out = np.zeros(max(len(off) - 1, 0), np.int32)
+        _lib.check(hd._L.orbm_distinctive_descriptors(hd._h, _vp(desc), _vp(off), len(off) - 1, _vp(out)))
         return out
 
     @staticmethod

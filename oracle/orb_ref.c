@@ -1060,6 +1060,28 @@ void orbref_voc_transform(const orbref_voc *v, const uint8_t *desc, int n, int l
     *n_words_out = nb; *n_fv = nf;
 }
 
+/* ---- MapPoint::computeDescriptor: modules/BasicObject/MapPoint.cpp:103-152 ---- */
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+int orbref_distinctive_descriptor(const uint8_t *desc, int n)
+{
+    if (n <= 0) return -1; /* :122 */
+    int *dist = (int *)malloc(sizeof(int) * (size_t)n * n), *row = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        dist[i * n + i] = 0;
+        for (int j = i + 1; j < n; ++j)
+            dist[i * n + j] = dist[j * n + i] = orbref_hamming(desc + 32 * (size_t)i, desc + 32 * (size_t)j);
+    }
+    int bestMedian = 256, bestIdx = 0;
+    for (int i = 0; i < n; ++i) {
+        memcpy(row, dist + i * n, sizeof(int) * (size_t)n);
+        qsort(row, (size_t)n, sizeof(int), cmp_int);
+        const int median = row[(n - 1) / 2];
+        if (median < bestMedian) { bestMedian = median; bestIdx = i; }
+    }
+    free(dist); free(row);
+    return bestIdx;
+}
+
 /* ---- Frame grid: modules/BasicObject/Frame.cpp:33-51, :90-127 (GRID_SIZE 40) ---- */
 #define GRID_SIZE 40
 orbref_grid *orbref_grid_build(const orbref_kp *kps, int n, int img_w, int img_h)

@@ -180,6 +180,10 @@ void orbref_voc_transform(const orbref_voc *v, const uint8_t *desc, int n, int l
                           double *bow_vals, int *n_words_out, uint32_t *fv_nodes, int32_t *fv_off, uint32_t *fv_idx,
                           int *n_fv);
 
+/* MapPoint::computeDescriptor (modules/BasicObject/MapPoint.cpp:103-152): index of the descriptor with the least
+ * median distance to the n descriptors (sorted row[(n-1)/2]); -1 when n == 0 */
+int orbref_distinctive_descriptor(const uint8_t *desc, int n);
+
 /* SearchForInitialization (modules/ORB/ORBMatcher.cpp:33-116) */
 int orbref_search_for_initialization(float nn_ratio, int check_orientation,
                                      const orbref_kp *kps1, const uint8_t *desc1, int n1,

@@ -400,3 +400,9 @@ class Vocabulary:
         lib().orbref_voc_transform(self.h, _p(desc), n, levelsup, _p(bi), _p(bv), C.addressof(nw), _p(fn), _p(fo), _p(fi),
                                    C.addressof(nf))
         return bi[: nw.value], bv[: nw.value], (fn[: nf.value], fo[: nf.value + 1], fi[: fo[nf.value]])
+
+
+def distinctive_descriptor(desc):
+    """MapPoint::computeDescriptor (MapPoint.cpp:103-152) for one map point."""
+    desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+    return lib().orbref_distinctive_descriptor(_p(desc), len(desc))

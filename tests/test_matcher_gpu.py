@@ -241,3 +241,26 @@ def test_search_by_projection_points(oracle_mod):
     ref = oracle_mod.search_by_projection_points(0.8, d1, q_xy, q_radius, q_level, q_ok, k2, d2, w, h, mp0)
     assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
     assert got[0] > 100 and got[2][0] == int((q_ok == 0).sum())
+
+
+def test_distinctive_descriptors(oracle_mod):
+    """MapPoint::computeDescriptor for a batch of map points (MapPoint.cpp:103-152)."""
+    from monoorbslam3_amd.matcher import ORBMatcher
+    rng = np.random.RandomState(12)
+    sizes = [0, 1, 2, 3, 4, 7, 64, 65, 130, 1024] + list(rng.randint(1, 40, 300))
+    groups = []
+    for k, n in enumerate(sizes):
+        if k % 3 == 0:  # near-duplicates: many equal medians, the first index must win
+            base = rng.randint(0, 256, (1, 32)).astype(np.uint8)
+            g = np.repeat(base, n, axis=0)
+            for r in g[n // 2:]:
+                r[rng.randint(32)] ^= 1 << rng.randint(8)
+        else:
+            g = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+        groups.append(g)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    got = ORBMatcher.ComputeDistinctiveDescriptors(np.concatenate(groups), off)
+    want = [oracle_mod.distinctive_descriptor(g) for g in groups]
+    assert list(got) == want
+    with pytest.raises(Exception):
+        ORBMatcher.ComputeDistinctiveDescriptors(np.zeros((1025, 32), np.uint8), np.array([0, 1025], np.int32))

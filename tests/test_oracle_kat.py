@@ -672,3 +672,28 @@ def test_golden_extract_fixture(O):
     for f in ("x", "y", "angle", "response", "octave"):
         assert np.array_equal(kps[f], z[f]), f
     assert np.array_equal(desc, z["desc"])
+
+
+def test_distinctive_descriptor_kats(oracle_mod):
+    """MapPoint.cpp:103-152: least median (sorted row[(N-1)/2], self distance included), first index on ties."""
+    z = np.zeros(32, np.uint8)
+
+    def d(nbits):
+        v = z.copy()
+        for b in range(nbits):
+            v[b >> 3] |= 1 << (b & 7)
+        return v
+    assert oracle_mod.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == -1
+    assert oracle_mod.distinctive_descriptor(d(5)[None]) == 0
+    assert oracle_mod.distinctive_descriptor(np.stack([d(0), d(9)])) == 0  # N=2: median = row[0] = 0 for both rows
+    # N=3: median = the smaller of the two other distances: rows (0,10,30)->10, (0,10,20)->10, (0,20,30)->20: first wins
+    assert oracle_mod.distinctive_descriptor(np.stack([d(0), d(10), d(30)])) == 0
+    # N=4: median = row[1]: rows d(0):(0,40,42,44)->40, d(40):(0,2,4,40)->2, d(42):(0,2,2,42)->2, d(44):(0,2,4,44)->2
+    assert oracle_mod.distinctive_descriptor(np.stack([d(0), d(40), d(42), d(44)])) == 1
+    # brute force with numpy on random groups
+    rng = np.random.RandomState(3)
+    for n in (5, 8, 13):
+        g = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+        dist = np.unpackbits(g[:, None] ^ g[None], axis=2).sum(2)
+        med = np.sort(dist, axis=1)[:, (n - 1) // 2]
+        assert oracle_mod.distinctive_descriptor(g) == int(np.argmin(med))
