@@ -48,8 +48,9 @@ def algorithmic_bytes(ex, w, h, kp_per_frame):
     }, P
 
 
-def cpu_baseline(frames, n_features, threads):
-    """The C oracle (restatement of the reference's CPU extractor) on the host cores."""
+def cpu_baseline(frames, n_features, threads, match):
+    """The C oracle (restatement of the reference's CPU extractor and best/second-best loop) on the host cores: the
+    same work as one GPU step -- extract every frame, then match it against its predecessor."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import orb_ref_py
     orb_ref_py.build()
@@ -57,9 +58,12 @@ def cpu_baseline(frames, n_features, threads):
     orc[0].extract(frames[0])  # warm-up
 
     def work(t):
-        n = 0
+        n, prev = 0, None
         for i in range(t, len(frames), threads):
-            orc[t].extract(frames[i])
+            _, desc, _ = orc[t].extract(frames[i])
+            if match and prev is not None:
+                orb_ref_py.best2(prev, desc)
+            prev = desc
             n += 1
         return n
 
@@ -291,12 +295,14 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = min(16, os.cpu_count() or 1)
-        n_cpu = max(threads * 8, 64)
+        n_cpu = threads * 24  # about 20-30 s of CPU work in total, a couple of seconds of wall time
         cf = base[np.arange(n_cpu) % n_distinct]
-        v, done, cdt = cpu_baseline(cf, NF, threads)
+        v, done, cdt = cpu_baseline(cf, NF, threads, not args.no_match)
         out["cpu_baseline"] = {"value": round(v, 2), "unit": "frames/s", "cores": threads, "kind": "port",
-                               "sample": "%d frames of the same synthetic workload, extraction only, C oracle "
-                                         "(restatement of the reference's CPU ORBextractor, -O2), %.1f s wall" % (done, cdt)}
+                               "sample": "%d frames of the same synthetic workload, extraction%s, C oracle (restatement of "
+                                         "the reference's CPU code, -O2), %.1f s wall on %d threads"
+                                         % (done, "" if args.no_match else " + best/second-best match against the "
+                                            "previous frame", cdt, threads)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1082,6 +1082,21 @@ int orbref_distinctive_descriptor(const uint8_t *desc, int n)
     return bestIdx;
 }
 
+/* ---- dense best / second-best: the inner loop of modules/ORB/ORBMatcher.cpp:148-162 ---- */
+void orbref_best2(const uint8_t *a, int na, const uint8_t *b, int nb, int32_t *best_idx, uint16_t *best,
+                  uint16_t *second)
+{
+    for (int i = 0; i < na; ++i) {
+        int b1 = 256, b2 = 256, bi = -1;
+        for (int j = 0; j < nb; ++j) {
+            const int d = orbref_hamming(a + 32 * (size_t)i, b + 32 * (size_t)j);
+            if (d < b1) { b2 = b1; b1 = d; bi = j; }
+            else if (d < b2) b2 = d;
+        }
+        best_idx[i] = bi; best[i] = (uint16_t)b1; second[i] = (uint16_t)b2;
+    }
+}
+
 /* ---- Frame grid: modules/BasicObject/Frame.cpp:33-51, :90-127 (GRID_SIZE 40) ---- */
 #define GRID_SIZE 40
 orbref_grid *orbref_grid_build(const orbref_kp *kps, int n, int img_w, int img_h)

@@ -184,6 +184,11 @@ void orbref_voc_transform(const orbref_voc *v, const uint8_t *desc, int n, int l
  * median distance to the n descriptors (sorted row[(n-1)/2]); -1 when n == 0 */
 int orbref_distinctive_descriptor(const uint8_t *desc, int n);
 
+/* The best / second-best loop of SearchByBow (modules/ORB/ORBMatcher.cpp:148-162) over all rows of b for every
+ * row of a: strict '<' in ascending candidate order, both distances start at 256, best index -1 without candidates. */
+void orbref_best2(const uint8_t *a, int na, const uint8_t *b, int nb, int32_t *best_idx, uint16_t *best,
+                  uint16_t *second);
+
 /* SearchForInitialization (modules/ORB/ORBMatcher.cpp:33-116) */
 int orbref_search_for_initialization(float nn_ratio, int check_orientation,
                                      const orbref_kp *kps1, const uint8_t *desc1, int n1,

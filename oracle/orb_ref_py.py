@@ -406,3 +406,12 @@ def distinctive_descriptor(desc):
     """MapPoint::computeDescriptor (MapPoint.cpp:103-152) for one map point."""
     desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
     return lib().orbref_distinctive_descriptor(_p(desc), len(desc))
+
+
+def best2(a, b):
+    """dense best / second-best of every row of a among the rows of b (ORBMatcher.cpp:148-162)"""
+    a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, 32)
+    b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 32)
+    bi, bd, sd = np.zeros(len(a), np.int32), np.zeros(len(a), np.uint16), np.zeros(len(a), np.uint16)
+    lib().orbref_best2(_p(a), len(a), _p(b), len(b), _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
