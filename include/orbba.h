@@ -8,9 +8,12 @@
  *   Huber kernel, delta = sqrtf(5.991)                 modules/Backend/Optimize.cpp:857, :880-882
  *   g2o BaseBinaryEdge::constructQuadraticForm         (g2o 20201223, not vendored): H_ii += J_i^T W J_i,
  *                                                      H_ij += J_i^T W J_j, b_i -= J_i^T W e, W = rho'(chi2) * Omega
- * The Schur complement, the reduced solve and the LM loop stay with g2o.
- * Everything is IEEE double.  Host pointers in and out; the call uploads, runs two kernels
- * (per-edge linearise, fixed-order block reduction) and downloads.
+ * orbba_linearize delivers one iteration's blocks to a host solver; orbba_optimize / orbba_local_bundle_adjustment
+ *  keep the whole Levenberg-Marquardt loop on the device: Schur complement over the marginalised
+ * points, dense Cholesky of the reduced pose system, back-substitution, VertexSE3 / Vertex3D updates -- the algorithm
+ * of g2o 20201223's OptimizationAlgorithmLevenberg + BlockSolver_6_3 (not vendored in the reference; restated from
+ * its published sources, checked against the numpy restatement in oracle/ba_ref.py to a stated tolerance).
+ * Everything is IEEE double.  Host pointers in and out.
  */
 #ifndef ORBBA_H
 #define ORBBA_H
@@ -48,6 +51,37 @@ typedef struct orbba_result {
 
 /* any output pointer may be NULL */
 int orbba_linearize(const orbba_problem *p, orbba_result *r, int device);
+
+/* g2o::OptimizationAlgorithmLevenberg's knobs; a zero field takes g2o's default */
+typedef struct orbba_lm_options {
+    int32_t max_iterations;     /* optimizer.optimize(n) */
+    int32_t max_trials;         /* _maxTrialsAfterFailure, default 10 */
+    double tau;                 /* computeLambdaInit: lambda0 = tau * max |H_jj|, default 1e-5 */
+    double good_step_lower;     /* default 1/3 */
+    double good_step_upper;     /* default 2/3 */
+    double user_lambda_init;    /* > 0: fixed initial lambda */
+    const uint8_t *edge_active; /* n_edges, 0 = edge at level 1 (Optimize.cpp:900-902); NULL = all active */
+} orbba_lm_options;
+
+typedef struct orbba_lm_result {
+    double *pose_R;  /* n_poses x 9, optimised (fixed poses unchanged) */
+    double *pose_t;  /* n_poses x 3 */
+    double *points;  /* n_points x 3 */
+    double *chi2;    /* n_edges: e^T Omega e at the final estimate (inactive edges included, as e->chi2() at :917) */
+    int32_t iterations, trials; /* outer LM iterations run, linear solves tried */
+    double lambda;              /* final damping */
+    double chi2_initial, chi2_final; /* activeRobustChi2 before / after */
+    float device_ms;            /* HIP-event time of the whole loop (includes the small host decisions) */
+} orbba_lm_result;
+
+/* optimizer.initializeOptimization(); optimizer.optimize(max_iterations) for the graph of
+ * Optimize::localBundleAdjustment (Optimize.cpp:811-893): VertexSE3 poses (fixed ones constant), marginalised
+ * Vertex3D points, EdgeSE3Project3D edges with the Huber kernel of p->huber_delta (<= 0: none). */
+int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o, orbba_lm_result *r, int device);
+
+/* Optimize.cpp:892-922: optimize(5) with Huber; edges with chi2 > 5.991 go to level 1 and the kernel is dropped;
+ * optimize(10); outlier[e] = final chi2 > 5.991 (the observations the reference then erases).  outlier may be NULL. */
+int orbba_local_bundle_adjustment(const orbba_problem *p, orbba_lm_result *r, uint8_t *outlier, int device);
 
 #ifdef __cplusplus
 }

@@ -51,3 +51,72 @@ def linearize(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, ed
     _lib.check(fn(C.byref(prob), C.byref(res), device))
     out["kernel_ms"] = float(res.kernel_ms)
     return out
+
+
+class _LmOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("max_trials", C.c_int32), ("tau", C.c_double),
+                ("good_step_lower", C.c_double), ("good_step_upper", C.c_double), ("user_lambda_init", C.c_double),
+                ("edge_active", C.c_void_p)]
+
+
+class _LmResult(C.Structure):
+    _fields_ = [("pose_R", C.c_void_p), ("pose_t", C.c_void_p), ("points", C.c_void_p), ("chi2", C.c_void_p),
+                ("iterations", C.c_int32), ("trials", C.c_int32), ("lam", C.c_double), ("chi2_initial", C.c_double),
+                ("chi2_final", C.c_double), ("device_ms", C.c_float)]
+
+
+def _problem(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, edge_z, edge_inv_sigma2, huber_delta):
+    f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    keep = [f8(pose_R).reshape(-1, 9), f8(pose_t).reshape(-1, 3), np.ascontiguousarray(pose_fixed, dtype=np.uint8),
+            f8(points).reshape(-1, 3), np.ascontiguousarray(edge_pose, dtype=np.int32),
+            np.ascontiguousarray(edge_point, dtype=np.int32), f8(edge_z).reshape(-1, 2), f8(edge_inv_sigma2)]
+    prob = _Problem(cam[0], cam[1], cam[2], cam[3], huber_delta, len(keep[0]), len(keep[3]), len(keep[4]),
+                    *[a.ctypes.data for a in keep])
+    return prob, keep
+
+
+def _lm_out(prob):
+    out = {"pose_R": np.zeros((prob.n_poses, 3, 3)), "pose_t": np.zeros((prob.n_poses, 3)),
+           "points": np.zeros((prob.n_points, 3)), "chi2": np.zeros(prob.n_edges)}
+    res = _LmResult(out["pose_R"].ctypes.data, out["pose_t"].ctypes.data, out["points"].ctypes.data,
+                    out["chi2"].ctypes.data)
+    return out, res
+
+
+def _lm_finish(out, res):
+    out.update(iterations=res.iterations, trials=res.trials, lam=res.lam, chi2_initial=res.chi2_initial,
+               chi2_final=res.chi2_final, device_ms=float(res.device_ms))
+    return out
+
+
+def optimize(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, edge_z, edge_inv_sigma2,
+             huber_delta=HUBER_MONO, iterations=5, edge_active=None, device=-1):
+    """optimizer.optimize(iterations) of Optimize::localBundleAdjustment's graph (Optimize.cpp:811-893) on the GPU."""
+    L = _lib.lib()
+    fn = L.orbba_optimize
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(_Problem), C.POINTER(_LmOptions), C.POINTER(_LmResult), C.c_int]
+    prob, keep = _problem(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, edge_z, edge_inv_sigma2, huber_delta)
+    opt = _LmOptions(max_iterations=iterations)
+    if edge_active is not None:
+        act = np.ascontiguousarray(edge_active, dtype=np.uint8)
+        opt.edge_active = act.ctypes.data
+    out, res = _lm_out(prob)
+    _lib.check(fn(C.byref(prob), C.byref(opt), C.byref(res), device))
+    return _lm_finish(out, res)
+
+
+def local_bundle_adjustment(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, edge_z, edge_inv_sigma2,
+                            huber_delta=HUBER_MONO, device=-1):
+    """Optimize.cpp:892-922: optimize(5) with Huber, drop the chi2 > 5.991 edges and the kernel, optimize(10); the
+    returned dict also holds `outlier` (the observations the reference erases at :924-935)."""
+    L = _lib.lib()
+    fn = L.orbba_local_bundle_adjustment
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(_Problem), C.POINTER(_LmResult), C.c_void_p, C.c_int]
+    prob, keep = _problem(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, edge_z, edge_inv_sigma2, huber_delta)
+    out, res = _lm_out(prob)
+    outlier = np.zeros(prob.n_edges, np.uint8)
+    _lib.check(fn(C.byref(prob), C.byref(res), outlier.ctypes.data, device))
+    out["outlier"] = outlier.astype(bool)
+    return _lm_finish(out, res)

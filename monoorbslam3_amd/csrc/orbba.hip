@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -30,7 +32,8 @@ __global__ __launch_bounds__(256) void k_ba_edges(BaCam cam, int n_edges, const 
                                                   const double *__restrict__ pose_t, const uint8_t *__restrict__ pose_fixed,
                                                   const double *__restrict__ points, const int *__restrict__ edge_pose,
                                                   const int *__restrict__ edge_point, const double *__restrict__ edge_z,
-                                                  const double *__restrict__ edge_w, double *__restrict__ chi2_out,
+                                                  const double *__restrict__ edge_w,
+                                                  const uint8_t *__restrict__ edge_active, double *__restrict__ chi2_out,
                                                   double *__restrict__ err_out, double *__restrict__ Hlp,
                                                   double *__restrict__ Cpp /* n_edges x 27 */,
                                                   double *__restrict__ Cll /* n_edges x 9 */)
@@ -55,7 +58,8 @@ __global__ __launch_bounds__(256) void k_ba_edges(BaCam cam, int n_edges, const 
     // g2o RobustKernelHuber: rho'(chi2) = 1 inside delta^2, delta / sqrt(chi2) outside
     double rw = 1.0;
     if (cam.delta > 0.0 && chi2 > cam.delta * cam.delta) rw = cam.delta / sqrt(chi2);
-    const double W = rw * om;
+    // an edge at level 1 (Optimize.cpp:900-902) is not part of the active set: its chi2 is still reported
+    const double W = (edge_active && !edge_active[e]) ? 0.0 : rw * om;
     // Pinhole::getProjJacobian (Pinhole.cpp:49-53)
     const double Jp[6] = {cam.fx / Z, 0.0, -cam.fx * X / (Z * Z), 0.0, cam.fy / Z, -cam.fy * Y / (Z * Z)};
     // J_point = -Jp * R  (G2oTypes.cpp:44)
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(256) void k_ba_edges(BaCam cam, int n_edges, const 
     if (err_out) { err_out[2 * e] = ex; err_out[2 * e + 1] = ey; }
     const bool fixed = pose_fixed[ip] != 0;
     // point block: H_ll += Jl^T W Jl (6 unique), b_l -= Jl^T W e
+    if (!Cll || !Cpp) return; // error-only evaluation (an LM trial): the linearisation of the iteration is kept
     double *cl = Cll + (size_t)e * 9;
     int k = 0;
 #pragma unroll
@@ -223,7 +228,7 @@ extern "C" int orbba_linearize(const orbba_problem *p, orbba_result *r, int devi
     if (NE)
         hipLaunchKernelGGL(k_ba_edges, dim3((NE + 255) / 256), dim3(256), 0, 0, cam, NE, dR.as<double>(), dt.as<double>(),
                            dfix.as<uint8_t>(), dP.as<double>(), dep.as<int>(), del.as<int>(), dz.as<double>(), dw.as<double>(),
-                           dchi.as<double>(), derr.as<double>(), dHlp.as<double>(), dCpp.as<double>(), dCll.as<double>());
+                           (const uint8_t *)nullptr, dchi.as<double>(), derr.as<double>(), dHlp.as<double>(), dCpp.as<double>(), dCll.as<double>());
     hipLaunchKernelGGL(k_ba_reduce_pose, dim3(NP), dim3(256), 0, 0, dpo.as<int>(), dpe.as<int>(), dCpp.as<double>(),
                        dHpp.as<double>(), dbp.as<double>());
     hipLaunchKernelGGL(k_ba_reduce_point, dim3((NL + 255) / 256), dim3(256), 0, 0, NL, dlo.as<int>(), dCll.as<double>(),
@@ -242,5 +247,486 @@ extern "C" int orbba_linearize(const orbba_problem *p, orbba_result *r, int devi
     if (r->b_p) B_TRY(hipMemcpy(r->b_p, dbp.p, sizeof(double) * 6 * NP, hipMemcpyDeviceToHost));
     if (r->H_ll) B_TRY(hipMemcpy(r->H_ll, dHll.p, sizeof(double) * 9 * NL, hipMemcpyDeviceToHost));
     if (r->b_l) B_TRY(hipMemcpy(r->b_l, dbl.p, sizeof(double) * 3 * NL, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+
+// =====================================================================================================================
+// Levenberg-Marquardt with marginalised points on the device: what g2o's
+// OptimizationAlgorithmLevenberg + BlockSolver_6_3 do for the graph of Optimize::localBundleAdjustment
+// (modules/Backend/Optimize.cpp:811-911).  All f64, fixed-order reductions, the host only takes the accept/reject
+// decision of each trial from three scalars.
+//   k_lm_points     thread = point: (H_ll + lambda I)^-1 and its product with b_l
+//   k_lm_schur      workgroup = one 6x6 block (i, j >= i) of the reduced system over the free poses:
+//                   S_ij = [i == j](H_pp + lambda I) - sum_l H_pl(i,l) H_ll^-1 H_pl(j,l)^T,  rhs_i = b_p - sum_l H_pl H_ll^-1 b_l
+//   k_lm_chol_solve single workgroup: in-place Cholesky of S and the two triangular solves
+//   k_lm_backsub    thread = point: x_l = H_ll^-1 (b_l - sum_e H_pl^T x_p); partial sums of x (lambda x + b)
+//   k_lm_update_*   VertexSE3::oplusImpl (exp(update) * estimate, G2oTypes.h:112-115) and Vertex3D::oplusImpl (:155-158)
+//   k_lm_chi2       partial sums of the robustified chi2 over the active edges
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_lm_points(int n_points, double lam, const double *__restrict__ Hll,
+                                                   const double *__restrict__ bl, double *__restrict__ inv,
+                                                   double *__restrict__ tl)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= n_points) return;
+    const double *h = Hll + (size_t)l * 9;
+    const double a = h[0] + lam, b = h[1], c = h[2], d = h[4] + lam, e = h[5], f = h[8] + lam; // symmetric
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02;
+    const double id = 1.0 / det;
+    double m[9];
+    m[0] = c00 * id; m[1] = c01 * id; m[2] = c02 * id;
+    m[3] = m[1]; m[4] = (a * f - c * c) * id; m[5] = (b * c - a * e) * id;
+    m[6] = m[2]; m[7] = m[5]; m[8] = (a * d - b * b) * id;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) inv[(size_t)l * 9 + k] = m[k];
+    const double b0 = bl[3 * l], b1 = bl[3 * l + 1], b2 = bl[3 * l + 2];
+    tl[3 * l] = m[0] * b0 + m[1] * b1 + m[2] * b2;
+    tl[3 * l + 1] = m[3] * b0 + m[4] * b1 + m[5] * b2;
+    tl[3 * l + 2] = m[6] * b0 + m[7] * b1 + m[8] * b2;
+}
+
+__global__ __launch_bounds__(256) void k_lm_schur(int n_free, int n_points, double lam, const int *__restrict__ free_pose,
+                                                  const int *__restrict__ edge_of /* [n_free][n_points] */,
+                                                  const double *__restrict__ Hpp, const double *__restrict__ bp,
+                                                  const double *__restrict__ Hlp, const double *__restrict__ inv,
+                                                  const double *__restrict__ tl, double *__restrict__ S,
+                                                  double *__restrict__ rhs)
+{
+    __shared__ double red[4][42];
+    // block index -> (i, j >= i)
+    int i = 0, rem = blockIdx.x;
+    while (rem >= n_free - i) { rem -= n_free - i; ++i; }
+    const int j = i + rem, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double acc[42];
+#pragma unroll
+    for (int k = 0; k < 42; ++k) acc[k] = 0.0;
+    const int *ei = edge_of + (size_t)i * n_points, *ej = edge_of + (size_t)j * n_points;
+    for (int l = tid; l < n_points; l += 256) {
+        const int ea = ei[l], eb = ej[l];
+        if (ea < 0 || eb < 0) continue;
+        const double *A = Hlp + (size_t)ea * 18, *B = Hlp + (size_t)eb * 18, *m = inv + (size_t)l * 9;
+        double Cm[18]; // H_ll^-1 * B (3x6)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Cm[6 * r + c] = m[3 * r] * B[c] + m[3 * r + 1] * B[6 + c] + m[3 * r + 2] * B[12 + c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[6 * r + c] += A[r] * Cm[c] + A[6 + r] * Cm[6 + c] + A[12 + r] * Cm[12 + c];
+        if (i == j) {
+            const double *t = tl + (size_t)l * 3;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[36 + r] += A[r] * t[0] + A[6 + r] * t[1] + A[12 + r] * t[2];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 42; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wv][k] = v;
+    }
+    __syncthreads();
+    const int n = 6 * n_free;
+    if (tid < 36) {
+        const int r = tid / 6, c = tid % 6;
+        const double sum = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        double v = -sum;
+        if (i == j) v += Hpp[(size_t)free_pose[i] * 36 + tid] + (r == c ? lam : 0.0);
+        S[(size_t)(6 * i + r) * n + 6 * j + c] = v;
+        if (i != j) S[(size_t)(6 * j + c) * n + 6 * i + r] = v;
+    } else if (tid < 42 && i == j) {
+        const int r = tid - 36;
+        rhs[6 * i + r] = bp[(size_t)free_pose[i] * 6 + r] - ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    }
+}
+
+// S (n x n, row-major, lower triangle used) -> L in place; x = S^-1 rhs.  *ok = 0 if a pivot is not positive.
+__global__ __launch_bounds__(256) void k_lm_chol_solve(int n, double *__restrict__ S, const double *__restrict__ rhs,
+                                                       double *__restrict__ x, int *__restrict__ ok)
+{
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int i = tid; i < n; i += 256) x[i] = rhs[i];
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        if (tid == 0) {
+            const double d = S[(size_t)k * n + k];
+            if (!(d > 0.0)) bad = 1;
+            else S[(size_t)k * n + k] = sqrt(d);
+        }
+        __syncthreads();
+        if (bad) break;
+        const double dk = S[(size_t)k * n + k];
+        for (int r = k + 1 + tid; r < n; r += 256) S[(size_t)r * n + k] /= dk;
+        __syncthreads();
+        const int m = n - k - 1;
+        for (int idx = tid; idx < m * m; idx += 256) {
+            const int r = k + 1 + idx / m, c = k + 1 + idx % m;
+            if (c <= r) S[(size_t)r * n + c] -= S[(size_t)r * n + k] * S[(size_t)c * n + k];
+        }
+        __syncthreads();
+    }
+    if (bad) {
+        if (tid == 0) *ok = 0;
+        for (int i = tid; i < n; i += 256) x[i] = 0.0;
+        return;
+    }
+    for (int k = 0; k < n; ++k) { // L y = rhs
+        if (tid == 0) x[k] /= S[(size_t)k * n + k];
+        __syncthreads();
+        const double yk = x[k];
+        for (int r = k + 1 + tid; r < n; r += 256) x[r] -= S[(size_t)r * n + k] * yk;
+        __syncthreads();
+    }
+    for (int k = n - 1; k >= 0; --k) { // L^T x = y
+        if (tid == 0) x[k] /= S[(size_t)k * n + k];
+        __syncthreads();
+        const double xk = x[k];
+        for (int r = tid; r < k; r += 256) x[r] -= S[(size_t)k * n + r] * xk;
+        __syncthreads();
+    }
+    if (tid == 0) *ok = 1;
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double *red4)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+
+__global__ __launch_bounds__(256) void k_lm_backsub(int n_points, double lam, const int *__restrict__ point_off,
+                                                    const int *__restrict__ edge_pose, const int *__restrict__ pose_slot,
+                                                    const double *__restrict__ Hlp, const double *__restrict__ xp,
+                                                    const double *__restrict__ bl, const double *__restrict__ inv,
+                                                    double *__restrict__ xl, double *__restrict__ partial)
+{
+    __shared__ double red4[4];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    double sc = 0.0;
+    if (l < n_points) {
+        double r0 = bl[3 * l], r1 = bl[3 * l + 1], r2 = bl[3 * l + 2];
+        for (int e = point_off[l]; e < point_off[l + 1]; ++e) {
+            const int s = pose_slot[edge_pose[e]];
+            if (s < 0) continue;
+            const double *A = Hlp + (size_t)e * 18, *q = xp + 6 * s;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { r0 -= A[c] * q[c]; r1 -= A[6 + c] * q[c]; r2 -= A[12 + c] * q[c]; }
+        }
+        const double *m = inv + (size_t)l * 9;
+        const double x0 = m[0] * r0 + m[1] * r1 + m[2] * r2, x1 = m[3] * r0 + m[4] * r1 + m[5] * r2,
+                     x2 = m[6] * r0 + m[7] * r1 + m[8] * r2;
+        xl[3 * l] = x0; xl[3 * l + 1] = x1; xl[3 * l + 2] = x2;
+        sc = x0 * (lam * x0 + bl[3 * l]) + x1 * (lam * x1 + bl[3 * l + 1]) + x2 * (lam * x2 + bl[3 * l + 2]);
+    }
+    const double tot = block_sum_256(sc, red4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// one workgroup: poses <- exp(x_p) * poses for the free poses, and their share of computeScale()
+__global__ __launch_bounds__(256) void k_lm_update_poses(int n_free, double lam, const int *__restrict__ free_pose,
+                                                         const double *__restrict__ xp, const double *__restrict__ bp,
+                                                         double *__restrict__ R, double *__restrict__ t,
+                                                         double *__restrict__ scale_out)
+{
+    __shared__ double red4[4];
+    double sc = 0.0;
+    for (int i = threadIdx.x; i < n_free; i += 256) {
+        const int ip = free_pose[i];
+        const double *u = xp + 6 * i;
+        const double wx = u[0], wy = u[1], wz = u[2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sc += u[k] * (lam * u[k] + bp[(size_t)ip * 6 + k]);
+        // g2o SE3Quat::exp
+        const double th = sqrt(wx * wx + wy * wy + wz * wz);
+        const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+        double K2[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) K2[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+        double ra, rb, va, vb;
+        if (th < 0.00001) { ra = 1.0; rb = 0.5; va = 0.5; vb = 1.0 / 6.0; }
+        else {
+            ra = sin(th) / th; rb = (1.0 - cos(th)) / (th * th);
+            va = rb; vb = (th - sin(th)) / (th * th * th);
+        }
+        double E[9], V[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const double I = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+            E[k] = I + ra * K[k] + rb * K2[k];
+            V[k] = I + va * K[k] + vb * K2[k];
+        }
+        double Rn[9], tn[3];
+        const double *Ro = R + (size_t)ip * 9, *to = t + (size_t)ip * 3;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Rn[3 * r + c] = E[3 * r] * Ro[c] + E[3 * r + 1] * Ro[3 + c] + E[3 * r + 2] * Ro[6 + c];
+            tn[r] = (E[3 * r] * to[0] + E[3 * r + 1] * to[1] + E[3 * r + 2] * to[2]) +
+                    (V[3 * r] * u[3] + V[3 * r + 1] * u[4] + V[3 * r + 2] * u[5]);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[(size_t)ip * 9 + k] = Rn[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[(size_t)ip * 3 + k] = tn[k];
+    }
+    const double tot = block_sum_256(sc, red4);
+    if (threadIdx.x == 0) *scale_out = tot;
+}
+
+__global__ __launch_bounds__(256) void k_lm_update_points(int n3, const double *__restrict__ xl, double *__restrict__ P)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n3) P[i] += xl[i];
+}
+
+__global__ __launch_bounds__(256) void k_lm_chi2(int n_edges, double delta, const double *__restrict__ chi2,
+                                                 const uint8_t *__restrict__ active, double *__restrict__ partial)
+{
+    __shared__ double red4[4];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (e < n_edges && (!active || active[e])) {
+        v = chi2[e];
+        if (delta > 0.0 && v > delta * delta) v = 2.0 * delta * sqrt(v) - delta * delta; // RobustKernelHuber rho[0]
+    }
+    const double tot = block_sum_256(v, red4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+extern "C" int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o, orbba_lm_result *r, int device)
+{
+    if (!p || !o || !r) return orbx_set_error(ORBX_E_ARG, "null argument");
+    if (p->n_poses < 1 || p->n_points < 1 || p->n_edges < 1) return orbx_set_error(ORBX_E_ARG, "bad sizes");
+    if (!p->pose_R || !p->pose_t || !p->pose_fixed || !p->points || !p->edge_pose || !p->edge_point || !p->edge_z ||
+        !p->edge_inv_sigma2)
+        return orbx_set_error(ORBX_E_ARG, "null input array");
+    if (o->max_iterations < 0) return orbx_set_error(ORBX_E_ARG, "negative iteration count");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return orbx_set_error(ORBX_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device >= 0) B_TRY(hipSetDevice(device));
+    const int NP = p->n_poses, NL = p->n_points, NE = p->n_edges;
+    const double tau = o->tau > 0 ? o->tau : 1e-5, lower = o->good_step_lower > 0 ? o->good_step_lower : 1.0 / 3.0,
+                 upper = o->good_step_upper > 0 ? o->good_step_upper : 2.0 / 3.0;
+    const int max_trials = o->max_trials > 0 ? o->max_trials : 10;
+    // ---- index structures
+    std::vector<int> pose_off(NP + 1, 0), pose_edges(NE), point_off(NL + 1, 0), free_pose, pose_slot(NP, -1);
+    for (int i = 0; i < NP; ++i)
+        if (!p->pose_fixed[i]) { pose_slot[i] = (int)free_pose.size(); free_pose.push_back(i); }
+    const int NF = (int)free_pose.size(), N = 6 * NF;
+    if (NF < 1) return orbx_set_error(ORBX_E_ARG, "every pose is fixed: nothing to optimise");
+    if ((size_t)NF * NL > (size_t)1 << 28) return orbx_set_error(ORBX_E_UNSUPPORTED, "free poses x points table too large");
+    std::vector<int> edge_of((size_t)NF * NL, -1);
+    for (int e = 0; e < NE; ++e) {
+        const int ip = p->edge_pose[e], il = p->edge_point[e];
+        if (ip < 0 || ip >= NP || il < 0 || il >= NL) return orbx_set_error(ORBX_E_ARG, "edge index out of range");
+        if (e && il < p->edge_point[e - 1]) return orbx_set_error(ORBX_E_ARG, "edges must be grouped by point");
+        pose_off[ip + 1]++;
+        point_off[il + 1]++;
+        if (pose_slot[ip] >= 0) {
+            int &slot = edge_of[(size_t)pose_slot[ip] * NL + il];
+            if (slot >= 0) return orbx_set_error(ORBX_E_ARG, "a point is observed twice by the same key frame");
+            slot = e;
+        }
+    }
+    for (int i = 0; i < NP; ++i) pose_off[i + 1] += pose_off[i];
+    for (int i = 0; i < NL; ++i) point_off[i + 1] += point_off[i];
+    {
+        std::vector<int> fill(pose_off.begin(), pose_off.end() - 1);
+        for (int e = 0; e < NE; ++e) pose_edges[fill[p->edge_pose[e]]++] = e;
+    }
+    const int EB = (NE + 255) / 256, LB = (NL + 255) / 256;
+    Dev dR, dt, dRb, dtb, dfix, dP, dPb, dep, del, dz, dw, dact, dchi, dHlp, dCpp, dCll, dpo, dpe, dlo, dHpp, dbp, dHll, dbl, dinv,
+        dtl, dfree, dslot, deo, dS, drhs, dxp, dxl, dpart, dflag;
+    B_TRY(dR.alloc(8 * 9 * NP)); B_TRY(dt.alloc(8 * 3 * NP)); B_TRY(dRb.alloc(8 * 9 * NP)); B_TRY(dtb.alloc(8 * 3 * NP));
+    B_TRY(dfix.alloc(NP)); B_TRY(dP.alloc(8 * 3 * NL)); B_TRY(dPb.alloc(8 * 3 * NL));
+    B_TRY(dep.alloc(4 * NE)); B_TRY(del.alloc(4 * NE)); B_TRY(dz.alloc(16 * NE)); B_TRY(dw.alloc(8 * NE)); B_TRY(dact.alloc(NE));
+    B_TRY(dchi.alloc(8 * NE)); B_TRY(dHlp.alloc((size_t)8 * 18 * NE)); B_TRY(dCpp.alloc((size_t)8 * 27 * NE));
+    B_TRY(dCll.alloc((size_t)8 * 9 * NE));
+    B_TRY(dpo.alloc(4 * (NP + 1))); B_TRY(dpe.alloc(4 * NE)); B_TRY(dlo.alloc(4 * (NL + 1)));
+    B_TRY(dHpp.alloc(8 * 36 * NP)); B_TRY(dbp.alloc(8 * 6 * NP)); B_TRY(dHll.alloc(8 * 9 * NL)); B_TRY(dbl.alloc(8 * 3 * NL));
+    B_TRY(dinv.alloc(8 * 9 * NL)); B_TRY(dtl.alloc(8 * 3 * NL)); B_TRY(dfree.alloc(4 * NF)); B_TRY(dslot.alloc(4 * NP));
+    B_TRY(deo.alloc((size_t)4 * NF * NL)); B_TRY(dS.alloc((size_t)8 * N * N)); B_TRY(drhs.alloc(8 * N)); B_TRY(dxp.alloc(8 * N));
+    B_TRY(dxl.alloc(8 * 3 * NL)); B_TRY(dpart.alloc(8 * (EB + LB + 1))); B_TRY(dflag.alloc(4));
+    B_TRY(hipMemcpy(dR.p, p->pose_R, 8 * 9 * NP, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dt.p, p->pose_t, 8 * 3 * NP, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dfix.p, p->pose_fixed, NP, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dP.p, p->points, 8 * 3 * NL, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dep.p, p->edge_pose, 4 * NE, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(del.p, p->edge_point, 4 * NE, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dz.p, p->edge_z, 16 * NE, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dw.p, p->edge_inv_sigma2, 8 * NE, hipMemcpyHostToDevice));
+    if (o->edge_active) B_TRY(hipMemcpy(dact.p, o->edge_active, NE, hipMemcpyHostToDevice));
+    const uint8_t *d_active = o->edge_active ? dact.as<uint8_t>() : nullptr;
+    B_TRY(hipMemcpy(dpo.p, pose_off.data(), 4 * (NP + 1), hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dpe.p, pose_edges.data(), 4 * NE, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dlo.p, point_off.data(), 4 * (NL + 1), hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dfree.p, free_pose.data(), 4 * NF, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dslot.p, pose_slot.data(), 4 * NP, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(deo.p, edge_of.data(), (size_t)4 * NF * NL, hipMemcpyHostToDevice));
+    const BaCam cam = {p->fx, p->fy, p->cx, p->cy, p->huber_delta};
+    hipEvent_t e0, e1;
+    B_TRY(hipEventCreate(&e0)); B_TRY(hipEventCreate(&e1));
+    B_TRY(hipEventRecord(e0, 0));
+
+    std::vector<double> part((size_t)EB + LB + 1);
+    // errors at the current estimate (+ the whole linearisation when `full`), returns activeRobustChi2
+    auto evaluate = [&](bool full, double *chi_out) -> int {
+        hipLaunchKernelGGL(k_ba_edges, dim3(EB), dim3(256), 0, 0, cam, NE, dR.as<double>(), dt.as<double>(), dfix.as<uint8_t>(),
+                           dP.as<double>(), dep.as<int>(), del.as<int>(), dz.as<double>(), dw.as<double>(), d_active,
+                           dchi.as<double>(), (double *)nullptr, full ? dHlp.as<double>() : nullptr,
+                           full ? dCpp.as<double>() : nullptr, full ? dCll.as<double>() : nullptr);
+        if (full) {
+            hipLaunchKernelGGL(k_ba_reduce_pose, dim3(NP), dim3(256), 0, 0, dpo.as<int>(), dpe.as<int>(), dCpp.as<double>(),
+                               dHpp.as<double>(), dbp.as<double>());
+            hipLaunchKernelGGL(k_ba_reduce_point, dim3(LB), dim3(256), 0, 0, NL, dlo.as<int>(), dCll.as<double>(),
+                               dHll.as<double>(), dbl.as<double>());
+        }
+        hipLaunchKernelGGL(k_lm_chi2, dim3(EB), dim3(256), 0, 0, NE, cam.delta, dchi.as<double>(), d_active, dpart.as<double>());
+        B_TRY(hipMemcpy(part.data(), dpart.p, 8 * EB, hipMemcpyDeviceToHost));
+        double sum = 0.0;
+        for (int b = 0; b < EB; ++b) sum += part[b];
+        *chi_out = sum;
+        return ORBX_OK;
+    };
+
+    double lam = 0.0, ni = 2.0, chi_initial = 0.0, current = 0.0;
+    int its = 0, trials_total = 0, rc = ORBX_OK;
+    for (int it = 0; it < o->max_iterations; ++it) {
+        if ((rc = evaluate(true, &current))) return rc;
+        if (it == 0) {
+            chi_initial = current;
+            if (o->user_lambda_init > 0) lam = o->user_lambda_init;
+            else { // computeLambdaInit: tau * max |H_jj| over the free vertices
+                std::vector<double> hpp((size_t)36 * NP), hll((size_t)9 * NL);
+                B_TRY(hipMemcpy(hpp.data(), dHpp.p, 8 * 36 * NP, hipMemcpyDeviceToHost));
+                B_TRY(hipMemcpy(hll.data(), dHll.p, 8 * 9 * NL, hipMemcpyDeviceToHost));
+                double mx = 0.0;
+                for (int ip : free_pose)
+                    for (int k = 0; k < 6; ++k) mx = std::max(mx, std::fabs(hpp[(size_t)36 * ip + 7 * k]));
+                for (int l = 0; l < NL; ++l)
+                    for (int k = 0; k < 3; ++k) mx = std::max(mx, std::fabs(hll[(size_t)9 * l + 4 * k]));
+                lam = tau * mx;
+            }
+            ni = 2.0;
+        }
+        double rho = 0.0;
+        int qmax = 0;
+        do {
+            // push(): keep the estimates
+            B_TRY(hipMemcpyAsync(dRb.p, dR.p, 8 * 9 * NP, hipMemcpyDeviceToDevice, 0));
+            B_TRY(hipMemcpyAsync(dtb.p, dt.p, 8 * 3 * NP, hipMemcpyDeviceToDevice, 0));
+            B_TRY(hipMemcpyAsync(dPb.p, dP.p, 8 * 3 * NL, hipMemcpyDeviceToDevice, 0));
+            hipLaunchKernelGGL(k_lm_points, dim3(LB), dim3(256), 0, 0, NL, lam, dHll.as<double>(), dbl.as<double>(),
+                               dinv.as<double>(), dtl.as<double>());
+            hipLaunchKernelGGL(k_lm_schur, dim3(NF * (NF + 1) / 2), dim3(256), 0, 0, NF, NL, lam, dfree.as<int>(), deo.as<int>(),
+                               dHpp.as<double>(), dbp.as<double>(), dHlp.as<double>(), dinv.as<double>(), dtl.as<double>(),
+                               dS.as<double>(), drhs.as<double>());
+            hipLaunchKernelGGL(k_lm_chol_solve, dim3(1), dim3(256), 0, 0, N, dS.as<double>(), drhs.as<double>(), dxp.as<double>(),
+                               dflag.as<int>());
+            hipLaunchKernelGGL(k_lm_backsub, dim3(LB), dim3(256), 0, 0, NL, lam, dlo.as<int>(), dep.as<int>(), dslot.as<int>(),
+                               dHlp.as<double>(), dxp.as<double>(), dbl.as<double>(), dinv.as<double>(), dxl.as<double>(),
+                               dpart.as<double>() + EB);
+            hipLaunchKernelGGL(k_lm_update_poses, dim3(1), dim3(256), 0, 0, NF, lam, dfree.as<int>(), dxp.as<double>(),
+                               dbp.as<double>(), dR.as<double>(), dt.as<double>(), dpart.as<double>() + EB + LB);
+            hipLaunchKernelGGL(k_lm_update_points, dim3((3 * NL + 255) / 256), dim3(256), 0, 0, 3 * NL, dxl.as<double>(),
+                               dP.as<double>());
+            double temp = 0.0;
+            if ((rc = evaluate(false, &temp))) return rc;
+            int ok2 = 0;
+            B_TRY(hipMemcpy(&ok2, dflag.p, 4, hipMemcpyDeviceToHost));
+            B_TRY(hipMemcpy(part.data() + EB, dpart.as<double>() + EB, 8 * (LB + 1), hipMemcpyDeviceToHost));
+            if (!ok2) temp = std::numeric_limits<double>::max();
+            double scale = part[(size_t)EB + LB]; // poses first, then the points block by block
+            for (int b = 0; b < LB; ++b) scale += part[(size_t)EB + b];
+            scale += 1e-3;
+            rho = (current - temp) / scale;
+            ++trials_total;
+            if (rho > 0 && std::isfinite(temp)) {
+                double alpha = 1.0 - std::pow(2 * rho - 1, 3);
+                alpha = std::min(alpha, upper);
+                lam *= std::max(lower, alpha);
+                ni = 2.0;
+                current = temp;
+            } else {
+                lam *= ni;
+                ni *= 2;
+                // pop(): restore
+                B_TRY(hipMemcpyAsync(dR.p, dRb.p, 8 * 9 * NP, hipMemcpyDeviceToDevice, 0));
+                B_TRY(hipMemcpyAsync(dt.p, dtb.p, 8 * 3 * NP, hipMemcpyDeviceToDevice, 0));
+                B_TRY(hipMemcpyAsync(dP.p, dPb.p, 8 * 3 * NL, hipMemcpyDeviceToDevice, 0));
+                if (!std::isfinite(lam)) break;
+            }
+            ++qmax;
+        } while (rho < 0 && qmax < max_trials);
+        ++its;
+        if (qmax == max_trials || rho == 0 || !std::isfinite(lam)) break; // Terminate
+    }
+    double final_chi = 0.0;
+    if ((rc = evaluate(false, &final_chi))) return rc;
+    B_TRY(hipEventRecord(e1, 0));
+    B_TRY(hipEventSynchronize(e1));
+    B_TRY(hipGetLastError());
+    float ms = 0;
+    B_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    r->iterations = its;
+    r->trials = trials_total;
+    r->lambda = lam;
+    r->chi2_initial = o->max_iterations > 0 ? chi_initial : final_chi;
+    r->chi2_final = final_chi;
+    r->device_ms = ms;
+    if (r->pose_R) B_TRY(hipMemcpy(r->pose_R, dR.p, 8 * 9 * NP, hipMemcpyDeviceToHost));
+    if (r->pose_t) B_TRY(hipMemcpy(r->pose_t, dt.p, 8 * 3 * NP, hipMemcpyDeviceToHost));
+    if (r->points) B_TRY(hipMemcpy(r->points, dP.p, 8 * 3 * NL, hipMemcpyDeviceToHost));
+    if (r->chi2) B_TRY(hipMemcpy(r->chi2, dchi.p, 8 * NE, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// The optimisation part of Optimize::localBundleAdjustment (Optimize.cpp:892-922)
+extern "C" int orbba_local_bundle_adjustment(const orbba_problem *p, orbba_lm_result *r, uint8_t *outlier, int device)
+{
+    if (!p || !r) return orbx_set_error(ORBX_E_ARG, "null argument");
+    const int NP = p->n_poses, NL = p->n_points, NE = p->n_edges;
+    if (NP < 1 || NL < 1 || NE < 1) return orbx_set_error(ORBX_E_ARG, "bad sizes");
+    std::vector<double> R1((size_t)9 * NP), t1((size_t)3 * NP), P1((size_t)3 * NL), chi((size_t)NE);
+    orbba_lm_options o1 = {};
+    o1.max_iterations = 5; // optimizer.optimize(5), :893
+    orbba_lm_result r1 = {};
+    r1.pose_R = R1.data(); r1.pose_t = t1.data(); r1.points = P1.data(); r1.chi2 = chi.data();
+    int rc = orbba_optimize(p, &o1, &r1, device);
+    if (rc) return rc;
+    std::vector<uint8_t> active((size_t)NE);
+    for (int e = 0; e < NE; ++e) active[e] = !(chi[e] > 5.991); // :899-902
+    orbba_problem p2 = *p;
+    p2.pose_R = R1.data(); p2.pose_t = t1.data(); p2.points = P1.data();
+    p2.huber_delta = 0.0; // setRobustKernel(nullptr), :904
+    orbba_lm_options o2 = {};
+    o2.max_iterations = 10; // :909
+    o2.edge_active = active.data();
+    std::vector<double> chi2v((size_t)NE);
+    double *user_chi = r->chi2;
+    r->chi2 = chi2v.data();
+    rc = orbba_optimize(&p2, &o2, r, device);
+    r->chi2 = user_chi;
+    if (rc) return rc;
+    r->device_ms += r1.device_ms;
+    r->iterations += r1.iterations;
+    r->trials += r1.trials;
+    r->chi2_initial = r1.chi2_initial;
+    if (user_chi) std::copy(chi2v.begin(), chi2v.end(), user_chi);
+    if (outlier)
+        for (int e = 0; e < NE; ++e) outlier[e] = chi2v[e] > 5.991; // :917-921
     return ORBX_OK;
 }

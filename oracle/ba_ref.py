@@ -65,14 +65,127 @@ def linearize(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, ed
 
 
 def se3_exp(upd):
-    """g2o SE3Quat::exp for update = (omega, upsilon) (VertexSE3::oplusImpl, G2oTypes.h:112-115)."""
-    w, u = upd[:3], upd[3:]
-    th = np.linalg.norm(w)
+    """g2o SE3Quat::exp (g2o 20201223 types/slam3d/se3quat.h, not vendored) for update = (omega, upsilon), as used by
+    VertexSE3::oplusImpl (reference modules/Backend/G2oTypes.h:112-115): returns (R, t) of the increment."""
+    w, u = np.asarray(upd[:3], np.float64), np.asarray(upd[3:], np.float64)
+    th = np.sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2])
     K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
-    if th < 1e-12:
-        Rm = np.eye(3) + K
-        V = np.eye(3) + 0.5 * K
+    K2 = K @ K
+    if th < 0.00001:
+        Rm = np.eye(3) + K + 0.5 * K2
+        V = np.eye(3) + 0.5 * K + K2 / 6.0
     else:
-        Rm = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
-        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+        Rm = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / (th * th) * K2
+        V = np.eye(3) + (1 - np.cos(th)) / (th * th) * K + (th - np.sin(th)) / (th ** 3) * K2
     return Rm, V @ u
+
+
+def robust_chi2(chi2, huber_delta, active=None):
+    """SparseOptimizer::activeRobustChi2 with g2o's RobustKernelHuber: rho(e2) = e2 inside delta^2, 2 delta sqrt(e2) -
+    delta^2 outside; plain chi2 without a kernel (Optimize.cpp:904 removes it for the second round)."""
+    r = np.array(chi2, np.float64)
+    if huber_delta > 0:
+        out = r > huber_delta * huber_delta
+        r[out] = 2 * huber_delta * np.sqrt(r[out]) - huber_delta * huber_delta
+    if active is not None:
+        r = r[np.asarray(active, bool)]
+    return float(r.sum())
+
+
+def lm_optimize(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, edge_z, edge_inv_sigma2, huber_delta,
+                iterations, edge_active=None, tau=1e-5, max_trials=10, lower=1.0 / 3.0, upper=2.0 / 3.0):
+    """g2o's OptimizationAlgorithmLevenberg + BlockSolver_6_3 with marginalised points, restated densely
+    (g2o 20201223: optimization_algorithm_levenberg.cpp solve(), block_solver.hpp buildSystem/solve, sparse_optimizer.cpp
+    optimize()) for the graph Optimize::localBundleAdjustment builds (reference modules/Backend/Optimize.cpp:811-911).
+    Inactive edges (setLevel(1), Optimize.cpp:900-902) take no part.  Returns dict(pose_R, pose_t, points, chi2,
+    iterations, lam, chi2_initial, chi2_final, trials)."""
+    R = np.array(pose_R, np.float64).reshape(-1, 3, 3)
+    t = np.array(pose_t, np.float64).reshape(-1, 3)
+    P = np.array(points, np.float64).reshape(-1, 3)
+    fixed = np.asarray(pose_fixed, bool)
+    ep, el = np.asarray(edge_pose), np.asarray(edge_point)
+    act = np.ones(len(ep), bool) if edge_active is None else np.asarray(edge_active, bool)
+    free = np.flatnonzero(~fixed)
+    slot = -np.ones(len(fixed), int)
+    slot[free] = np.arange(len(free))
+    nf, nl = len(free), len(P)
+
+    def system(Rc, tc, Pc):
+        lin = linearize(cam, Rc, tc, fixed, Pc, ep[act], el[act], np.asarray(edge_z).reshape(-1, 2)[act],
+                        np.asarray(edge_inv_sigma2)[act], huber_delta)
+        Hpl = np.zeros((nf, 6, nl, 3))
+        es = slot[ep[act]]
+        ok = es >= 0
+        np.add.at(Hpl, (es[ok], slice(None), el[act][ok], slice(None)), np.transpose(lin["H_lp"][ok], (0, 2, 1)))
+        return lin, Hpl
+
+    def chi(Rc, tc, Pc):
+        e, _ = residual(cam, Rc[ep], tc[ep], Pc[el], np.asarray(edge_z, np.float64).reshape(-1, 2))
+        return np.asarray(edge_inv_sigma2, np.float64) * (e * e).sum(1)
+
+    lam, ni, its, trials_total = 0.0, 2.0, 0, 0
+    chi2_initial = robust_chi2(chi(R, t, P), huber_delta, act)
+    for it in range(iterations):
+        current = robust_chi2(chi(R, t, P), huber_delta, act)
+        lin, Hpl = system(R, t, P)
+        Hpp, bp, Hll, bl = lin["H_pp"][free], lin["b_p"][free], lin["H_ll"], lin["b_l"]
+        if it == 0:  # computeLambdaInit: tau * max |diagonal| over the free vertices
+            diag = np.concatenate([np.abs(np.einsum("nii->ni", Hpp)).ravel(), np.abs(np.einsum("nii->ni", Hll)).ravel()])
+            lam, ni = tau * float(diag.max()), 2.0
+        rho, qmax = 0.0, 0
+        while True:
+            Rb, tb, Pb = R.copy(), t.copy(), P.copy()  # push()
+            inv = np.linalg.inv(Hll + lam * np.eye(3))
+            T = np.einsum("panb,nbc->panc", Hpl, inv)  # Hpl * Hll^-1, block by block
+            S = -(T.reshape(nf * 6, nl * 3) @ Hpl.reshape(nf * 6, nl * 3).T)
+            for i in range(nf):
+                S[6 * i:6 * i + 6, 6 * i:6 * i + 6] += Hpp[i] + lam * np.eye(6)
+            rhs = bp.reshape(-1) - T.reshape(nf * 6, nl * 3) @ bl.reshape(-1)
+            ok2 = True
+            try:
+                Lc = np.linalg.cholesky(S)
+                xp = np.linalg.solve(Lc.T, np.linalg.solve(Lc, rhs))
+            except np.linalg.LinAlgError:
+                ok2, xp = False, np.zeros(nf * 6)
+            xl = np.einsum("nab,nb->na", inv, bl - (Hpl.reshape(nf * 6, nl, 3) * xp[:, None, None]).sum(0))
+            for i, ip in enumerate(free):  # VertexSE3::oplusImpl: exp(update) * estimate
+                dR, dt = se3_exp(xp[6 * i:6 * i + 6])
+                R[ip], t[ip] = dR @ R[ip], dR @ t[ip] + dt
+            P = P + xl  # Vertex3D::oplusImpl
+            temp = robust_chi2(chi(R, t, P), huber_delta, act) if ok2 else np.finfo(np.float64).max
+            scale = float((xp * (lam * xp + bp.reshape(-1))).sum() + (xl * (lam * xl + bl)).sum()) + 1e-3
+            rho = (current - temp) / scale
+            trials_total += 1
+            if rho > 0 and np.isfinite(temp):
+                alpha = min(1.0 - (2 * rho - 1) ** 3, upper)
+                lam *= max(lower, alpha)
+                ni = 2.0
+                current = temp
+            else:
+                lam *= ni
+                ni *= 2
+                R, t, P = Rb, tb, Pb  # pop()
+                if not np.isfinite(lam):
+                    break
+            qmax += 1
+            if not (rho < 0 and qmax < max_trials):
+                break
+        its += 1
+        if qmax == max_trials or rho == 0 or not np.isfinite(lam):
+            break  # Terminate: optimize() leaves its loop
+    final = chi(R, t, P)
+    return {"pose_R": R, "pose_t": t, "points": P, "chi2": final, "iterations": its, "lam": lam,
+            "chi2_initial": chi2_initial, "chi2_final": robust_chi2(final, huber_delta, act), "trials": trials_total}
+
+
+def local_bundle_adjustment(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, edge_z, edge_inv_sigma2,
+                            huber_delta):
+    """The optimisation part of Optimize::localBundleAdjustment (Optimize.cpp:892-922): optimize(5) with the Huber
+    kernel; edges with chi2 > 5.991 leave (setLevel(1)) and the kernel is removed; optimize(10); final outlier flags."""
+    a = lm_optimize(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, edge_z, edge_inv_sigma2, huber_delta, 5)
+    active = a["chi2"] <= 5.991
+    b = lm_optimize(cam, a["pose_R"], a["pose_t"], pose_fixed, a["points"], edge_pose, edge_point, edge_z, edge_inv_sigma2,
+                    0.0, 10, edge_active=active)
+    b["outlier"] = b["chi2"] > 5.991
+    b["first_round"] = a
+    return b

@@ -71,3 +71,101 @@ def test_gpu_matches_oracle(n_poses, n_points):
     if n_points == 3000:
         assert len(pr["edge_pose"]) > 20000
         print("BA linearise: %d edges, %.3f ms on device" % (len(pr["edge_pose"]), got["kernel_ms"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Levenberg-Marquardt with marginalised points (g2o's OptimizationAlgorithmLevenberg + BlockSolver_6_3)
+def _perturbed(n_poses, n_points, seed, outliers=0):
+    from oracle import ba_ref
+    pr = synth.make_ba_problem(n_poses, n_points, seed=seed, n_fixed=min(2, n_poses - 1))
+    rng = np.random.RandomState(seed)
+    R = np.array(pr["pose_R"]).reshape(-1, 3, 3).copy()
+    t = np.array(pr["pose_t"]).reshape(-1, 3).copy()
+    P = np.array(pr["points"]).reshape(-1, 3).copy()
+    for i in np.flatnonzero(~np.asarray(pr["pose_fixed"], bool)):
+        dR, dt = ba_ref.se3_exp(np.concatenate([rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3)]))
+        R[i], t[i] = dR @ R[i], dR @ t[i] + dt
+    P += rng.normal(0, 0.05, P.shape)
+    z = np.array(pr["edge_z"]).reshape(-1, 2).copy()
+    if outliers:
+        bad = rng.choice(len(z), outliers, replace=False)
+        z[bad] += rng.uniform(15, 60, (outliers, 2)) * rng.choice([-1, 1], (outliers, 2))
+    args = (pr["cam"], R, t, pr["pose_fixed"], P, pr["edge_pose"], pr["edge_point"], z, pr["edge_inv_sigma2"])
+    return pr, args
+
+
+def test_oracle_lm_converges_and_keeps_fixed_poses():
+    from oracle import ba_ref
+    pr, args = _perturbed(6, 200, 3)
+    out = ba_ref.lm_optimize(*args, float(np.sqrt(np.float32(5.991))), 10)
+    n_edges = len(pr["edge_pose"])
+    assert out["chi2_final"] < 0.15 * out["chi2_initial"]
+    assert out["chi2_final"] < 2.5 * n_edges  # 1-px noise at 1/sigma^2 <= 1: about two per edge at most
+    fixed = np.asarray(pr["pose_fixed"], bool)
+    assert np.array_equal(out["pose_R"][fixed], np.asarray(args[1])[fixed]) and np.array_equal(out["pose_t"][fixed], args[2][fixed])
+    # (depth along the viewing rays is weakly constrained with 1-px noise, so the distance to the generating points
+    #  is not a criterion; the reprojection error is)
+    # rotations stay orthonormal
+    assert np.abs(out["pose_R"] @ out["pose_R"].transpose(0, 2, 1) - np.eye(3)).max() < 1e-12
+
+
+def test_oracle_se3_exp_is_a_rigid_motion():
+    from oracle import ba_ref
+    for upd in (np.zeros(6), np.array([1e-7, -2e-7, 3e-7, 0.1, 0.2, 0.3]), np.array([0.3, -0.2, 0.1, 1, 2, 3])):
+        R, t = ba_ref.se3_exp(upd)
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(R) - 1) < 1e-12
+    assert np.allclose(ba_ref.se3_exp(np.array([0, 0, 0, 1, 2, 3.0]))[1], [1, 2, 3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_poses,n_points,huber", [(6, 200, True), (6, 200, False), (20, 3000, True)])
+def test_gpu_lm_matches_oracle(n_poses, n_points, huber):
+    """Same LM decisions (iteration / trial counts), estimates within 1e-6 relative of the numpy restatement: the two
+    differ only in summation order and in the dense Cholesky."""
+    from oracle import ba_ref
+    from monoorbslam3_amd import ba
+    pr, args = _perturbed(n_poses, n_points, 5)
+    delta = ba.HUBER_MONO if huber else 0.0
+    ref = ba_ref.lm_optimize(*args, delta, 6)
+    got = ba.optimize(*args, huber_delta=delta, iterations=6)
+    assert (got["iterations"], got["trials"]) == (ref["iterations"], ref["trials"])
+    assert abs(got["chi2_initial"] - ref["chi2_initial"]) <= 1e-9 * ref["chi2_initial"]
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"]
+    assert abs(got["lam"] - ref["lam"]) <= 1e-6 * ref["lam"]
+    for k in ("pose_R", "pose_t", "points"):
+        assert _close(got[k], ref[k], 1e-6), k
+    assert _close(got["chi2"], ref["chi2"], 1e-5)
+    assert got["chi2_final"] < 0.2 * got["chi2_initial"]
+    if n_points == 3000:
+        print("BA LM: %d edges, %d iterations / %d solves, %.2f ms on device" %
+              (len(pr["edge_pose"]), got["iterations"], got["trials"], got["device_ms"]))
+
+
+@pytest.mark.gpu
+def test_gpu_local_bundle_adjustment_rejects_outliers():
+    """Optimize.cpp:892-922 end to end: 40 gross outliers among ~1000 observations are flagged, the rest fit."""
+    from oracle import ba_ref
+    from monoorbslam3_amd import ba
+    pr, args = _perturbed(6, 200, 9, outliers=40)
+    ref = ba_ref.local_bundle_adjustment(*args, ba.HUBER_MONO)
+    got = ba.local_bundle_adjustment(*args)
+    # 40 gross outliers + the ~5 % tail of the 1-px noise beyond chi2 = 5.991
+    assert np.array_equal(got["outlier"], ref["outlier"]) and 40 <= got["outlier"].sum() <= 100
+    assert abs(got["chi2_final"] - ref["chi2_final"]) <= 1e-6 * ref["chi2_final"]
+    for k in ("pose_R", "pose_t", "points"):
+        assert _close(got[k], ref[k], 1e-6), k
+    assert got["chi2_final"] < 2.5 * (~got["outlier"]).sum()
+
+
+@pytest.mark.gpu
+def test_gpu_lm_argument_errors():
+    from monoorbslam3_amd import ba
+    pr, args = _perturbed(4, 30, 2)
+    all_fixed = list(args)
+    all_fixed[3] = np.ones(4, np.uint8)
+    with pytest.raises(Exception, match="fixed"):
+        ba.optimize(*all_fixed)
+    unsorted_edges = list(args)
+    unsorted_edges[6] = np.asarray(args[6])[::-1].copy()
+    with pytest.raises(Exception, match="grouped by point"):
+        ba.optimize(*unsorted_edges)
