@@ -335,8 +335,7 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(ORBX_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
-    orbx_ctx *c = new orbx_ctx();
-    memset(c, 0, sizeof *c);
+    orbx_ctx *c = new orbx_ctx(); // value-initialised: every member is zero
     c->cfg = *cfg;
     if (c->cfg.max_batch < 1) c->cfg.max_batch = 1;
     int dev = cfg->device;
