@@ -251,6 +251,20 @@ def main():
                 traffic = tj["bytes_per_launch"][dominant]
         except Exception:
             traffic = None
+    # VALU instructions per stage per step from a rocprofv3 --pmc SQ_INSTS_VALU pass (tools/pmc_valu.py): the bound these
+    # integer kernels actually sit under is VALU issue, calibrated at VALU_PEAK_GWINST on this chip
+    valu = None
+    vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
+    if os.path.exists(vpath):
+        try:
+            vj = json.load(open(vpath))
+            if vj.get("batch") == B:
+                valu = {k: {"wave_instr_per_step": int(n),
+                            "achieved_gwinst_s": round(n / (acc[k] * 1e-3) / 1e9, 1),
+                            "frac_of_calibrated_peak": round(n / (acc[k] * 1e-3) / 1e9 / VALU_PEAK_GWINST, 3)}
+                        for k, n in vj.get("wave_instr_per_step", {}).items() if k in acc and acc[k] > 0}
+        except Exception:
+            valu = None
     fb_ms = acc["fast"] + acc["orient_desc"]
     fast_brief_gbs = 2 * P * B / (fb_ms * 1e-3) / 1e9
     pairs = float((counts.astype(np.float64) * np.roll(counts, -1)).sum())
@@ -289,6 +303,7 @@ def main():
             "algorithmic_bytes_per_launch": alg[dominant] * B,
             "launch_ms": round(acc[dominant], 4),
         },
+        "valu_issue": {"peak_gwinst_s": VALU_PEAK_GWINST, "stages": valu},
         "roofline_fast_plus_brief": {"bound": "hbm", "achieved": round(fast_brief_gbs, 1), "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": round(fast_brief_gbs / HBM_PEAK_GBS, 4),
                                      "algorithmic_bytes_per_frame": 2 * P},

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 --pmc SQ_INSTS_VALU pass (counter_collection CSV) into profiles/pmc_valu.json: VALU wave-instructions
+per stage per step (all launches of the stage).  Usage: pmc_valu.py <pmc_dir> <batch> <out.json>"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_blur_cols": "blur", "k_blur_edges": "blur",
+         "k_octree_lds": "octree", "k_octree": "octree", "k_orient": "orient_desc", "k_orient_desc": "orient_desc",
+         "k_best2": "match_best2"}
+LAUNCHES_PER_STEP = {"k_resize": 7}
+
+
+def main():
+    root, batch, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    acc = defaultdict(list)
+    for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == "SQ_INSTS_VALU":
+                acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+    res, detail = defaultdict(float), {}
+    for k, v in acc.items():
+        if k not in STAGE:
+            continue
+        if k == "k_best2":  # bench launches a (B-1)-pair and a 1-pair problem per step: sum both
+            per_step = sum(v) / (len(v) / 2)
+        else:
+            per_step = sum(v) / len(v) * LAUNCHES_PER_STEP.get(k, 1)
+        res[STAGE[k]] += per_step
+        detail[k] = round(per_step)
+    json.dump({"batch": batch, "unit": "VALU wave-instructions per stage per step (SQ_INSTS_VALU, all launches)",
+               "wave_instr_per_step": {k: int(v) for k, v in res.items()}, "detail": detail}, open(out, "w"), indent=1)
+    print(json.dumps(dict(res)))
+
+
+if __name__ == "__main__":
+    main()
