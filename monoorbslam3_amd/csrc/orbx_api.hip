@@ -63,6 +63,12 @@ struct orbx_ctx {
     int n_sub;
     hipStream_t sub[8];
     hipEvent_t ev_fork, ev_join[8];
+    // The blur only needs the pyramid, FAST -> quadtree -> orientation only the raw levels: inside a frame range the
+    // blur runs on a side stream next to that chain and joins before the descriptor kernel.  Slot 8 serves the
+    // unsplit (small batch) case.
+    int side_blur;
+    hipStream_t side[9];
+    hipEvent_t ev_pyr[9], ev_blur[9];
     // stage timing
     int timing;
     hipEvent_t ev[ORBX_N_STAGES + 1];
@@ -357,6 +363,15 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
             return cleanup(fail(ORBX_E_NO_DEVICE, "sub-stream creation failed"));
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess)
         return cleanup(fail(ORBX_E_NO_DEVICE, "hipEventCreate failed"));
+    for (int i = 0; i < 9; ++i)
+        if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_pyr[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_blur[i], hipEventDisableTiming) != hipSuccess)
+            return cleanup(fail(ORBX_E_NO_DEVICE, "side-stream creation failed"));
+    {
+        const char *e = getenv("ORBX_SIDE_BLUR");
+        c->side_blur = e ? atoi(e) != 0 : 1;
+    }
     {
         const char *e = getenv("ORBX_STREAMS");
         c->n_sub = e ? std::min(std::max(atoi(e), 1), 8) : 4;
@@ -407,6 +422,11 @@ extern "C" void orbx_destroy(orbx_t *c)
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < 9; ++i) {
+        if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); }
+        if (c->ev_pyr[i]) (void)hipEventDestroy(c->ev_pyr[i]);
+        if (c->ev_blur[i]) (void)hipEventDestroy(c->ev_blur[i]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -462,7 +482,7 @@ static OrbxBuffers offset_buffers(const OrbxBuffers &a, int f0, int kcap_total)
 }
 
 static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs, int l0_pitch, int f0, int n_frames,
-                   orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n, bool t)
+                   orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n, bool t, int slot)
 {
     const OrbxLevels &LV = c->levels;
     const int L = LV.n_levels;
@@ -483,13 +503,23 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
                            n_frames);
     }
     if (t) HIP_TRY(hipEventRecord(c->ev[1], s));
+    const bool side = !t && c->side_blur && slot >= 0;
+    if (side) { // pyramid ready -> blur on the side stream
+        HIP_TRY(hipEventRecord(c->ev_pyr[slot], s));
+        HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_pyr[slot], 0));
+        orbx_launch_blur(c->side[slot], d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps,
+                         n_frames);
+        HIP_TRY(hipEventRecord(c->ev_blur[slot], c->side[slot]));
+    }
     orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_cells, c->n_fast_cells, n_frames);
     if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
-    orbx_launch_blur(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames);
+    if (!side)
+        orbx_launch_blur(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames);
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));
     orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes);
     if (t) HIP_TRY(hipEventRecord(c->ev[4], s));
-    orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames);
+    orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames,
+                            side ? c->ev_blur[slot] : nullptr);
     if (t) { HIP_TRY(hipEventRecord(c->ev[5], s)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
     return ORBX_OK;
@@ -502,12 +532,12 @@ static int enqueue_batch(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t
 {
     c->last_l0 = d_l0; c->last_l0_fs = l0_fs; c->last_l0_pitch = l0_pitch; c->last_frames = n_frames;
     const int ns = c->timing ? 1 : std::min(c->n_sub, n_frames / 8);
-    if (ns <= 1) return enqueue(c, s, d_l0, l0_fs, l0_pitch, 0, n_frames, d_kp, d_desc, cap, d_n, c->timing != 0);
+    if (ns <= 1) return enqueue(c, s, d_l0, l0_fs, l0_pitch, 0, n_frames, d_kp, d_desc, cap, d_n, c->timing != 0, 8);
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     for (int i = 0; i < ns; ++i) {
         const int f0 = (int)((long long)n_frames * i / ns), f1 = (int)((long long)n_frames * (i + 1) / ns);
         HIP_TRY(hipStreamWaitEvent(c->sub[i], c->ev_fork, 0));
-        int rc = enqueue(c, c->sub[i], d_l0, l0_fs, l0_pitch, f0, f1 - f0, d_kp, d_desc, cap, d_n, false);
+        int rc = enqueue(c, c->sub[i], d_l0, l0_fs, l0_pitch, f0, f1 - f0, d_kp, d_desc, cap, d_n, false, i);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(c->ev_join[i], c->sub[i]));
         HIP_TRY(hipStreamWaitEvent(s, c->ev_join[i], 0));

@@ -1364,11 +1364,12 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
 
 void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
-                             uint8_t *out_desc, int cap, int32_t *out_n, int n_frames)
+                             uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done)
 {
     const int pf_o = (levels.kcap_total + OR_KP - 1) / OR_KP, pf_d = (levels.kcap_total + 4 * DP_K - 1) / (4 * DP_K);
     hipLaunchKernelGGL(k_orient, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, b,
                        u_max, pf_o, n_frames);
+    if (blur_done) (void)hipStreamWaitEvent(s, blur_done, 0); // the blurred levels come from a side stream
     hipLaunchKernelGGL(k_orient_desc, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, d_levels, b, out_kp,
                        out_desc, cap, out_n, pf_d, n_frames);
 }
