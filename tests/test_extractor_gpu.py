@@ -119,6 +119,19 @@ def test_full_hd_config4(oracle_mod):
     assert ex.tap_level_counts(0).tolist() == orc.extract(img)[2]
 
 
+@pytest.mark.parametrize("nf", [2000, 10000])
+def test_uhd_frame(oracle_mod, nf):
+    """3840x2160 (8.3 Mpx, 9 200 FAST cells on level 0 alone): coordinates, candidate capacities and the quadtree's list
+    bounds far above the benchmark sizes; 10 000 features takes the global-scratch quadtree."""
+    w, h = 3840, 2160
+    ex, orc = _mk(oracle_mod, nf, w, h)
+    img = synth.make_frames(1, w, h, seed=99)[0]
+    kps, desc = ex(img)
+    _check_frame(ex, orc, img, kps, desc, stages=False)
+    assert ex.tap_level_counts(0).tolist() == orc.extract(img)[2]
+    assert kps["x"].max() > 3700 and kps["y"].max() > 2000
+
+
 def test_odd_sizes_and_strides(oracle_mod):
     """widths that are not multiples of 4 (blur / resize edge groups), tall images (nIni = 1), tiny top levels"""
     for (w, h, nf) in ((333, 251, 300), (405, 607, 500), (130, 97, 100)):
