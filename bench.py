@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="time extraction only")
+    ap.add_argument("--records", action="store_true",
+                    help="also build complete frame records per step: undistortion + grid (orbf) and bag of words on a "
+                         "synthetic ORBvoc-sized vocabulary (orbv); not the headline configuration")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank computes on cuda:0")
@@ -141,6 +144,17 @@ def main():
     d_sd = [torch.zeros((B, cap), dtype=torch.int16, device=dev) for _ in range(NBUF)]
     mh = MatcherHandle(device=local_rank)
     ML = _mlib()
+    rec = None
+    if args.records:  # SURVEY 8f rows 2 and 3 chained behind the extraction, all on device buffers
+        from monoorbslam3_amd.frame import FramePost
+        from monoorbslam3_amd.vocabulary import ORBVocabulary
+        fpost = FramePost(W, H, 718.856, 718.856, W / 2.0, H / 2.0, dist=(-0.2834, 0.0739, 1.9e-4, 1.8e-5), device=local_rank)
+        voc = ORBVocabulary.from_arrays(synth.make_vocabulary(10, 6, seed=1, p_early_leaf=0.0, p_stop=0.0), device=local_rank)
+        z = lambda shape, dt: [torch.zeros(shape, dtype=dt, device=dev) for _ in range(NBUF)]  # noqa: E731
+        rec = dict(fpost=fpost, voc=voc, kp_un=z((B, cap, 28), torch.uint8), cell_start=z((B, fpost.n_cells + 1), torch.int32),
+                   cell_items=z((B, cap), torch.int32), bow_ids=z((B, cap), torch.int32), bow_vals=z((B, cap), torch.float64),
+                   n_words=z((B,), torch.int32), fv_nodes=z((B, cap), torch.int32), fv_off=z((B, cap + 1), torch.int32),
+                   fv_idx=z((B, cap), torch.int32), n_fv=z((B,), torch.int32))
     # dedicated non-default streams: the C ABI treats a NULL stream as "the handle's own stream", and the RCCL
     # gather below must be ordered behind the kernels it depends on
     torch.cuda.synchronize()
@@ -180,6 +194,13 @@ def main():
             side.wait_event(ev_gathered[i])     # ... and its previous gather have finished
         ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, d_kp[i].data_ptr(), d_desc[i].data_ptr(), cap,
                                 d_n[i].data_ptr(), stream)
+        if rec:
+            rec["fpost"].post_device(B, d_kp[i].data_ptr(), d_n[i].data_ptr(), cap, rec["kp_un"][i].data_ptr(),
+                                     rec["cell_start"][i].data_ptr(), rec["cell_items"][i].data_ptr(), stream)
+            rec["voc"].transform_device(B, d_desc[i].data_ptr(), d_n[i].data_ptr(), cap, 4, rec["bow_ids"][i].data_ptr(),
+                                        rec["bow_vals"][i].data_ptr(), rec["n_words"][i].data_ptr(),
+                                        rec["fv_nodes"][i].data_ptr(), rec["fv_off"][i].data_ptr(),
+                                        rec["fv_idx"][i].data_ptr(), rec["n_fv"][i].data_ptr(), stream)
         ev_extracted[i].record(side)
         if not args.no_match:
             mstream.wait_event(ev_extracted[i])
@@ -283,11 +304,16 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": "KITTI 1242x375, 2000 feat, 8-level pyramid scale 1.2, FAST 20/7; extract + "
-                               "2000x2000 Hamming best-2 per frame" if (W, H, NF) == (1242, 375, 2000) else
+                               "2000x2000 Hamming best-2 per frame" + (" + frame records (undistort, grid, bag of words)" if args.records else "")
+                               if (W, H, NF) == (1242, 375, 2000) else
                                "%dx%d, %d feat" % (W, H, NF),
                    "frames_per_gpu_per_step": B, "width": W, "height": H, "n_features": NF,
-                   "match": not args.no_match, "parallelism": "frames sharded 1 batch/GPU, one gather of records to rank 0 per step"},
+                   "match": not args.no_match, "records": bool(args.records), "parallelism": "frames sharded 1 batch/GPU, one gather of records to rank 0 per step"},
         "keypoints_per_frame": round(kp_mean, 1),
+        "records": ({"words_per_frame": round(float(rec["n_words"][0].float().mean().item()), 1),
+                     "fv_nodes_per_frame": round(float(rec["n_fv"][0].float().mean().item()), 1),
+                     "grid_items_per_frame": round(float(rec["cell_start"][0][:, -1].float().mean().item()), 1)}
+                    if rec else None),
         "stages_ms": {k: round(v, 4) for k, v in acc.items()},
         "match_ms": round(match_ms, 4),
         "match_gpairs_per_s": round(pairs / (match_ms * 1e-3) / 1e9, 2) if match_ms > 0 else None,
