@@ -11,6 +11,9 @@
 
 namespace DBoW2 {
     typedef unsigned int NodeId;
+    typedef unsigned int WordId;
+    typedef double WordValue;
+    class BowVector : public std::map<WordId, WordValue> {};
     class FeatureVector : public std::map<NodeId, std::vector<unsigned int>> {
     public:
         void addFeature(NodeId id, unsigned int i_feature) { (*this)[id].push_back(i_feature); }

@@ -3,6 +3,8 @@
 #define ORBX_SHIM_USE_REF_MIRROR
 #include "ORBExtractor.h"
 #include "ORBMatcher.h"
+#include "ORBVocabulary.h"
+#include "FramePost.h"
 
 int shim_check_instantiate() {
     using namespace mono_orb_slam3;
@@ -15,5 +17,11 @@ int shim_check_instantiate() {
                            std::vector<int> &, int) const = &ORBMatcher::SearchForInitialization;
     int (*dd)(const cv::Mat &, const cv::Mat &) = &ORBMatcher::DescriptorDistance;
     float (*sf)(int) = &ORBExtractor::getScaleFactor;
-    return op && bow && tri && ini && dd && sf;
+    // Frame.cpp:175-176 and ORBVocabulary.cpp:10-25
+    void (Vocabulary::*tr)(const std::vector<cv::Mat> &, DBoW2::BowVector &, DBoW2::FeatureVector &, int) const = &Vocabulary::transform;
+    bool (*mk)(const std::string &) = &ORBVocabulary::createORBVocabulary;
+    const Vocabulary *(*get)() = &ORBVocabulary::getORBVocabulary;
+    bool (FramePost::*fp)(std::vector<cv::KeyPoint> &, std::vector<cv::KeyPoint> &,
+                          std::vector<std::vector<std::vector<size_t>>> &) const = &FramePost::operator();
+    return op && bow && tri && ini && dd && sf && tr && mk && get && fp;
 }

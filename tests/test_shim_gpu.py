@@ -64,3 +64,67 @@ def test_cpp_shim_end_to_end(oracle_mod, tmp_path):
     r_n, r_m = oracle_mod.search_for_triangulation(False, d1, k1["angle"], ok1, fv1, d2, k2["angle"], np.zeros(n2, np.uint8), fv2)
     assert n_tri == r_n and np.array_equal(m_tri, r_m)
     assert ORBMatcher.DescriptorDistance(d1[0], d2[0]) == int(np.unpackbits(d1[0] ^ d2[0]).sum())
+
+
+def test_cpp_frame_records_end_to_end(oracle_mod, tmp_path):
+    """compat/FramePost.h + compat/ORBVocabulary.h driven like Frame::Frame / Frame::computeBow, then SearchByBow on
+    the FeatureVectors they produce; every array equals the oracle's."""
+    from monoorbslam3_amd.extractor import KP_DTYPE
+    exe = str(tmp_path / "records_smoke")
+    lib = os.path.join(ROOT, "monoorbslam3_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "monoorbslam3_amd", "compat"),
+                           os.path.join(ROOT, "tests", "cpp", "records_smoke.cpp"), "-o", exe,
+                           "-L", lib, "-lorbx", "-Wl,-rpath," + lib])
+    w, h = 752, 480
+    canvas = synth.make_canvas(w + 40, h + 20, seed=4321)
+    frames = [np.ascontiguousarray(canvas[5:5 + h, 10:10 + w]), np.ascontiguousarray(canvas[7:7 + h, 14:14 + w])]
+    raw = tmp_path / "in.raw"
+    with open(raw, "wb") as f:
+        f.write(b"%d %d\n" % (w, h))
+        for fr in frames:
+            f.write(fr.tobytes())
+    voc = synth.make_vocabulary(10, 4, seed=21, flip_bits=60)
+    vpath = tmp_path / "voc.txt"
+    synth.write_vocabulary_text(voc, str(vpath))
+    out = tmp_path / "out.bin"
+    print(subprocess.check_output([exe, str(raw), str(vpath), str(out)], text=True))
+    buf = open(out, "rb").read()
+    orc = oracle_mod.Oracle(1000, 1.2, 8, 20, 7)
+    R = oracle_mod.Vocabulary(oracle_mod.parse_vocabulary_text(str(vpath)))
+    cam = dict(width=w, height=h, fx=458.654, fy=457.296, cx=367.215, cy=248.375)
+    dist = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)
+    o, recs = 0, []
+    for k in range(2):
+        n, nw, nf, cols, rows, n_bow = np.frombuffer(buf, np.int32, 6, o); o += 24
+        kraw = np.frombuffer(buf, KP_DTYPE, n, o); o += 28 * n
+        kun = np.frombuffer(buf, KP_DTYPE, n, o); o += 28 * n
+        desc = np.frombuffer(buf, np.uint8, 32 * n, o).reshape(n, 32); o += 32 * n
+        cells = []
+        for _ in range(cols * rows):
+            cnt = int(np.frombuffer(buf, np.int32, 1, o)[0]); o += 4
+            cells.append(np.frombuffer(buf, np.int32, cnt, o)); o += 4 * cnt
+        bow = np.frombuffer(buf, np.dtype([("id", "<u4"), ("v", "<f8")]), nw, o); o += 12 * nw
+        fv_nodes, fv_lists = [], []
+        for _ in range(nf):
+            node, cnt = np.frombuffer(buf, np.uint32, 2, o); o += 8
+            fv_nodes.append(node); fv_lists.append(np.frombuffer(buf, np.uint32, int(cnt), o)); o += 4 * int(cnt)
+        # extraction and Frame.cpp:24-51
+        ok, od, _ = orc.extract(frames[k])
+        assert n == len(ok) and np.array_equal(desc, od)
+        w_raw, w_un, w_start, w_items = oracle_mod.frame_post(**cam, dist=dist, kps=ok)
+        assert kraw.tobytes() == w_raw.tobytes() and kun.tobytes() == w_un.tobytes()
+        assert (cols, rows) == (19, 12)
+        for c in range(cols * rows):
+            assert np.array_equal(cells[c], w_items[w_start[c]:w_start[c + 1]])
+        # Frame::computeBow
+        wi, wv, (wn, wo, wx) = R.transform(od, 2)
+        assert np.array_equal(bow["id"], wi) and bow["v"].tobytes() == wv.tobytes()
+        assert np.array_equal(np.array(fv_nodes, np.uint32), wn)
+        for r in range(nf):
+            assert np.array_equal(fv_lists[r], wx[wo[r]:wo[r + 1]])
+        recs.append((kun, od, (wn, wo, wx), n_bow))
+    (k1, d1, fv1, n_bow), (k2, d2, fv2, _) = recs
+    r_n, _ = oracle_mod.search_by_bow(0.7, True, d1, k1["angle"], np.ones(len(k1), np.uint8), fv1, d2, k2["angle"],
+                                      np.full(len(k2), -1, np.int32), fv2)
+    assert n_bow == r_n and n_bow > 30

@@ -36,3 +36,37 @@ for bits, label in ((0, "dense: one node, 2000x2000 pairs"), (4, "16 nodes (~125
     print("%-36s SearchByBow %.3f ms (%d matches)   SearchForTriangulation %.3f ms" % (label, ms, nm, ms2))
 print("hamming_matrix 2000x2000 (8 MB out): %.3f ms;  best2 2000x2000: %.3f ms" % (
     timeit(lambda: ORBMatcher.hamming_matrix(a, b)), timeit(lambda: ORBMatcher.best2(a, b))))
+
+# ---- window searches on two extracted views (752x480, 2000 features), as the tracking thread calls them every frame
+import torch  # noqa: E402,F401  (loads the HIP runtime the library shares)
+from monoorbslam3_amd.extractor import ORBExtractor  # noqa: E402
+
+w, h = 752, 480
+canvas = synth.make_canvas(w + 40, h + 20, seed=909)
+f1 = np.ascontiguousarray(canvas[5:5 + h, 10:10 + w])
+f2 = np.ascontiguousarray(canvas[9:9 + h, 16:16 + w])
+ex = ORBExtractor(2000, 1.2, 8, 20, 7)
+k1, d1 = ex(f1)
+k2, d2 = ex(f2)
+n1, n2 = len(k1), len(k2)
+q_xy = np.stack([k1["x"] - 6.0 + rng.normal(0, 1.5, n1), k1["y"] - 4.0 + rng.normal(0, 1.5, n1)], axis=1).astype(np.float32)
+q_ok = np.ones(n1, np.uint8)
+mp = np.full(n2, -1, np.int32)
+m9 = ORBMatcher(0.9, True)
+ms = timeit(lambda: m9.SearchByProjectionFrame(d1, q_xy, (7.0 * k1["size"]).astype(np.float32), k1["octave"], k1["angle"], q_ok,
+                                              k2, d2, w, h, mp))
+nm = m9.SearchByProjectionFrame(d1, q_xy, (7.0 * k1["size"]).astype(np.float32), k1["octave"], k1["angle"], q_ok, k2, d2, w, h, mp)[0]
+print("SearchByProjection(last frame -> frame), %d queries, radius 7*size: %.3f ms (%d matches)" % (n1, ms, nm))
+q_level = k1["octave"].astype(np.int32)
+q_radius = (4.0 * 1.2 ** q_level).astype(np.float32)
+ms = timeit(lambda: ORBMatcher(0.8, True).SearchByProjectionPoints(d1, q_xy, q_radius, q_level, q_ok, k2, d2, w, h, mp))
+print("SearchByProjection(map points -> frame), %d queries: %.3f ms" % (n1, ms))
+pre = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+ms = timeit(lambda: m9.SearchForInitialization(k1, d1, k2, d2, w, h, pre.copy(), 100))
+print("SearchForInitialization (window 100): %.3f ms" % ms)
+# map-point descriptors: 3000 points x 2..12 observations
+sizes = rng.randint(2, 13, 3000)
+off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+obs = rng.randint(0, 256, (int(off[-1]), 32)).astype(np.uint8)
+print("ComputeDistinctiveDescriptors, 3000 points / %d observations: %.3f ms" % (off[-1],
+      timeit(lambda: ORBMatcher.ComputeDistinctiveDescriptors(obs, off))))
