@@ -83,6 +83,33 @@ int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o, orbba_lm_r
  * optimize(10); outlier[e] = final chi2 > 5.991 (the observations the reference then erases).  outlier may be NULL. */
 int orbba_local_bundle_adjustment(const orbba_problem *p, orbba_lm_result *r, uint8_t *outlier, int device);
 
+/* Optimize::poseOptimize (modules/Backend/Optimize.cpp:444-545) for a batch of frames at once: per frame one
+ * VertexSE3 and one EdgeSE3Project3DOnlyPose (G2oTypes.h:209-236, G2oTypes.cpp:27-34) per matched map point; four rounds
+ * of optimize(10), each restarted from the frame's initial pose on the edges the previous round left as inliers
+ * (chi2 <= 5.991), Huber kernel throughout (the `iter == 2` test at :518 never fires).  Frames with fewer than three
+ * correspondences come back unchanged with n_inliers = 0 (:491). */
+typedef struct orbba_pose_problem {
+    double fx, fy, cx, cy;
+    double huber_delta;             /* (double)sqrtf(5.991), :466 */
+    int32_t n_frames;
+    int32_t rounds, iterations;     /* 0 = the reference's 4 and 10 (:495) */
+    const int32_t *edge_off;        /* n_frames + 1: frame f owns edges [edge_off[f], edge_off[f+1]) */
+    const double *pose_R, *pose_t;  /* n_frames x 9 / x 3: frame->T_cw */
+    const double *points;           /* n_edges x 3: mp->getPos() */
+    const double *edge_z;           /* n_edges x 2: kp.pt */
+    const double *edge_inv_sigma2;  /* n_edges: 1 / kp.size^2 (:478) */
+} orbba_pose_problem;
+
+typedef struct orbba_pose_result {
+    double *pose_R, *pose_t;  /* n_frames x 9 / x 3 */
+    uint8_t *inlier;          /* n_edges: 0 = the map point the reference drops from the frame (:531-537) */
+    int32_t *n_inliers;       /* n_frames: the return value of poseOptimize */
+    double *chi2;             /* n_edges at the final pose, may be NULL */
+    float kernel_ms;
+} orbba_pose_result;
+
+int orbba_pose_optimize_batch(const orbba_pose_problem *p, orbba_pose_result *r, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,3 +120,39 @@ def local_bundle_adjustment(cam, pose_R, pose_t, pose_fixed, points, edge_pose, 
     _lib.check(fn(C.byref(prob), C.byref(res), outlier.ctypes.data, device))
     out["outlier"] = outlier.astype(bool)
     return _lm_finish(out, res)
+
+
+class _PoseProblem(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("huber_delta", C.c_double),
+                ("n_frames", C.c_int32), ("rounds", C.c_int32), ("iterations", C.c_int32), ("edge_off", C.c_void_p),
+                ("pose_R", C.c_void_p), ("pose_t", C.c_void_p), ("points", C.c_void_p), ("edge_z", C.c_void_p),
+                ("edge_inv_sigma2", C.c_void_p)]
+
+
+class _PoseResult(C.Structure):
+    _fields_ = [("pose_R", C.c_void_p), ("pose_t", C.c_void_p), ("inlier", C.c_void_p), ("n_inliers", C.c_void_p),
+                ("chi2", C.c_void_p), ("kernel_ms", C.c_float)]
+
+
+def pose_optimize_batch(cam, pose_R, pose_t, edge_off, points, edge_z, edge_inv_sigma2, huber_delta=HUBER_MONO, device=-1):
+    """Optimize::poseOptimize (Optimize.cpp:444-545) for many frames at once; frame f owns edges
+    edge_off[f]:edge_off[f+1].  Returns dict(pose_R, pose_t, inlier, n_inliers, chi2, kernel_ms)."""
+    L = _lib.lib()
+    fn = L.orbba_pose_optimize_batch
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(_PoseProblem), C.POINTER(_PoseResult), C.c_int]
+    f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+    R, t = f8(pose_R).reshape(-1, 9), f8(pose_t).reshape(-1, 3)
+    off = np.ascontiguousarray(edge_off, dtype=np.int32)
+    P, z, w = f8(points).reshape(-1, 3), f8(edge_z).reshape(-1, 2), f8(edge_inv_sigma2).reshape(-1)
+    B, ne = len(R), int(off[-1])
+    out = {"pose_R": np.zeros((B, 3, 3)), "pose_t": np.zeros((B, 3)), "inlier": np.zeros(max(ne, 1), np.uint8),
+           "n_inliers": np.zeros(B, np.int32), "chi2": np.zeros(max(ne, 1))}
+    vp = lambda a: a.ctypes.data  # noqa: E731
+    prob = _PoseProblem(cam[0], cam[1], cam[2], cam[3], huber_delta, B, 0, 0, vp(off), vp(R), vp(t), vp(P), vp(z), vp(w))
+    res = _PoseResult(vp(out["pose_R"]), vp(out["pose_t"]), vp(out["inlier"]), vp(out["n_inliers"]), vp(out["chi2"]), 0.0)
+    _lib.check(fn(C.byref(prob), C.byref(res), device))
+    out["inlier"] = out["inlier"][:ne].astype(bool)
+    out["chi2"] = out["chi2"][:ne]
+    out["kernel_ms"] = float(res.kernel_ms)
+    return out

@@ -730,3 +730,310 @@ extern "C" int orbba_local_bundle_adjustment(const orbba_problem *p, orbba_lm_re
         for (int e = 0; e < NE; ++e) outlier[e] = chi2v[e] > 5.991; // :917-921
     return ORBX_OK;
 }
+
+
+// =====================================================================================================================
+// Optimize::poseOptimize (modules/Backend/Optimize.cpp:444-545) for a batch of frames: one workgroup runs one frame's
+// whole procedure -- four rounds of (restart from the initial pose, up to ten Levenberg-Marquardt iterations on the
+// inlier edges with the Huber kernel, re-classification of every edge at chi2 <= 5.991) -- without leaving the kernel.
+// The 6x6 system is reduced over the edges in a fixed order (strided per thread, wave shuffles, four partials) and then
+// solved redundantly by every lane, so all control flow is uniform across the workgroup.
+// =====================================================================================================================
+__device__ __forceinline__ void se3_exp_apply(const double *u, double *R, double *t)
+{
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double th = sqrt(wx * wx + wy * wy + wz * wz);
+    const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double K2[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) K2[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+    double ra, rb, va, vb;
+    if (th < 0.00001) { ra = 1.0; rb = 0.5; va = 0.5; vb = 1.0 / 6.0; }
+    else {
+        ra = sin(th) / th; rb = (1.0 - cos(th)) / (th * th);
+        va = rb; vb = (th - sin(th)) / (th * th * th);
+    }
+    double E[9], V[9], Rn[9], tn[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double I = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+        E[k] = I + ra * K[k] + rb * K2[k];
+        V[k] = I + va * K[k] + vb * K2[k];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Rn[3 * r + c] = E[3 * r] * R[c] + E[3 * r + 1] * R[3 + c] + E[3 * r + 2] * R[6 + c];
+        tn[r] = (E[3 * r] * t[0] + E[3 * r + 1] * t[1] + E[3 * r + 2] * t[2]) + (V[3 * r] * u[3] + V[3 * r + 1] * u[4] + V[3 * r + 2] * u[5]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = Rn[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = tn[k];
+}
+
+// all 256 threads get the sum of v[0..K) over the workgroup, summed in a fixed order
+template <int K> __device__ __forceinline__ void block_sum_vals(double *v, double (*red)[28])
+{
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        v[k] = x;
+    }
+    __syncthreads(); // the previous round's readers are done
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+}
+
+// solves (H + lam I) x = b for the symmetric 6x6 H given by its 21 upper-triangular entries; false if not positive definite
+__device__ __forceinline__ bool solve6(const double *h21, double lam, const double *b, double *x)
+{
+    double L[36];
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) { L[6 * j + i] = h21[k] + (i == j ? lam : 0.0); ++k; } // lower triangle
+    for (int c = 0; c < 6; ++c) {
+        double d = L[6 * c + c];
+        for (int m = 0; m < c; ++m) d -= L[6 * c + m] * L[6 * c + m];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        L[6 * c + c] = d;
+        for (int r = c + 1; r < 6; ++r) {
+            double v = L[6 * r + c];
+            for (int m = 0; m < c; ++m) v -= L[6 * r + m] * L[6 * c + m];
+            L[6 * r + c] = v / d;
+        }
+    }
+    double y[6];
+    for (int r = 0; r < 6; ++r) {
+        double v = b[r];
+        for (int m = 0; m < r; ++m) v -= L[6 * r + m] * y[m];
+        y[r] = v / L[6 * r + r];
+    }
+    for (int r = 5; r >= 0; --r) {
+        double v = y[r];
+        for (int m = r + 1; m < 6; ++m) v -= L[6 * m + r] * x[m];
+        x[r] = v / L[6 * r + r];
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, int iterations, const int *__restrict__ edge_off,
+                                                       const double *__restrict__ R0, const double *__restrict__ t0,
+                                                       const double *__restrict__ Pw, const double *__restrict__ z,
+                                                       const double *__restrict__ w, double *__restrict__ R_out,
+                                                       double *__restrict__ t_out, uint8_t *__restrict__ inlier,
+                                                       int *__restrict__ n_inliers, double *__restrict__ chi2_out)
+{
+    __shared__ double red[4][28];
+    const int f = blockIdx.x, tid = threadIdx.x, e0 = edge_off[f], n = edge_off[f + 1] - e0;
+    double Ri[9], ti[3], R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = Ri[k] = R0[(size_t)f * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = ti[k] = t0[(size_t)f * 3 + k];
+    for (int e = tid; e < n; e += 256) inlier[e0 + e] = 1;
+    const double d2 = cam.delta * cam.delta;
+
+    // residual of edge e at pose (R, t); returns chi2, optionally the pieces needed for the Jacobian
+    auto edge_chi = [&](int e, const double *Rc, const double *tc, double *ex, double *ey, double *Pc) -> double {
+        const double *P = Pw + (size_t)(e0 + e) * 3;
+        const double X = Rc[0] * P[0] + Rc[1] * P[1] + Rc[2] * P[2] + tc[0];
+        const double Y = Rc[3] * P[0] + Rc[4] * P[1] + Rc[5] * P[2] + tc[1];
+        const double Z = Rc[6] * P[0] + Rc[7] * P[1] + Rc[8] * P[2] + tc[2];
+        const double u = cam.fx * (X / Z) + cam.cx, v = cam.fy * (Y / Z) + cam.cy;
+        *ex = z[(size_t)(e0 + e) * 2] - u;
+        *ey = z[(size_t)(e0 + e) * 2 + 1] - v;
+        Pc[0] = X; Pc[1] = Y; Pc[2] = Z;
+        return w[e0 + e] * (*ex * *ex + *ey * *ey);
+    };
+    auto robust_sum = [&](const double *Rc, const double *tc) -> double { // activeRobustChi2
+        double s[1] = {0.0};
+        for (int e = tid; e < n; e += 256) {
+            if (!inlier[e0 + e]) continue;
+            double ex, ey, Pc[3];
+            double c = edge_chi(e, Rc, tc, &ex, &ey, Pc);
+            if (cam.delta > 0.0 && c > d2) c = 2.0 * cam.delta * sqrt(c) - d2;
+            s[0] += c;
+        }
+        block_sum_vals<1>(s, red);
+        return s[0];
+    };
+
+    if (n >= 3) { // fewer than three correspondences: nothing is done (:491)
+        for (int round = 0; round < rounds; ++round) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R[k] = Ri[k]; // vPose->setEstimate(Tcw) (:497)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t[k] = ti[k];
+            double cnt[1] = {0.0};
+            for (int e = tid; e < n; e += 256) cnt[0] += inlier[e0 + e] ? 1.0 : 0.0;
+            block_sum_vals<1>(cnt, red);
+            double lam = 0.0, ni = 2.0;
+            if (cnt[0] > 0.0) {
+                for (int it = 0; it < iterations; ++it) {
+                    // computeActiveErrors + buildSystem
+                    double acc[28];
+#pragma unroll
+                    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+                    for (int e = tid; e < n; e += 256) {
+                        if (!inlier[e0 + e]) continue;
+                        double ex, ey, Pc[3];
+                        const double c = edge_chi(e, R, t, &ex, &ey, Pc);
+                        double rw = 1.0, rc = c;
+                        if (cam.delta > 0.0 && c > d2) { rw = cam.delta / sqrt(c); rc = 2.0 * cam.delta * sqrt(c) - d2; }
+                        const double W = rw * w[e0 + e], X = Pc[0], Y = Pc[1], Z = Pc[2];
+                        const double Jp[6] = {cam.fx / Z, 0.0, -cam.fx * X / (Z * Z), 0.0, cam.fy / Z, -cam.fy * Y / (Z * Z)};
+                        double Jq[12];
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const double a = Jp[3 * r], b = Jp[3 * r + 1], cc = Jp[3 * r + 2];
+                            Jq[6 * r + 0] = b * Z - cc * Y;
+                            Jq[6 * r + 1] = -a * Z + cc * X;
+                            Jq[6 * r + 2] = a * Y - b * X;
+                            Jq[6 * r + 3] = -a; Jq[6 * r + 4] = -b; Jq[6 * r + 5] = -cc;
+                        }
+                        int k = 0;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i)
+#pragma unroll
+                            for (int j = i; j < 6; ++j) acc[k++] += W * (Jq[i] * Jq[j] + Jq[6 + i] * Jq[6 + j]);
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) acc[21 + i] += -W * (Jq[i] * ex + Jq[6 + i] * ey);
+                        acc[27] += rc;
+                    }
+                    block_sum_vals<28>(acc, red);
+                    double current = acc[27];
+                    const double *h21 = acc, *b = acc + 21;
+                    if (it == 0) { // computeLambdaInit
+                        double mx = 0.0;
+                        int k = 0;
+                        for (int i = 0; i < 6; ++i) { mx = fmax(mx, fabs(h21[k])); k += 6 - i; }
+                        lam = 1e-5 * mx;
+                        ni = 2.0;
+                    }
+                    double rho = 0.0;
+                    int qmax = 0;
+                    do {
+                        double Rb[9], tb[3], x[6];
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) Rb[k] = R[k];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) tb[k] = t[k];
+                        const bool ok2 = solve6(h21, lam, b, x);
+                        if (!ok2)
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) x[k] = 0.0;
+                        se3_exp_apply(x, R, t);
+                        double temp = robust_sum(R, t);
+                        if (!ok2) temp = 1.7976931348623157e308;
+                        double scale = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) scale += x[k] * (lam * x[k] + b[k]);
+                        scale += 1e-3;
+                        rho = (current - temp) / scale;
+                        if (rho > 0 && isfinite(temp)) {
+                            double alpha = 1.0 - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+                            alpha = fmin(alpha, 2.0 / 3.0);
+                            lam *= fmax(1.0 / 3.0, alpha);
+                            ni = 2.0;
+                            current = temp;
+                        } else {
+                            lam *= ni;
+                            ni *= 2;
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) R[k] = Rb[k];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) t[k] = tb[k];
+                            if (!isfinite(lam)) break;
+                        }
+                        ++qmax;
+                    } while (rho < 0 && qmax < 10);
+                    if (qmax == 10 || rho == 0 || !isfinite(lam)) break;
+                }
+            }
+            // :503-516 -- every edge is re-evaluated at the round's pose
+            __syncthreads();
+            for (int e = tid; e < n; e += 256) {
+                double ex, ey, Pc[3];
+                const double c = edge_chi(e, R, t, &ex, &ey, Pc);
+                inlier[e0 + e] = !(c > 5.991);
+            }
+            __syncthreads();
+        }
+    }
+    double cnt[1] = {0.0};
+    for (int e = tid; e < n; e += 256) {
+        double ex, ey, Pc[3];
+        const double c = edge_chi(e, R, t, &ex, &ey, Pc);
+        if (chi2_out) chi2_out[e0 + e] = c;
+        cnt[0] += (n >= 3 && inlier[e0 + e]) ? 1.0 : 0.0;
+    }
+    block_sum_vals<1>(cnt, red);
+    if (tid == 0) {
+        n_inliers[f] = (int)cnt[0];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R_out[(size_t)f * 9 + k] = R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t_out[(size_t)f * 3 + k] = t[k];
+    }
+}
+
+extern "C" int orbba_pose_optimize_batch(const orbba_pose_problem *p, orbba_pose_result *r, int device)
+{
+    if (!p || !r) return orbx_set_error(ORBX_E_ARG, "null argument");
+    if (p->n_frames < 1 || !p->edge_off || !p->pose_R || !p->pose_t) return orbx_set_error(ORBX_E_ARG, "bad sizes / null arrays");
+    const int B = p->n_frames, NE = p->edge_off[B];
+    for (int f = 0; f < B; ++f)
+        if (p->edge_off[f + 1] < p->edge_off[f] || p->edge_off[0] != 0)
+            return orbx_set_error(ORBX_E_ARG, "edge offsets must start at 0 and be non-decreasing");
+    if (NE > 0 && (!p->points || !p->edge_z || !p->edge_inv_sigma2)) return orbx_set_error(ORBX_E_ARG, "null edge array");
+    if (!r->pose_R || !r->pose_t || !r->n_inliers || (NE > 0 && !r->inlier)) return orbx_set_error(ORBX_E_ARG, "null output array");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return orbx_set_error(ORBX_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device >= 0) B_TRY(hipSetDevice(device));
+    Dev doff, dR0, dt0, dP, dz, dw, dR, dt, din, dni, dchi;
+    B_TRY(doff.alloc(4 * (B + 1))); B_TRY(dR0.alloc(8 * 9 * B)); B_TRY(dt0.alloc(8 * 3 * B)); B_TRY(dP.alloc((size_t)24 * NE));
+    B_TRY(dz.alloc((size_t)16 * NE)); B_TRY(dw.alloc((size_t)8 * NE)); B_TRY(dR.alloc(8 * 9 * B)); B_TRY(dt.alloc(8 * 3 * B));
+    B_TRY(din.alloc(NE)); B_TRY(dni.alloc(4 * B)); B_TRY(dchi.alloc((size_t)8 * NE));
+    B_TRY(hipMemcpy(doff.p, p->edge_off, 4 * (B + 1), hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dR0.p, p->pose_R, 8 * 9 * B, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(dt0.p, p->pose_t, 8 * 3 * B, hipMemcpyHostToDevice));
+    if (NE) {
+        B_TRY(hipMemcpy(dP.p, p->points, (size_t)24 * NE, hipMemcpyHostToDevice));
+        B_TRY(hipMemcpy(dz.p, p->edge_z, (size_t)16 * NE, hipMemcpyHostToDevice));
+        B_TRY(hipMemcpy(dw.p, p->edge_inv_sigma2, (size_t)8 * NE, hipMemcpyHostToDevice));
+    }
+    const BaCam cam = {p->fx, p->fy, p->cx, p->cy, p->huber_delta};
+    hipEvent_t e0, e1;
+    B_TRY(hipEventCreate(&e0)); B_TRY(hipEventCreate(&e1));
+    B_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_pose_optimize, dim3(B), dim3(256), 0, 0, cam, p->rounds > 0 ? p->rounds : 4,
+                       p->iterations > 0 ? p->iterations : 10, doff.as<int>(), dR0.as<double>(), dt0.as<double>(), dP.as<double>(),
+                       dz.as<double>(), dw.as<double>(), dR.as<double>(), dt.as<double>(), din.as<uint8_t>(), dni.as<int>(),
+                       dchi.as<double>());
+    B_TRY(hipEventRecord(e1, 0));
+    B_TRY(hipEventSynchronize(e1));
+    B_TRY(hipGetLastError());
+    float ms = 0;
+    B_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    r->kernel_ms = ms;
+    B_TRY(hipMemcpy(r->pose_R, dR.p, 8 * 9 * B, hipMemcpyDeviceToHost));
+    B_TRY(hipMemcpy(r->pose_t, dt.p, 8 * 3 * B, hipMemcpyDeviceToHost));
+    B_TRY(hipMemcpy(r->n_inliers, dni.p, 4 * B, hipMemcpyDeviceToHost));
+    if (NE) B_TRY(hipMemcpy(r->inlier, din.p, NE, hipMemcpyDeviceToHost));
+    if (NE && r->chi2) B_TRY(hipMemcpy(r->chi2, dchi.p, (size_t)8 * NE, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}

@@ -189,3 +189,84 @@ def local_bundle_adjustment(cam, pose_R, pose_t, pose_fixed, points, edge_pose, 
     b["outlier"] = b["chi2"] > 5.991
     b["first_round"] = a
     return b
+
+
+def pose_optimize(cam, R0, t0, Pw, z, inv_sigma2, huber_delta, rounds=4, iterations=10, tau=1e-5, max_trials=10,
+                  lower=1.0 / 3.0, upper=2.0 / 3.0):
+    """Optimize::poseOptimize (reference modules/Backend/Optimize.cpp:444-545) for one frame: a single VertexSE3 and one
+    EdgeSE3Project3DOnlyPose (G2oTypes.h:209-236, G2oTypes.cpp:27-34) per matched map point, Huber kernel on every edge;
+    four rounds of optimize(10), each restarted from the initial pose (:497) on the edges classified as inliers by the
+    previous round (chi2 <= 5.991, :506-516; the `iter == 2` test at :518 never fires, so the kernel stays).  The LM loop
+    is g2o 20201223's OptimizationAlgorithmLevenberg on the 6x6 system.  Returns dict(R, t, inlier, n_inliers, chi2)."""
+    fx, fy, cx, cy = cam
+    R0 = np.array(R0, np.float64).reshape(3, 3)
+    t0 = np.array(t0, np.float64).reshape(3)
+    Pw = np.asarray(Pw, np.float64).reshape(-1, 3)
+    z = np.asarray(z, np.float64).reshape(-1, 2)
+    om = np.asarray(inv_sigma2, np.float64)
+    n = len(Pw)
+    inlier = np.ones(n, bool)
+    def err(R, t):
+        Pc = Pw @ R.T + t
+        e = z - np.stack([fx * (Pc[:, 0] / Pc[:, 2]) + cx, fy * (Pc[:, 1] / Pc[:, 2]) + cy], 1)
+        return e, Pc
+
+    def chi_of(R, t):
+        e, _ = err(R, t)
+        return om * (e * e).sum(1)
+
+    if n < 3:  # :491
+        return {"R": R0, "t": t0, "inlier": inlier, "n_inliers": 0, "chi2": chi_of(R0, t0)}
+    R, t = R0, t0
+    for _ in range(rounds):
+        R, t = R0.copy(), t0.copy()  # vPose->setEstimate(Tcw) (:497)
+        act = inlier.copy()          # initializeOptimization(0): level-0 edges
+        lam, ni = 0.0, 2.0
+        if act.any():
+            for it in range(iterations):
+                e, Pc = err(R, t)
+                chi = om * (e * e).sum(1)
+                current = robust_chi2(chi, huber_delta, act)
+                X, Y, Z = Pc[:, 0], Pc[:, 1], Pc[:, 2]
+                zero = np.zeros_like(X)
+                Jp = np.stack([np.stack([fx / Z, zero, -fx * X / (Z * Z)], 1), np.stack([zero, fy / Z, -fy * Y / (Z * Z)], 1)], 1)
+                Jq = np.concatenate([Jp @ hat(Pc), -Jp], axis=2)
+                rw = np.ones(n)
+                out = chi > huber_delta * huber_delta
+                rw[out] = huber_delta / np.sqrt(chi[out])
+                W = np.where(act, rw * om, 0.0)
+                H = np.einsum("e,eki,ekj->ij", W, Jq, Jq)
+                b = -np.einsum("e,eki,ek->i", W, Jq, e)
+                if it == 0:
+                    lam, ni = tau * float(np.abs(np.diag(H)).max()), 2.0
+                rho, qmax = 0.0, 0
+                while True:
+                    Rb, tb = R, t
+                    try:
+                        Lc = np.linalg.cholesky(H + lam * np.eye(6))
+                        x = np.linalg.solve(Lc.T, np.linalg.solve(Lc, b))
+                        ok2 = True
+                    except np.linalg.LinAlgError:
+                        x, ok2 = np.zeros(6), False
+                    dR, dt = se3_exp(x)
+                    R, t = dR @ R, dR @ t + dt
+                    temp = robust_chi2(chi_of(R, t), huber_delta, act) if ok2 else np.finfo(np.float64).max
+                    scale = float((x * (lam * x + b)).sum()) + 1e-3
+                    rho = (current - temp) / scale
+                    if rho > 0 and np.isfinite(temp):
+                        lam *= max(lower, min(1.0 - (2 * rho - 1) ** 3, upper))
+                        ni = 2.0
+                        current = temp
+                    else:
+                        lam *= ni
+                        ni *= 2
+                        R, t = Rb, tb
+                        if not np.isfinite(lam):
+                            break
+                    qmax += 1
+                    if not (rho < 0 and qmax < max_trials):
+                        break
+                if qmax == max_trials or rho == 0 or not np.isfinite(lam):
+                    break
+        inlier = ~(chi_of(R, t) > 5.991)  # :503-516 (outliers get computeError() first, so every edge is re-evaluated)
+    return {"R": R, "t": t, "inlier": inlier, "n_inliers": int(inlier.sum()), "chi2": chi_of(R, t)}

@@ -169,3 +169,63 @@ def test_gpu_lm_argument_errors():
     unsorted_edges[6] = np.asarray(args[6])[::-1].copy()
     with pytest.raises(Exception, match="grouped by point"):
         ba.optimize(*unsorted_edges)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Optimize::poseOptimize for a batch of frames (a14b)
+def _pose_frames(sizes, seed, outlier_frac=0.1):
+    """Per frame: a true pose, points in front of it, exact projections + noise of one pixel times the level scale,
+    weights 1/scale^2, a share of gross outliers, and a perturbed initial pose."""
+    from oracle import ba_ref
+    cam = (718.856, 718.856, 607.19, 185.22)
+    rng = np.random.RandomState(seed)
+    R0, t0, P, Z, W, off = [], [], [], [], [], [0]
+    for n in sizes:
+        Rt, tt = ba_ref.se3_exp(np.concatenate([rng.normal(0, 0.2, 3), rng.normal(0, 1.0, 3)]))
+        Pc = np.stack([rng.uniform(-8, 8, n), rng.uniform(-3, 3, n), rng.uniform(6, 30, n)], 1)
+        Pw = (Pc - tt) @ Rt  # Pc = R Pw + t
+        scale = 1.2 ** rng.randint(0, 8, n)
+        z = np.stack([cam[0] * Pc[:, 0] / Pc[:, 2] + cam[2], cam[1] * Pc[:, 1] / Pc[:, 2] + cam[3]], 1)
+        z += rng.normal(0, 1, (n, 2)) * scale[:, None]
+        bad = rng.uniform(size=n) < outlier_frac
+        z[bad] += rng.uniform(15, 80, (int(bad.sum()), 2)) * rng.choice([-1, 1], (int(bad.sum()), 2))
+        dR, dt = ba_ref.se3_exp(np.concatenate([rng.normal(0, 0.01, 3), rng.normal(0, 0.05, 3)]))
+        R0.append(dR @ Rt); t0.append(dR @ tt + dt)
+        P.append(Pw); Z.append(z); W.append(1.0 / (scale * scale)); off.append(off[-1] + n)
+    cat = lambda xs, w: np.concatenate(xs) if off[-1] else np.zeros((0, w))  # noqa: E731
+    return cam, np.array(R0), np.array(t0), np.array(off, np.int32), cat(P, 3), cat(Z, 2), np.concatenate(W) if off[-1] else np.zeros(0)
+
+
+def test_oracle_pose_optimize_recovers_pose_and_flags_outliers():
+    from oracle import ba_ref
+    cam, R0, t0, off, P, Z, W = _pose_frames([400], 3)
+    out = ba_ref.pose_optimize(cam, R0[0], t0[0], P, Z, W, float(np.sqrt(np.float32(5.991))))
+    chi0 = ba_ref.pose_optimize(cam, R0[0], t0[0], P, Z, W, float(np.sqrt(np.float32(5.991))), rounds=0)["chi2"]
+    assert np.median(out["chi2"]) < 0.2 * np.median(chi0)
+    assert 0.8 * 400 < out["n_inliers"] < 0.93 * 400  # ~10 % gross outliers + the 5 % tail of the noise
+    assert ba_ref.pose_optimize(cam, R0[0], t0[0], P[:2], Z[:2], W[:2], 2.4)["n_inliers"] == 0  # :491
+
+
+@pytest.mark.gpu
+def test_gpu_pose_optimize_batch_matches_oracle():
+    from oracle import ba_ref
+    from monoorbslam3_amd import ba
+    sizes = [300, 1500, 2, 0, 64, 257, 2000, 3]
+    cam, R0, t0, off, P, Z, W = _pose_frames(sizes, 17)
+    got = ba.pose_optimize_batch(cam, R0, t0, off, P, Z, W)
+    for f, n in enumerate(sizes):
+        sl = slice(off[f], off[f + 1])
+        ref = ba_ref.pose_optimize(cam, R0[f], t0[f], P[sl], Z[sl], W[sl], ba.HUBER_MONO)
+        assert got["n_inliers"][f] == ref["n_inliers"], f
+        if n >= 3:
+            assert np.array_equal(got["inlier"][sl], ref["inlier"]), f
+        assert _close(got["pose_R"][f], ref["R"], 1e-7) and _close(got["pose_t"][f], ref["t"], 1e-6), f
+        if n:
+            assert _close(got["chi2"][sl], ref["chi2"], 1e-5), f
+    assert got["n_inliers"][2] == 0 and got["n_inliers"][3] == 0
+    assert np.array_equal(got["pose_R"][2], R0[2]) and np.array_equal(got["pose_t"][3], t0[3])
+    # throughput shape: 256 frames x 1000 correspondences in one launch
+    cam, R0, t0, off, P, Z, W = _pose_frames([1000] * 256, 5)
+    big = ba.pose_optimize_batch(cam, R0, t0, off, P, Z, W)
+    assert (big["n_inliers"] > 800).all()
+    print("poseOptimize: 256 frames x 1000 edges in %.3f ms (%.1f us/frame)" % (big["kernel_ms"], big["kernel_ms"] * 1e3 / 256))
