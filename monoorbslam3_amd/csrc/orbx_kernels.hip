@@ -41,14 +41,17 @@ struct __attribute__((packed, aligned(1))) UnalignedU64 { unsigned long long v; 
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, size_t src_fs, int src_pitch, int sw,
                                                 int sh, uint8_t *__restrict__ dst, size_t dst_fs, int dst_pitch,
                                                 int dw, int dh, const OrbxTap *__restrict__ xtap,
-                                                const OrbxTap *__restrict__ ytap)
+                                                const OrbxTap *__restrict__ ytap, int gx, int gy, int n_frames)
 {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int dy0 = (blockIdx.y * 4 + threadIdx.y) * RS_ROWS;
+    int frame, blk; // a frame's blocks share one XCD: source rows used by two block rows are fetched once
+    if (!xcd_remap(gx * gy, n_frames, &frame, &blk)) return;
+    const int by = blk / gx, bx = blk - by * gx;
+    const int dx0 = (bx * 64 + threadIdx.x) * 4;
+    const int dy0 = (by * 4 + threadIdx.y) * RS_ROWS;
     if (dx0 >= dw || dy0 >= dh) return;
-    const uint8_t *S = src + (size_t)blockIdx.z * src_fs;
-    uint8_t *D = dst + (size_t)blockIdx.z * dst_fs;
+    const uint8_t *S = src + (size_t)frame * src_fs;
+    uint8_t *D = dst + (size_t)frame * dst_fs;
     // the tap table is padded to a multiple of 4 entries (host side), 32 bytes per thread
     const uint4 t01 = reinterpret_cast<const uint4 *>(xtap + dx0)[0], t23 = reinterpret_cast<const uint4 *>(xtap + dx0)[1];
     const int ofs[4] = {(int)t01.x, (int)t01.z, (int)t23.x, (int)t23.z};
@@ -100,9 +103,9 @@ void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int sr
                         uint8_t *dst, size_t dst_fs, int dst_pitch, int dw, int dh, const OrbxTap *xtap,
                         const OrbxTap *ytap, int n_frames)
 {
-    dim3 block(64, 4), grid((dw + 255) / 256, (dh + 4 * RS_ROWS - 1) / (4 * RS_ROWS), n_frames);
-    hipLaunchKernelGGL(k_resize, grid, block, 0, s, src, src_fs, src_pitch, sw, sh, dst, dst_fs, dst_pitch, dw, dh,
-                       xtap, ytap);
+    const int gx = (dw + 255) / 256, gy = (dh + 4 * RS_ROWS - 1) / (4 * RS_ROWS);
+    hipLaunchKernelGGL(k_resize, dim3(orbx_xcd_grid(gx * gy, n_frames)), dim3(64, 4), 0, s, src, src_fs, src_pitch, sw, sh, dst,
+                       dst_fs, dst_pitch, dw, dh, xtap, ytap, gx, gy, n_frames);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -471,10 +474,12 @@ __device__ __forceinline__ void blur_strip(const uint8_t *__restrict__ S, int pi
 
 __global__ __launch_bounds__(256) void k_blur_cols(FastSrc src, const OrbxLevels *__restrict__ levels,
                                                    const BlurTile *__restrict__ tiles, uint8_t *__restrict__ arena,
-                                                   size_t arena_fs, const int *__restrict__ taps)
+                                                   size_t arena_fs, const int *__restrict__ taps, int n_tiles, int n_frames)
 {
-    const BlurTile t = tiles[blockIdx.x];
-    const int frame = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, level = t.level;
+    int frame, tile_id; // all tiles of a frame on one XCD: the 6 halo rows between bands are then L2 hits
+    if (!xcd_remap(n_tiles, n_frames, &frame, &tile_id)) return;
+    const BlurTile t = tiles[tile_id];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, level = t.level;
     const OrbxLevel &lv = levels->lv[level];
     const int w = lv.w, h = lv.h, pitch = src.pitch[level];
     const int x = t.tx * BL_W + 4 * lane;
@@ -533,8 +538,8 @@ void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pit
         src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
         src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
     }
-    hipLaunchKernelGGL(k_blur_cols, dim3(n_tiles, n_frames), dim3(256), 0, s, src, d_levels,
-                       reinterpret_cast<const BlurTile *>(d_tiles), b.img_arena, b.img_frame_stride, taps7);
+    hipLaunchKernelGGL(k_blur_cols, dim3(orbx_xcd_grid(n_tiles, n_frames)), dim3(256), 0, s, src, d_levels,
+                       reinterpret_cast<const BlurTile *>(d_tiles), b.img_arena, b.img_frame_stride, taps7, n_tiles, n_frames);
     int max_h = 1;
     for (int l = 0; l < levels.n_levels; ++l) max_h = levels.lv[l].h > max_h ? levels.lv[l].h : max_h;
     const int tasks = 3 * ((max_h + BE_ROWS - 1) / BE_ROWS);
