@@ -193,3 +193,32 @@ def test_batch_device_pointers_and_determinism(oracle_mod):
         for fld in ("x", "y", "angle", "response", "octave"):
             assert np.array_equal(got[fld], ok[fld]), fld
         assert np.array_equal(desc[f, :n[f]], od)
+
+
+def test_golden_fixtures_through_the_c_abi(oracle_mod):
+    """the committed fixtures (tests/golden, oracle-generated) reproduced by the HIP path alone: extraction, bag of
+    words, undistortion + grid, map-point descriptors"""
+    import os
+    from monoorbslam3_amd.extractor import ORBExtractor
+    from monoorbslam3_amd.frame import FramePost
+    from monoorbslam3_amd.matcher import ORBMatcher
+    from monoorbslam3_amd.vocabulary import ORBVocabulary
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    e = np.load(os.path.join(gold, "extract_320x240_n300.npz"))
+    z = np.load(os.path.join(gold, "records_320x240.npz"))
+    ex = ORBExtractor(300, 1.2, 8, 20, 7)
+    kps, desc = ex(e["image"])
+    for f in ("x", "y", "angle", "response", "octave"):
+        assert np.array_equal(kps[f], e[f]), f
+    assert np.array_equal(desc, e["desc"])
+    k, L, sc, wt = (int(v) for v in z["voc_hdr"])
+    V = ORBVocabulary.from_arrays(dict(k=k, L=L, scoring=sc, weighting=wt, parent=z["voc_parent"], is_leaf=z["voc_leaf"],
+                                       desc=z["voc_desc"], weight=z["voc_weight"]))
+    bi, bv, (fn, fo, fi) = V.transform(desc, 1)
+    assert np.array_equal(bi, z["bow_ids"]) and bv.tobytes() == z["bow_vals"].tobytes()
+    assert np.array_equal(fn, z["fv_nodes"]) and np.array_equal(fo, z["fv_off"]) and np.array_equal(fi, z["fv_idx"])
+    w, h, fx, fy, cx, cy = z["cam"]
+    _, un, start, items = FramePost(int(w), int(h), float(fx), float(fy), float(cx), float(cy), dist=tuple(z["dist"]))(kps)
+    assert np.array_equal(un["x"], z["un_x"]) and np.array_equal(un["y"], z["un_y"])
+    assert np.array_equal(start, z["cell_start"]) and np.array_equal(items, z["cell_items"])
+    assert ORBMatcher.ComputeDistinctiveDescriptors(z["g_desc"], z["g_off"]).tolist() == z["medoid"].tolist()

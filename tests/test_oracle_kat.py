@@ -697,3 +697,29 @@ def test_distinctive_descriptor_kats(oracle_mod):
         dist = np.unpackbits(g[:, None] ^ g[None], axis=2).sum(2)
         med = np.sort(dist, axis=1)[:, (n - 1) // 2]
         assert oracle_mod.distinctive_descriptor(g) == int(np.argmin(med))
+
+
+def _records_fixture():
+    z = np.load(os.path.join(GOLDEN, "records_320x240.npz"))
+    img = np.load(os.path.join(GOLDEN, "extract_320x240_n300.npz"))
+    k, L, sc, wt = (int(v) for v in z["voc_hdr"])
+    voc = dict(k=k, L=L, scoring=sc, weighting=wt, parent=z["voc_parent"], is_leaf=z["voc_leaf"], desc=z["voc_desc"],
+               weight=z["voc_weight"])
+    w, h, fx, fy, cx, cy = z["cam"]
+    cam = dict(width=int(w), height=int(h), fx=float(fx), fy=float(fy), cx=float(cx), cy=float(cy))
+    return z, img, voc, cam
+
+
+def test_golden_records_fixture(O):
+    """bag of words, undistortion + grid and map-point descriptors on the committed frame (oracle-generated drift guard)"""
+    z, img, voc, cam = _records_fixture()
+    o = O.Oracle(300, 1.2, 8, 20, 7)
+    kps, desc, _ = o.extract(img["image"])
+    bi, bv, (fn, fo, fi) = O.Vocabulary(voc).transform(desc, 1)
+    assert np.array_equal(bi, z["bow_ids"]) and bv.tobytes() == z["bow_vals"].tobytes()
+    assert np.array_equal(fn, z["fv_nodes"]) and np.array_equal(fo, z["fv_off"]) and np.array_equal(fi, z["fv_idx"])
+    _, un, start, items = O.frame_post(**cam, dist=tuple(z["dist"]), kps=kps)
+    assert np.array_equal(un["x"], z["un_x"]) and np.array_equal(un["y"], z["un_y"])
+    assert np.array_equal(start, z["cell_start"]) and np.array_equal(items, z["cell_items"])
+    got = [O.distinctive_descriptor(z["g_desc"][z["g_off"][i]:z["g_off"][i + 1]]) for i in range(len(z["medoid"]))]
+    assert got == z["medoid"].tolist()
