@@ -229,3 +229,37 @@ def test_gpu_pose_optimize_batch_matches_oracle():
     big = ba.pose_optimize_batch(cam, R0, t0, off, P, Z, W)
     assert (big["n_inliers"] > 800).all()
     print("poseOptimize: 256 frames x 1000 edges in %.3f ms (%.1f us/frame)" % (big["kernel_ms"], big["kernel_ms"] * 1e3 / 256))
+
+
+def test_oracle_lm_reaches_the_same_minimum_as_scipy():
+    """Independent check of the restated solver: without the robust kernel the LM loop and scipy's trust-region
+    least squares (its own Jacobian by finite differences, its own parameterisation through se3_exp) must end in the
+    same minimum of sum w |z - project(R P + t)|^2."""
+    from scipy.optimize import least_squares
+    from oracle import ba_ref
+    pr, args = _perturbed(4, 40, 21)
+    cam, R0, t0, fixed, P0, ep, el, z, w = args
+    fixed = np.asarray(fixed, bool)
+    free = np.flatnonzero(~fixed)
+    ep, el, z, w = np.asarray(ep), np.asarray(el), np.asarray(z, np.float64).reshape(-1, 2), np.asarray(w, np.float64)
+    ref = ba_ref.lm_optimize(cam, R0, t0, fixed, P0, ep, el, z, w, 0.0, 60)
+
+    def unpack(x):
+        R, t = R0.copy(), t0.copy()
+        for i, ip in enumerate(free):
+            dR, dt = ba_ref.se3_exp(x[6 * i:6 * i + 6])
+            R[ip], t[ip] = dR @ R0[ip], dR @ t0[ip] + dt
+        return R, t, P0 + x[6 * len(free):].reshape(-1, 3)
+
+    def fun(x):
+        R, t, P = unpack(x)
+        e, _ = ba_ref.residual(cam, R[ep], t[ep], P[el], z)
+        return (np.sqrt(w)[:, None] * e).ravel()
+
+    sol = least_squares(fun, np.zeros(6 * len(free) + P0.size), method="trf", xtol=1e-14, ftol=1e-14, gtol=1e-12, max_nfev=400)
+    cost_scipy = float((sol.fun ** 2).sum())
+    assert abs(ref["chi2_final"] - cost_scipy) <= 1e-6 * cost_scipy
+    R, t, P = unpack(sol.x)
+    e_ref, _ = ba_ref.residual(cam, ref["pose_R"][ep], ref["pose_t"][ep], ref["points"][el], z)
+    e_sp, _ = ba_ref.residual(cam, R[ep], t[ep], P[el], z)
+    assert np.abs(e_ref - e_sp).max() < 1e-3  # same reprojections (the gauge along the fixed poses is pinned by them)
