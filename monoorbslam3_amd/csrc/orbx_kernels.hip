@@ -234,13 +234,20 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
     __syncthreads();
     int thr = levels->ini_th;
     for (int pass = 0; pass < 2; ++pass) {
-        const s16x2 T = {(short)thr, (short)thr};
-        // ---- compass test: item = (row, run of 4 tile columns 4g..4g+3), g = 1..8
-        uint32_t mask = 0;
+        // ---- compass test: item = (row, run of 4 tile columns 4g..4g+3), g = 1..8.
+        // A 9-arc contains one point of every opposite pair, so a corner at threshold T needs
+        //   V - max(min(S,N), min(E,W)) > T   (both pairs hold a darker point)   or
+        //   min(max(S,N), max(E,W)) - V > T   (both pairs hold a brighter point).
+        // Two pixels per instruction in packed i16; m - (T+1) has its sign bit set iff the pixel fails, and the sign
+        // bytes of the item's four pixels are gathered with one v_perm.  acc collects them: bit 8j + 4 + it set =
+        // pixel j of iteration `it` is NOT a candidate.
+        const s16x2 T1 = {(short)(thr + 1), (short)(thr + 1)};
+        uint32_t acc = 0xFFFFFFFFu;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int i = it * 64 + lane;
             const int r = i >> 3, g = (i & 7) + 1;
+            uint32_t w = 0x80808080u; // rows below the cell: no candidates
             if (r < ch) {
                 const uint8_t *row = &tile[(r + 3) * FC_TP + 4 * g];
                 const uint32_t cm = *reinterpret_cast<const uint32_t *>(row - 4);
@@ -248,25 +255,29 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
                 const uint32_t cp = *reinterpret_cast<const uint32_t *>(row + 4);
                 const uint32_t up = *reinterpret_cast<const uint32_t *>(row - 3 * FC_TP);
                 const uint32_t dn = *reinterpret_cast<const uint32_t *>(row + 3 * FC_TP);
-                uint32_t bits = 0;
+                uint32_t x[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const s16x2 V = pk_bytes(0, c0, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));
-                    const s16x2 dE = V - pk_bytes(cp, c0, h ? PERM_SEL(5, 6) : PERM_SEL(3, 4));
-                    const s16x2 dW = V - pk_bytes(c0, cm, h ? PERM_SEL(3, 4) : PERM_SEL(1, 2));
-                    const s16x2 dS = V - pk_bytes(0, dn, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));
-                    const s16x2 dN = V - pk_bytes(0, up, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));
-                    const s16x2 hi = __builtin_elementwise_min(__builtin_elementwise_max(dS, dN),
-                                                               __builtin_elementwise_max(dE, dW));
-                    const s16x2 lo = __builtin_elementwise_max(__builtin_elementwise_min(dS, dN),
-                                                               __builtin_elementwise_min(dE, dW));
-                    const s16x2 m = __builtin_elementwise_max(hi, -lo) - T;
-                    bits |= (uint32_t)(m.x > 0) << (2 * h);
-                    bits |= (uint32_t)(m.y > 0) << (2 * h + 1);
+                    const s16x2 E = pk_bytes(cp, c0, h ? PERM_SEL(5, 6) : PERM_SEL(3, 4));
+                    const s16x2 Wv = pk_bytes(c0, cm, h ? PERM_SEL(3, 4) : PERM_SEL(1, 2));
+                    const s16x2 S = pk_bytes(0, dn, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));
+                    const s16x2 N = pk_bytes(0, up, h ? PERM_SEL(2, 3) : PERM_SEL(0, 1));
+                    const s16x2 A = __builtin_elementwise_max(__builtin_elementwise_min(S, N), __builtin_elementwise_min(E, Wv));
+                    const s16x2 B = __builtin_elementwise_min(__builtin_elementwise_max(S, N), __builtin_elementwise_max(E, Wv));
+                    const s16x2 m = __builtin_elementwise_max(V - A, B - V) - T1;
+                    x[h] = __builtin_bit_cast(uint32_t, m);
                 }
-                const int nvalid = min(max(cw + 4 - 4 * g, 0), 4); // region columns end at tc = 4 + cw
-                mask |= (bits & ((1u << nvalid) - 1)) << (4 * it);
+                w = __builtin_amdgcn_perm(x[1], x[0], 0x07050301u); // high bytes of the four i16
             }
+            acc = (w & 0x80808080u) | ((acc >> 1) & 0x7F7F7F7Fu);
+        }
+        uint32_t mask;
+        {
+            const int g = (lane & 7) + 1;
+            const int nvalid = min(max(cw + 4 - 4 * g, 0), 4); // region columns end at tc = 4 + cw
+            const uint32_t vmask = nvalid >= 4 ? 0xF0F0F0F0u : (0xF0F0F0F0u & ((1u << (8 * nvalid)) - 1u));
+            mask = ~acc & vmask;
         }
         int q1n;
         {
@@ -283,8 +294,8 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
             while (m) {
                 const int b = __ffs(m) - 1;
                 m &= m - 1;
-                const int i = (b >> 2) * 64 + lane;
-                queue1[slot++] = (uint16_t)(((i >> 3) << 8) | (4 * ((i & 7) + 1) + (b & 3))); // (row, tc)
+                const int i = ((b & 7) - 4) * 64 + lane; // bit 8j + 4 + it
+                queue1[slot++] = (uint16_t)(((i >> 3) << 8) | (4 * ((i & 7) + 1) + (b >> 3))); // (row, tc)
             }
         }
         __syncthreads();
