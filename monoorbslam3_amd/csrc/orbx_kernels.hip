@@ -1351,15 +1351,24 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
         if (!live[k]) continue;
         const OrbxLevel &lv = levels->lv[level[k]];
         const float a = ang[k].y, bb = ang[k].z;
-        const uint8_t *center = &patch[wv][k][18 * DP_W + 19 + (((int)(rec[k].x & 0xFFFF) - 19) & 15)];
+        // cvRound (ties to even) without v_rndne + v_cvt: adding 1.5 * 2^23 makes the float add itself round to the nearest
+        // integer (|value| <= 19 here), the integer is then the low mantissa bits.  The constant's bit pattern M is not
+        // subtracted per sample: (M + r) * 64 + (M + c) = r * 64 + c + 65 M, and 65 M is folded into the patch offset
+        // (unsigned arithmetic, wraps harmlessly).
+        static_assert(DP_W == 64, "row stride folded into a shift");
+        const float MAGIC = 12582912.f;
+        const uint32_t M = 0x4B400000u;
+        const uint8_t *pbytes = &patch[0][0][0];
+        const uint32_t centre = (uint32_t)((wv * DP_K + k) * (DP_H * DP_W) + 18 * DP_W + 19 + (((int)(rec[k].x & 0xFFFF) - 19) & 15)) -
+                                65u * M;
         u64 bits[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r0 = orb_round_f(ORB_FADD(ORB_FMUL(px0[j], bb), ORB_FMUL(py0[j], a)));
-            const int c0 = orb_round_f(ORB_FSUB(ORB_FMUL(px0[j], a), ORB_FMUL(py0[j], bb)));
-            const int r1 = orb_round_f(ORB_FADD(ORB_FMUL(px1[j], bb), ORB_FMUL(py1[j], a)));
-            const int c1 = orb_round_f(ORB_FSUB(ORB_FMUL(px1[j], a), ORB_FMUL(py1[j], bb)));
-            const int t0 = center[r0 * DP_W + c0], t1 = center[r1 * DP_W + c1];
+            const uint32_t r0 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px0[j], bb), ORB_FMUL(py0[j], a)), MAGIC));
+            const uint32_t c0 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px0[j], a), ORB_FMUL(py0[j], bb)), MAGIC));
+            const uint32_t r1 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px1[j], bb), ORB_FMUL(py1[j], a)), MAGIC));
+            const uint32_t c1 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px1[j], a), ORB_FMUL(py1[j], bb)), MAGIC));
+            const int t0 = pbytes[(r0 << 6) + c0 + centre], t1 = pbytes[(r1 << 6) + c1 + centre];
             bits[j] = __ballot(t0 < t1);
         }
         if (lane < 4) {
