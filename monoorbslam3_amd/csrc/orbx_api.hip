@@ -374,7 +374,10 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
     }
     {
         const char *e = getenv("ORBX_STREAMS");
-        c->n_sub = e ? std::min(std::max(atoi(e), 1), 8) : 4;
+        // Default 1: with the blur already on a side stream, splitting the batch into frame ranges on more streams loses
+        // (tools/overlap_sweep.sh: 103.6 k frames/s with 1, 95.7 k with 2, 94.8 k with 4 at the runtime's default of four
+        // hardware queues; more streams than queues alias and serialise).  The knob stays for experiments.
+        c->n_sub = e ? std::min(std::max(atoi(e), 1), 8) : 1;
     }
     if (hipMalloc((void **)&c->d_levels, sizeof(OrbxLevels)) != hipSuccess ||
         hipMalloc((void **)&c->d_umax, sizeof(int) * 16) != hipSuccess ||
