@@ -370,7 +370,7 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
             return cleanup(fail(ORBX_E_NO_DEVICE, "side-stream creation failed"));
     {
         const char *e = getenv("ORBX_SIDE_BLUR");
-        c->side_blur = e ? atoi(e) != 0 : 1;
+        c->side_blur = e ? atoi(e) : 1;
     }
     {
         const char *e = getenv("ORBX_STREAMS");
@@ -507,15 +507,18 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     }
     if (t) HIP_TRY(hipEventRecord(c->ev[1], s));
     const bool side = !t && c->side_blur && slot >= 0;
-    if (side) { // pyramid ready -> blur on the side stream
+    auto fork_blur = [&]() -> int { // the blur only needs the pyramid: side stream, joined before the descriptor kernel
         HIP_TRY(hipEventRecord(c->ev_pyr[slot], s));
         HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_pyr[slot], 0));
         orbx_launch_blur(c->side[slot], d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps,
                          n_frames);
         HIP_TRY(hipEventRecord(c->ev_blur[slot], c->side[slot]));
-    }
+        return ORBX_OK;
+    };
+    if (side && c->side_blur == 1) { int rc = fork_blur(); if (rc) return rc; } // next to FAST
     orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_cells, c->n_fast_cells, n_frames);
     if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
+    if (side && c->side_blur != 1) { int rc = fork_blur(); if (rc) return rc; } // next to the quadtree and orientation
     if (!side)
         orbx_launch_blur(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames);
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));
