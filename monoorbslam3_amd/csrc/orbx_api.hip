@@ -69,6 +69,10 @@ struct orbx_ctx {
     int side_blur;
     hipStream_t side[9];
     hipEvent_t ev_pyr[9], ev_blur[9];
+    // FAST on level 0 needs no pyramid: its cells start on the side stream at once, next to the (latency-bound) resize
+    // chain; the remaining levels' cells follow on the main stream
+    int early_fast;
+    hipEvent_t ev_start[9], ev_fast0[9];
     // stage timing
     int timing;
     hipEvent_t ev[ORBX_N_STAGES + 1];
@@ -366,11 +370,15 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
     for (int i = 0; i < 9; ++i)
         if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_pyr[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_blur[i], hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&c->ev_blur[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_start[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_fast0[i], hipEventDisableTiming) != hipSuccess)
             return cleanup(fail(ORBX_E_NO_DEVICE, "side-stream creation failed"));
     {
         const char *e = getenv("ORBX_SIDE_BLUR");
         c->side_blur = e ? atoi(e) : 1;
+        const char *f = getenv("ORBX_EARLY_FAST");
+        c->early_fast = f ? atoi(f) : 1;
     }
     {
         const char *e = getenv("ORBX_STREAMS");
@@ -429,6 +437,8 @@ extern "C" void orbx_destroy(orbx_t *c)
         if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); }
         if (c->ev_pyr[i]) (void)hipEventDestroy(c->ev_pyr[i]);
         if (c->ev_blur[i]) (void)hipEventDestroy(c->ev_blur[i]);
+        if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
+        if (c->ev_fast0[i]) (void)hipEventDestroy(c->ev_fast0[i]);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -498,6 +508,15 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         if (l == 0) { *p = d_l0; *fs = l0_fs; *pitch = l0_pitch; }
         else { *p = b.img_arena + LV.lv[l].raw_off; *fs = b.img_frame_stride; *pitch = LV.lv[l].pitch; }
     };
+    const bool side_ok = !t && c->side_blur && slot >= 0;
+    const int n_cells0 = LV.lv[0].n_cols * LV.lv[0].n_rows; // the cell list is level-major
+    const bool early = side_ok && c->early_fast && L > 1 && n_cells0 > 0 && n_cells0 < c->n_fast_cells;
+    if (early) {
+        HIP_TRY(hipEventRecord(c->ev_start[slot], s)); // candidate counters are zero from here on
+        HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_start[slot], 0));
+        orbx_launch_fast(c->side[slot], d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_cells, n_cells0, n_frames);
+        HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
+    }
     for (int l = 1; l < L; ++l) {
         const uint8_t *sp; size_t sfs; int spitch;
         raw(l - 1, &sp, &sfs, &spitch);
@@ -516,7 +535,13 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         return ORBX_OK;
     };
     if (side && c->side_blur == 1) { int rc = fork_blur(); if (rc) return rc; } // next to FAST
-    orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_cells, c->n_fast_cells, n_frames);
+    if (early) {
+        orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_cells + 4 * n_cells0,
+                         c->n_fast_cells - n_cells0, n_frames);
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_fast0[slot], 0));
+    } else {
+        orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_cells, c->n_fast_cells, n_frames);
+    }
     if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
     if (side && c->side_blur != 1) { int rc = fork_blur(); if (rc) return rc; } // next to the quadtree and orientation
     if (!side)
