@@ -30,6 +30,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GWINST = 557.4
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (falls back to the same wording when the file is not shipped)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "ORB extract+match frames/s @1242\u00d7375, 2000 feat; 1/2/4/8 GPU + %HBM roofline"
+
+
 def level_bytes(ex, w, h):
     sizes = [ex.level_size(w, h, l) for l in range(ex.n_levels)]
     return [a * b for a, b in sizes]
@@ -295,7 +303,7 @@ def main():
     pairs = float((counts.astype(np.float64) * np.roll(counts, -1)).sum())
 
     out = {
-        "metric": "ORB extract+match frames/s @1242x375, 2000 feat",
+        "metric": baseline_metric(),
         "value": round(fps, 2),
         "unit": "frames/s",
         "n_gpus": world,
