@@ -20,6 +20,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# A step uses four streams of its own (extraction, the extractor's side stream, match, and with N > 1 the gather) and RCCL
+# adds its own; the runtime's default of four hardware queues makes streams beyond that share a queue and serialise
+# (tools/overlap_sweep.sh).  Eight queues cost nothing at N = 1 (103.3 k vs 103.6 k frames/s) and keep the streams apart.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
