@@ -5,8 +5,8 @@ One "step" = one pass of the hot path over one resident batch of synthetic frame
 pyramid -> FAST cells -> blur -> quadtree -> orientation + rBRIEF for every frame, then the
 256-bit Hamming best-2 brute force (the SearchByBow inner loop) of every frame's descriptors
 against its neighbour's.  Inputs live in HBM before the timed region.  With N > 1 each rank
-processes its own batch (weak scaling) and the step ends with one RCCL all-gather of the
-fixed-capacity keypoint/descriptor records (monoorbslam3_amd/dist.py).
+processes its own batch (weak scaling) and every step issues one RCCL gather of the fixed-capacity
+keypoint/descriptor records to rank 0 on its own stream (monoorbslam3_amd/dist.py).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
 dominant kernel (HIP-event timing on the launch stream) and `cpu_baseline` (the C oracle
