@@ -170,8 +170,8 @@ extern "C" int orbf_create(const orbf_camera *cam, int device, orbf_t **out)
         return orbx_set_error(ORBX_E_ARG, "bad camera: size must be positive and n_dist in 0..12");
     if (cam->fx == 0.f || cam->fy == 0.f) return orbx_set_error(ORBX_E_ARG, "bad camera: zero focal length");
     int n_dev = 0;
-    F_TRY(hipGetDeviceCount(&n_dev));
-    if (n_dev <= 0) return orbx_set_error(ORBX_E_NO_DEVICE, "no HIP device (there is no CPU fallback)");
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return orbx_set_error(ORBX_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= n_dev) return orbx_set_error(ORBX_E_ARG, "device index out of range");
     F_TRY(hipSetDevice(device));
     orbf_ctx *c = new orbf_ctx();

@@ -286,8 +286,8 @@ extern "C" int orbv_create(int k, int L, int scoring, int weighting, int n_nodes
         if (parent[i] < 0 || parent[i] >= i)
             return orbx_set_error(ORBX_E_ARG, "node " + std::to_string(i) + ": parent must be an earlier node");
     int n_dev = 0;
-    V_TRY(hipGetDeviceCount(&n_dev));
-    if (n_dev <= 0) return orbx_set_error(ORBX_E_NO_DEVICE, "no HIP device (there is no CPU fallback)");
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return orbx_set_error(ORBX_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= n_dev) return orbx_set_error(ORBX_E_ARG, "device index out of range");
     V_TRY(hipSetDevice(device));
     orbv_ctx *c = new orbv_ctx();

@@ -91,3 +91,28 @@ def test_compat_shims_compile_against_mock_opencv(built):
     if not os.path.exists(src):
         pytest.skip("shim not built yet")
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src])
+
+
+def test_every_handle_type_fails_loudly_without_a_gpu():
+    """orbf / orbv / orbba entry points: no device -> a negative status and a message, never a CPU fallback."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    from monoorbslam3_amd import ba, frame, vocabulary
+    from monoorbslam3_amd._lib import OrbxError
+    with pytest.raises(OrbxError, match="no HIP device"):
+        frame.FramePost(640, 480, 500.0, 500.0, 320.0, 240.0)
+    voc = dict(k=2, L=1, scoring=0, weighting=0, parent=np.zeros(3, np.int32), is_leaf=np.array([0, 1, 1], np.uint8),
+               desc=np.zeros((3, 32), np.uint8), weight=np.array([0.0, 1.0, 1.0]))
+    with pytest.raises(OrbxError, match="no HIP device"):
+        vocabulary.ORBVocabulary.from_arrays(voc)
+    args = ((500.0, 500.0, 320.0, 240.0), np.eye(3)[None].repeat(2, 0), np.zeros((2, 3)), np.array([1, 0], np.uint8),
+            np.ones((3, 3)), np.array([0, 1, 1], np.int32), np.array([0, 1, 2], np.int32), np.zeros((3, 2)), np.ones(3))
+    for fn in (ba.linearize, ba.optimize, ba.local_bundle_adjustment):
+        with pytest.raises(OrbxError, match="no HIP device"):
+            fn(*args)
+    with pytest.raises(OrbxError, match="no HIP device"):
+        ba.pose_optimize_batch(args[0], np.eye(3)[None], np.zeros((1, 3)), np.array([0, 3], np.int32), np.ones((3, 3)),
+                               np.zeros((3, 2)), np.ones(3))
