@@ -10,6 +10,8 @@
  * SURVEY.md 8f rank 2 (+ the grid half of rank 1).
  *
  * Returns 0 or a negative ORBX_E_* code (orbx.h); text in orbx_last_error().
+ * A handle owns device scratch that every call uses: keep one call in flight per handle (calls enqueued on ONE stream
+ * are fine, they are ordered); use one handle per stream / host thread otherwise.
  */
 #ifndef ORBF_H
 #define ORBF_H

@@ -12,6 +12,8 @@
  * outputs are the two std::maps flattened in key order -- the FeatureVector in exactly the CSR form orbm_fv takes.
  *
  * Returns 0 or a negative ORBX_E_* code (orbx.h); text in orbx_last_error().
+ * The tree is read-only and shared, but a handle's per-feature scratch is not: keep the transform calls of one handle on
+ * one stream (they are then ordered); orbv_transform_features_device uses no scratch and may run anywhere.
  */
 #ifndef ORBV_H
 #define ORBV_H
