@@ -459,25 +459,60 @@ __device__ __forceinline__ void blur_strip(const uint8_t *__restrict__ S, int pi
     // input row n (level row ys-3+n) goes to slot n%7; from n = 6 on, output row ys+n-6 is complete:
     // its rows y-3 .. y+3 sit in slots (n+1)%7 .. (n+7)%7.  One unrolled-by-7 loop, no separate priming code.
     const int n_rows = ye - ys + 6;
+    auto emit = [&](int s, int n) {
+        const int y = ys + n - 6;
+        uint32_t r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t acc = 32768u;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc = mad_u24(k[j], hq[(s + 1 + j) % 7][i], acc);
+            r[i] = min(acc >> 16, 255u);
+        }
+        // rows of the arena are padded to a multiple of 64 bytes: the dword store stays inside the row
+        *reinterpret_cast<uint32_t *>(D + (size_t)y * dpitch + x) = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
+    };
+    if (!BORDER) {
+        // Interior columns: the three dwords of the rows n+1 and n+2 are requested before row n is used, so a wave has
+        // two loads in flight while it computes instead of a load -> wait -> compute -> store chain per row.  Row indices
+        // are reflected with a closed form (|overshoot| <= 3 < h) and clamped, so a prefetch past the last needed row
+        // reads a valid row and is simply not used.
+        struct __attribute__((packed, aligned(1))) U96 { uint32_t w[3]; };
+        auto fetch = [&](int n) -> U96 {
+            int rr = ys - 3 + min(n, n_rows - 1);
+            rr = rr < 0 ? -rr : (rr >= h ? 2 * h - 2 - rr : rr);
+            rr = min(max(rr, 0), h - 1);
+            return *reinterpret_cast<const U96 *>(S + (size_t)rr * pitch + x - 4);
+        };
+        // a ring of seven register triples indexed like hq (slot = n % 7, compile-time in the unrolled loop): no register
+        // copies, which would make the wave wait for the very loads that are meant to stay in flight
+        U96 q[7];
+        q[0] = fetch(0);
+        q[1] = fetch(1);
+        // the body has no branch on n (rows past the band are clamped re-reads whose results are never stored), so that
+        // the compiler's s_waitcnt placement can leave the younger loads in flight
+        for (int n0 = 0; n0 < n_rows; n0 += 7) {
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                const int n = n0 + s;
+                q[(s + 2) % 7] = fetch(n + 2);
+                blur_hrow(q[s].w[0], q[s].w[1], q[s].w[2], K0, K1, hq[s]);
+                if (clamp16) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hq[s][i] = min(hq[s][i], 65535u);
+                }
+                if (n >= 6 && n < n_rows) emit(s, n);
+            }
+        }
+        return;
+    }
     for (int n0 = 0; n0 < n_rows; n0 += 7) {
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
             const int n = n0 + s;
             if (n < n_rows) {
                 load_row(ys - 3 + n, hq[s]);
-                if (n >= 6) {
-                    const int y = ys + n - 6;
-                    uint32_t r[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        uint32_t acc = 32768u;
-#pragma unroll
-                        for (int j = 0; j < 7; ++j) acc = mad_u24(k[j], hq[(s + 1 + j) % 7][i], acc);
-                        r[i] = min(acc >> 16, 255u);
-                    }
-                    // rows of the arena are padded to a multiple of 64 bytes: the dword store stays inside the row
-                    *reinterpret_cast<uint32_t *>(D + (size_t)y * dpitch + x) = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
-                }
+                if (n >= 6) emit(s, n);
             }
         }
     }
