@@ -1335,13 +1335,19 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
     uint32_t pat[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) pat[j] = reinterpret_cast<const uint32_t *>(c_pattern)[lane + 64 * j];
+    // Everything about the wave's two keypoints is wave-uniform: the slot is forced into an SGPR so that the level table,
+    // the per-level counts and the keypoint records come through the scalar cache instead of a chain of dependent vector
+    // loads, each with its own s_waitcnt.
+    const int slot0 = __builtin_amdgcn_readfirstlane((blk * 4 + wv) * DP_K);
     bool live[DP_K];
     int level[DP_K], out_idx[DP_K];
     uint2 rec[DP_K];
     float4 ang[DP_K];
+    const uint8_t *corner[DP_K];
+    int cpitch[DP_K];
 #pragma unroll
     for (int k = 0; k < DP_K; ++k) {
-        const int slot = (blk * 4 + wv) * DP_K + k;
+        const int slot = slot0 + k;
         live[k] = slot < levels->kcap_total;
         int lvl = 0;
         for (int l = 1; l < L; ++l) lvl += live[k] && slot >= levels->lv[l].kp_off;
@@ -1354,26 +1360,39 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
         live[k] = live[k] && oi < cap;
         rec[k] = make_uint2(0, 0);
         ang[k] = make_float4(0.f, 1.f, 0.f, 0.f);
+        // a slot without a keypoint stages the top-left corner of the blurred level 0 (valid memory, never sampled), so
+        // that the loads below need no branch
+        const OrbxLevel &lv = levels->lv[live[k] ? lvl : 0];
+        int x = 19, y = 18;
         if (live[k]) {
             rec[k] = b.sel[(size_t)frame * levels->kcap_total + slot];
             ang[k] = b.kp_ang[(size_t)frame * levels->kcap_total + slot];
+            x = rec[k].x & 0xFFFF;
+            y = rec[k].x >> 16;
         }
+        cpitch[k] = lv.pitch;
+        // arena rows are 64-byte aligned, so one shift (x-19)&15 serves the whole patch: the rows go to LDS
+        // as they are (148 aligned 128-bit loads per keypoint) and only the centre index moves
+        corner[k] = b.img_arena + (size_t)frame * b.img_frame_stride + lv.blur_off + (size_t)(y - 18) * lv.pitch + ((x - 19) & ~15);
     }
+    // all six 128-bit loads of a lane (three per keypoint; the third covers items 128..147, clamped for the other lanes)
+    // are in flight together, then written to LDS
+    constexpr int DP_ITEMS = DP_H * (DP_W / 16), DP_IT = (DP_ITEMS + 63) / 64;
+    uint4 stage[DP_K][DP_IT];
 #pragma unroll
-    for (int k = 0; k < DP_K; ++k) {
-        if (live[k]) {
-            const OrbxLevel &lv = levels->lv[level[k]];
-            const int x = rec[k].x & 0xFFFF, y = rec[k].x >> 16, pitch = lv.pitch;
-            // arena rows are 64-byte aligned, so one shift (x-19)&15 serves the whole patch: the rows go to LDS
-            // as they are (148 aligned 128-bit loads per keypoint) and only the centre index moves
-            const uint8_t *corner = b.img_arena + (size_t)frame * b.img_frame_stride + lv.blur_off + (size_t)(y - 18) * pitch + ((x - 19) & ~15);
-            for (int q = lane; q < DP_H * (DP_W / 16); q += 64) {
-                const int r = q >> 2, dc = q & 3;
-                *reinterpret_cast<uint4 *>(&patch[wv][k][r * DP_W + 16 * dc]) =
-                    *reinterpret_cast<const uint4 *>(corner + (size_t)r * pitch + 16 * dc);
-            }
+    for (int k = 0; k < DP_K; ++k)
+#pragma unroll
+        for (int it = 0; it < DP_IT; ++it) {
+            const int q = min(lane + 64 * it, DP_ITEMS - 1), r = q >> 2, dc = q & 3;
+            stage[k][it] = *reinterpret_cast<const uint4 *>(corner[k] + (size_t)r * cpitch[k] + 16 * dc);
         }
-    }
+#pragma unroll
+    for (int k = 0; k < DP_K; ++k)
+#pragma unroll
+        for (int it = 0; it < DP_IT; ++it) {
+            const int q = min(lane + 64 * it, DP_ITEMS - 1), r = q >> 2, dc = q & 3;
+            *reinterpret_cast<uint4 *>(&patch[wv][k][r * DP_W + 16 * dc]) = stage[k][it];
+        }
     __syncthreads();
     float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
