@@ -174,7 +174,7 @@ __device__ __forceinline__ s16x2 pk_bytes(uint32_t hi, uint32_t lo, uint32_t sel
 // ---------------------------------------------------------------------------------------------
 #define FC_TP 40 // tile pitch; tile column tc <-> level x = x0 - 4 + tc, region columns tc in [4, 4 + cw)
 #define FC_SP 40 // score-map pitch; score column = tc - 3, so the cell occupies columns 1..cw
-struct FastCell {
+struct __attribute__((aligned(8))) FastCell { // 8-byte aligned: one scalar load per cell
     uint16_t level, cy, cx, pad;
 };
 __device__ __forceinline__ void fastc_load_ring(const uint8_t *t, int d[16])
@@ -218,18 +218,23 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
     for (int i = lane; i < 32 * FC_SP / 16; i += 64) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
     if (lane == 0) s_nkeep = 0;
     {
-        const int row_left = lv.w - (x0 - 4); // bytes from the tile's left edge to the end of the image row
-        for (int i = lane; i < 5 * th; i += 64) {
+        // The 36 x 40-byte tile as 5 x th eight-byte items, three per lane, all requested before the first is stored (the
+        // index is clamped instead of branching: a surplus lane re-reads the last item).  Items of the last cell column may
+        // reach past the end of the image row -- into the row's padding or the next row, never past the frame: the tile's
+        // last row is at most h - 17 -- and those bytes are never looked at: the compass test masks the columns beyond the
+        // cell and a ring of a cell pixel ends at column w - 17.
+        const int n_items = 5 * th;
+        unsigned long long v[3];
+        int dst[3];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int i = min(lane + 64 * it, n_items - 1);
             const int ty = i / 5, tx = (i - 5 * ty) * 8;
-            const uint8_t *p = S + (size_t)ty * pitch + tx;
-            unsigned long long v;
-            if (tx + 8 <= row_left) v = reinterpret_cast<const UnalignedU64b *>(p)->v;
-            else {
-                v = 0;
-                for (int k = 0; k < row_left - tx; ++k) v |= (unsigned long long)p[k] << (8 * k);
-            }
-            *reinterpret_cast<unsigned long long *>(&tile[ty * FC_TP + tx]) = v;
+            dst[it] = ty * FC_TP + tx;
+            v[it] = reinterpret_cast<const UnalignedU64b *>(S + (size_t)ty * pitch + tx)->v;
         }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) *reinterpret_cast<unsigned long long *>(&tile[dst[it]]) = v[it];
     }
     __syncthreads();
     int thr = levels->ini_th;
