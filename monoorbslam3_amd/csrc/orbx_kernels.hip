@@ -48,34 +48,39 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     if (!xcd_remap(gx * gy, n_frames, &frame, &blk)) return;
     const int by = blk / gx, bx = blk - by * gx;
     const int dx0 = (bx * 64 + threadIdx.x) * 4;
-    const int dy0 = (by * 4 + threadIdx.y) * RS_ROWS;
+    // a wave is one row of the 64 x 4 block, so its output rows and their row taps are wave-uniform: scalar loads
+    const int dy0 = (by * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * RS_ROWS;
     if (dx0 >= dw || dy0 >= dh) return;
     const uint8_t *S = src + (size_t)frame * src_fs;
     uint8_t *D = dst + (size_t)frame * dst_fs;
     // the tap table is padded to a multiple of 4 entries (host side), 32 bytes per thread
     const uint4 t01 = reinterpret_cast<const uint4 *>(xtap + dx0)[0], t23 = reinterpret_cast<const uint4 *>(xtap + dx0)[1];
-    const int ofs[4] = {(int)t01.x, (int)t01.z, (int)t23.x, (int)t23.z};
-    const uint32_t cc[4] = {t01.y, t01.w, t23.y, t23.w}; // c0 | c1 << 16
-    const int sx0 = ofs[0];
-    const bool wide_ok = sx0 + 8 <= sw;
-    unsigned long long w0[RS_ROWS], w1[RS_ROWS];
-    int b0[RS_ROWS], b1[RS_ROWS];
+    int b0[RS_ROWS], b1[RS_ROWS], sy0[RS_ROWS], sy1[RS_ROWS];
 #pragma unroll
     for (int r = 0; r < RS_ROWS; ++r) {
         const OrbxTap ty = ytap[min(dy0 + r, dh - 1)];
         b0[r] = ty.c0; b1[r] = ty.c1;
-        const int sy0 = min(max(ty.ofs, 0), sh - 1), sy1 = min(max(ty.ofs + 1, 0), sh - 1);
-        const uint8_t *S0 = S + (size_t)sy0 * src_pitch + sx0, *S1 = S + (size_t)sy1 * src_pitch + sx0;
-        if (wide_ok) {
-            w0[r] = reinterpret_cast<const UnalignedU64 *>(S0)->v;
-            w1[r] = reinterpret_cast<const UnalignedU64 *>(S1)->v;
-        } else { // right image edge: never read past the end of the row
-            w0[r] = w1[r] = 0;
-            for (int k = 0; k < sw - sx0; ++k) {
-                w0[r] |= (unsigned long long)S0[k] << (8 * k);
-                w1[r] |= (unsigned long long)S1[k] << (8 * k);
-            }
-        }
+        sy0[r] = min(max(ty.ofs, 0), sh - 1);
+        sy1[r] = min(max(ty.ofs + 1, 0), sh - 1);
+    }
+    const int ofs[4] = {(int)t01.x, (int)t01.z, (int)t23.x, (int)t23.z};
+    const uint32_t cc[4] = {t01.y, t01.w, t23.y, t23.w}; // c0 | c1 << 16
+    const int sx0 = ofs[0];
+    // All 2 * RS_ROWS source windows are requested together, without a branch: a window that would run past the end of
+    // the row (right image edge; level 0 is the caller's buffer, nothing may be read beyond it) is fetched from the last 8
+    // bytes of the row instead and shifted into place -- the bytes that fall off are zero, and the taps never select them.
+    const int sxl = min(sx0, sw - 8);
+    const uint32_t sft = (uint32_t)(sx0 - sxl) * 8u; // 0 .. 56
+    unsigned long long w0[RS_ROWS], w1[RS_ROWS];
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+        w0[r] = reinterpret_cast<const UnalignedU64 *>(S + (size_t)sy0[r] * src_pitch + sxl)->v;
+        w1[r] = reinterpret_cast<const UnalignedU64 *>(S + (size_t)sy1[r] * src_pitch + sxl)->v;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+        w0[r] >>= sft;
+        w1[r] >>= sft;
     }
     uint32_t sel[4];
 #pragma unroll
