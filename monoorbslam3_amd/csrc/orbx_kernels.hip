@@ -942,16 +942,29 @@ struct OctL {
 };
 #define OCT_NORANK 0xFFFFu
 
+#define OCT_UNROLL 4
 __device__ __forceinline__ void octl_child_counts(const OctL &c, int cur, int nrank)
 {
     for (int i = threadIdx.x; i < 4 * nrank; i += ORBX_OCT_THREADS) c.childcnt[i] = 0;
     __syncthreads();
-    for (int p = threadIdx.x; p < c.n; p += ORBX_OCT_THREADS) {
-        const uint32_t old = c.pnode[p], code = c.pcode[p];
-        const uint32_t r = c.rank[old];
-        if (r != OCT_NORANK) {
-            const uint32_t d = (cur ? c.node[1] : c.node[0])[old] >> 24;
-            atomicAdd(&c.childcnt[4 * r + ((code >> (30 - 2 * d)) & 3)], 1u);
+    // candidate loops: OCT_UNROLL global loads per thread are requested before the first is used (clamped index, no branch
+    // around the loads), otherwise every candidate costs a full memory latency
+    for (int p0 = threadIdx.x; p0 < c.n; p0 += OCT_UNROLL * ORBX_OCT_THREADS) {
+        uint32_t old[OCT_UNROLL], code[OCT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < OCT_UNROLL; ++u) {
+            const int p = min(p0 + u * ORBX_OCT_THREADS, c.n - 1);
+            old[u] = c.pnode[p];
+            code[u] = c.pcode[p];
+        }
+#pragma unroll
+        for (int u = 0; u < OCT_UNROLL; ++u) {
+            if (p0 + u * ORBX_OCT_THREADS >= c.n) break;
+            const uint32_t r = c.rank[old[u]];
+            if (r != OCT_NORANK) {
+                const uint32_t d = (cur ? c.node[1] : c.node[0])[old[u]] >> 24;
+                atomicAdd(&c.childcnt[4 * r + ((code[u] >> (30 - 2 * d)) & 3)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -997,17 +1010,28 @@ __device__ __forceinline__ void octl_apply(const OctL &c, int cur, int size, int
         }
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < c.n; p += ORBX_OCT_THREADS) {
-        const uint32_t old = c.pnode[p];
-        const uint32_t r = c.rank[old];
-        uint32_t np;
-        if (r < (uint32_t)nsplit) {
-            const uint32_t d = (cur ? c.node[1] : c.node[0])[old] >> 24;
-            np = c.childpos[4 * r + ((c.pcode[p] >> (30 - 2 * d)) & 3)];
-        } else {
-            np = c.newpos[old];
+    for (int p0 = threadIdx.x; p0 < c.n; p0 += OCT_UNROLL * ORBX_OCT_THREADS) {
+        uint32_t old[OCT_UNROLL], code[OCT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < OCT_UNROLL; ++u) {
+            const int p = min(p0 + u * ORBX_OCT_THREADS, c.n - 1);
+            old[u] = c.pnode[p];
+            code[u] = c.pcode[p];
         }
-        c.pnode[p] = np;
+#pragma unroll
+        for (int u = 0; u < OCT_UNROLL; ++u) {
+            const int p = p0 + u * ORBX_OCT_THREADS;
+            if (p >= c.n) break;
+            const uint32_t r = c.rank[old[u]];
+            uint32_t np;
+            if (r < (uint32_t)nsplit) {
+                const uint32_t d = (cur ? c.node[1] : c.node[0])[old[u]] >> 24;
+                np = c.childpos[4 * r + ((code[u] >> (30 - 2 * d)) & 3)];
+            } else {
+                np = c.newpos[old[u]];
+            }
+            c.pnode[p] = np;
+        }
     }
     __syncthreads();
     *new_size = T + U;
@@ -1049,24 +1073,32 @@ __global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree_lds(const OrbxLevel
     int cur = 0;
     for (int i = tid; i < lv.n_ini; i += ORBX_OCT_THREADS) c.childcnt[i] = 0;
     __syncthreads();
-    for (int p = tid; p < c.n; p += ORBX_OCT_THREADS) {
-        const u64 cd = c.cand[p];
-        const int x = (int)(cd & 0xFFFF), y = (int)((cd >> 16) & 0xFFFF);
-        const int idx = x / lv.h_x;
-        int ulx = lv.h_x * idx, brx = (idx == lv.n_ini - 1) ? (lv.w - ORBX_EDGE) : lv.h_x * (idx + 1); // :665
-        int uly = 0, bry = lv.region_h;
-        uint32_t code = 0;
+    for (int p0 = tid; p0 < c.n; p0 += OCT_UNROLL * ORBX_OCT_THREADS) {
+        u64 cdv[OCT_UNROLL];
 #pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            const int midx = ulx + (brx - ulx) / 2, midy = uly + (bry - uly) / 2; // DivideNode :368-369
-            const int qx = x >= midx, qy = y >= midy;                             // :397-407
-            ulx = qx ? midx : ulx; brx = qx ? brx : midx;
-            uly = qy ? midy : uly; bry = qy ? bry : midy;
-            code |= (uint32_t)(qx | (qy << 1)) << (30 - 2 * d);
+        for (int u = 0; u < OCT_UNROLL; ++u) cdv[u] = c.cand[min(p0 + u * ORBX_OCT_THREADS, c.n - 1)];
+#pragma unroll
+        for (int u = 0; u < OCT_UNROLL; ++u) {
+            const int p = p0 + u * ORBX_OCT_THREADS;
+            if (p >= c.n) break;
+            const u64 cd = cdv[u];
+            const int x = (int)(cd & 0xFFFF), y = (int)((cd >> 16) & 0xFFFF);
+            const int idx = x / lv.h_x;
+            int ulx = lv.h_x * idx, brx = (idx == lv.n_ini - 1) ? (lv.w - ORBX_EDGE) : lv.h_x * (idx + 1); // :665
+            int uly = 0, bry = lv.region_h;
+            uint32_t code = 0;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                const int midx = ulx + (brx - ulx) / 2, midy = uly + (bry - uly) / 2; // DivideNode :368-369
+                const int qx = x >= midx, qy = y >= midy;                             // :397-407
+                ulx = qx ? midx : ulx; brx = qx ? brx : midx;
+                uly = qy ? midy : uly; bry = qy ? bry : midy;
+                code |= (uint32_t)(qx | (qy << 1)) << (30 - 2 * d);
+            }
+            c.pcode[p] = code;
+            c.pnode[p] = idx;
+            atomicAdd(&c.childcnt[idx], 1u);
         }
-        c.pcode[p] = code;
-        c.pnode[p] = idx;
-        atomicAdd(&c.childcnt[idx], 1u);
     }
     __syncthreads();
     int size;
@@ -1082,7 +1114,14 @@ __global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree_lds(const OrbxLevel
                 c.newpos[i] = (uint16_t)pos++;
             }
         __syncthreads();
-        for (int p = tid; p < c.n; p += ORBX_OCT_THREADS) c.pnode[p] = c.newpos[c.pnode[p]];
+        for (int p0 = tid; p0 < c.n; p0 += OCT_UNROLL * ORBX_OCT_THREADS) {
+            uint32_t pn[OCT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < OCT_UNROLL; ++u) pn[u] = c.pnode[min(p0 + u * ORBX_OCT_THREADS, c.n - 1)];
+#pragma unroll
+            for (int u = 0; u < OCT_UNROLL; ++u)
+                if (p0 + u * ORBX_OCT_THREADS < c.n) c.pnode[p0 + u * ORBX_OCT_THREADS] = c.newpos[pn[u]];
+        }
         __syncthreads();
     }
 
@@ -1178,12 +1217,24 @@ __global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree_lds(const OrbxLevel
     for (int j = tid; j < size; j += ORBX_OCT_THREADS) best[j] = 0;
     __syncthreads();
     const uint32_t ncols = (uint32_t)lv.n_cols;
-    for (int p = tid; p < c.n; p += ORBX_OCT_THREADS) {
-        const u64 cd = c.cand[p];
-        const uint32_t x = (uint32_t)(cd & 0xFFFF), y = (uint32_t)((cd >> 16) & 0xFFFF), resp = (uint32_t)(cd >> 32);
-        const uint32_t order = ((y / ORBX_CELL) * ncols + x / ORBX_CELL) * (ORBX_CELL * ORBX_CELL) +
-                               (y % ORBX_CELL) * ORBX_CELL + x % ORBX_CELL;
-        atomicMax(&best[c.pnode[p]], ((u64)resp << 32) | (u64)(0xFFFFFFFFu - order));
+    for (int p0 = tid; p0 < c.n; p0 += OCT_UNROLL * ORBX_OCT_THREADS) {
+        u64 cdv[OCT_UNROLL];
+        uint32_t pn[OCT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < OCT_UNROLL; ++u) {
+            const int p = min(p0 + u * ORBX_OCT_THREADS, c.n - 1);
+            cdv[u] = c.cand[p];
+            pn[u] = c.pnode[p];
+        }
+#pragma unroll
+        for (int u = 0; u < OCT_UNROLL; ++u) {
+            if (p0 + u * ORBX_OCT_THREADS >= c.n) break;
+            const u64 cd = cdv[u];
+            const uint32_t x = (uint32_t)(cd & 0xFFFF), y = (uint32_t)((cd >> 16) & 0xFFFF), resp = (uint32_t)(cd >> 32);
+            const uint32_t order = ((y / ORBX_CELL) * ncols + x / ORBX_CELL) * (ORBX_CELL * ORBX_CELL) +
+                                   (y % ORBX_CELL) * ORBX_CELL + x % ORBX_CELL;
+            atomicMax(&best[pn[u]], ((u64)resp << 32) | (u64)(0xFFFFFFFFu - order));
+        }
     }
     __syncthreads();
     uint2 *sel = b.sel + (size_t)frame * levels->kcap_total + lv.kp_off;
