@@ -13,7 +13,8 @@ from collections import defaultdict
 
 STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_blur_cols": "blur", "k_octree_lds": "octree",
          "k_orient": "orient_desc", "k_orient_desc": "orient_desc", "k_best2": "match_best2"}
-LAUNCHES_PER_STEP = {"k_resize": 7}
+# per-step totals = sum over all dispatches of a kernel / number of steps in the run; a step has exactly one quadtree launch
+STEP_MARKER = "k_octree_lds"
 
 
 def per_kernel(root):
@@ -29,13 +30,12 @@ def main():
     res = defaultdict(float)
     detail = {}
     for label, root in (("fetch", fetch), ("write", write)):
-        for k, v in per_kernel(root).items():
+        acc = per_kernel(root)
+        n_steps = max(len(acc.get(STEP_MARKER, [])), 1)
+        for k, v in acc.items():
             if k not in STAGE:
                 continue
-            if k == "k_best2":  # bench launches a (B-1)-pair and a 1-pair problem: sum both
-                per_step = sum(v) / (len(v) / 2)
-            else:
-                per_step = sum(v) / len(v) * LAUNCHES_PER_STEP.get(k, 1)
+            per_step = sum(v) / n_steps  # resize: 7 launches, FAST: 2 (level 0 early + the rest), best-2: 2 per step
             res[STAGE[k]] += per_step * 1024 * (2 if label == "fetch" else 1)
             detail["%s.%s_KB" % (k, label)] = round(per_step, 1)
     json.dump({"batch": batch, "unit": "bytes per stage per step (all launches of the stage); fetch = 2 x FETCH_SIZE",

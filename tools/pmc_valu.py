@@ -10,7 +10,7 @@ from collections import defaultdict
 STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_blur_cols": "blur", "k_blur_edges": "blur",
          "k_octree_lds": "octree", "k_octree": "octree", "k_orient": "orient_desc", "k_orient_desc": "orient_desc",
          "k_best2": "match_best2"}
-LAUNCHES_PER_STEP = {"k_resize": 7}
+STEP_MARKER = "k_octree_lds"  # exactly one launch per step: per-step totals = sum over all dispatches / its count
 
 
 def main():
@@ -21,13 +21,11 @@ def main():
             if row["Counter_Name"] == "SQ_INSTS_VALU":
                 acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
     res, detail = defaultdict(float), {}
+    n_steps = max(len(acc.get(STEP_MARKER, [])), 1)
     for k, v in acc.items():
         if k not in STAGE:
             continue
-        if k == "k_best2":  # bench launches a (B-1)-pair and a 1-pair problem per step: sum both
-            per_step = sum(v) / (len(v) / 2)
-        else:
-            per_step = sum(v) / len(v) * LAUNCHES_PER_STEP.get(k, 1)
+        per_step = sum(v) / n_steps  # resize: 7 launches per step, FAST and best-2: 2
         res[STAGE[k]] += per_step
         detail[k] = round(per_step)
     json.dump({"batch": batch, "unit": "VALU wave-instructions per stage per step (SQ_INSTS_VALU, all launches)",
