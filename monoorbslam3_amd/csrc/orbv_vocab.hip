@@ -84,11 +84,23 @@ __global__ __launch_bounds__(256) void k_voc_descend(VocDev v, const uint8_t *__
     do {
         ++level;
         int best = 0x7fffffff, arg = b;
-        for (int c = b; c < e; ++c) {
-            const int d = ham256(a0, a1, v.pk_desc[2 * (size_t)c], v.pk_desc[2 * (size_t)c + 1]);
-            if (d < best) { // strict: the first child keeps ties (:1241)
-                best = d;
-                arg = c;
+        // children in groups of five whose ten 128-bit loads are requested together (index clamped, no branch around the
+        // loads: a loop with a dynamic trip count would otherwise cost one memory latency per child)
+        for (int c0 = b; c0 < e; c0 += 5) {
+            uint4 lo[5], hi[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const size_t c = (size_t)min(c0 + u, e - 1);
+                lo[u] = v.pk_desc[2 * c];
+                hi[u] = v.pk_desc[2 * c + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int d = ham256(a0, a1, lo[u], hi[u]);
+                if (c0 + u < e && d < best) { // strict: the first child keeps ties (:1241)
+                    best = d;
+                    arg = c0 + u;
+                }
             }
         }
         node = (int)v.pk_id[arg];
