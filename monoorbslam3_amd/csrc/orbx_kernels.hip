@@ -497,6 +497,29 @@ __device__ __forceinline__ void blur_strip(const uint8_t *__restrict__ S, int pi
         // a ring of seven register triples indexed like hq (slot = n % 7, compile-time in the unrolled loop): no register
         // copies, which would make the wave wait for the very loads that are meant to stay in flight
         U96 q[7];
+        if (ys - 3 >= 0 && ys - 3 + n_rows + 2 <= h) {
+            // band in the interior of the level (wave-uniform): every row it touches, the two prefetched beyond it
+            // included, exists -- the row pointer just advances by the pitch
+            const uint8_t *rp = S + (size_t)(ys - 3) * pitch + x - 4;
+            q[0] = *reinterpret_cast<const U96 *>(rp);
+            q[1] = *reinterpret_cast<const U96 *>(rp + pitch);
+            rp += 2 * (size_t)pitch;
+            for (int n0 = 0; n0 < n_rows; n0 += 7) {
+#pragma unroll
+                for (int s = 0; s < 7; ++s) {
+                    const int n = n0 + s;
+                    q[(s + 2) % 7] = *reinterpret_cast<const U96 *>(rp);
+                    rp += (n + 3 < n_rows + 2) ? pitch : 0; // stop at the last existing prefetch row
+                    blur_hrow(q[s].w[0], q[s].w[1], q[s].w[2], K0, K1, hq[s]);
+                    if (clamp16) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hq[s][i] = min(hq[s][i], 65535u);
+                    }
+                    if (n >= 6 && n < n_rows) emit(s, n);
+                }
+            }
+            return;
+        }
         q[0] = fetch(0);
         q[1] = fetch(1);
         // the body has no branch on n (rows past the band are clamped re-reads whose results are never stored), so that
