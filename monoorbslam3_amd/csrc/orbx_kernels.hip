@@ -37,7 +37,7 @@ __constant__ __attribute__((aligned(16))) int8_t c_pattern[ORB_PATTERN_POINTS * 
 // loads.
 struct __attribute__((packed, aligned(1))) UnalignedU64 { unsigned long long v; };
 
-#define RS_ROWS 4 // output rows per thread: 2*RS_ROWS independent 64-bit loads in flight per thread
+#define RS_ROWS 8 // output rows per thread: 2*RS_ROWS independent 64-bit loads in flight per thread
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, size_t src_fs, int src_pitch, int sw,
                                                 int sh, uint8_t *__restrict__ dst, size_t dst_fs, int dst_pitch,
                                                 int dw, int dh, const OrbxTap *__restrict__ xtap,
