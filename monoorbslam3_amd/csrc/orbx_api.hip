@@ -516,6 +516,9 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_start[slot], 0));
         orbx_launch_fast(c->side[slot], d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_cells, n_cells0, n_frames);
         HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
+        if (c->early_fast > 1) // level 0 needs no pyramid for its blur either
+            orbx_launch_blur(c->side[slot], d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps,
+                             n_frames, 0, 1);
     }
     for (int l = 1; l < L; ++l) {
         const uint8_t *sp; size_t sfs; int spitch;
@@ -530,7 +533,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         HIP_TRY(hipEventRecord(c->ev_pyr[slot], s));
         HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_pyr[slot], 0));
         orbx_launch_blur(c->side[slot], d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps,
-                         n_frames);
+                         n_frames, (early && c->early_fast > 1) ? 1 : 0, L);
         HIP_TRY(hipEventRecord(c->ev_blur[slot], c->side[slot]));
         return ORBX_OK;
     };
@@ -545,7 +548,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
     if (side && c->side_blur != 1) { int rc = fork_blur(); if (rc) return rc; } // next to the quadtree and orientation
     if (!side)
-        orbx_launch_blur(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames);
+        orbx_launch_blur(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames, 0, L);
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));
     orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes);
     if (t) HIP_TRY(hipEventRecord(c->ev[4], s));

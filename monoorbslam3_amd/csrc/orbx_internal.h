@@ -70,7 +70,7 @@ void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pit
 int orbx_build_fast_cells(const OrbxLevels &levels, uint16_t *out);
 void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                       const OrbxLevels &levels, const OrbxBuffers &b, const void *d_tiles, int n_tiles, const int *taps7,
-                      int n_frames);
+                      int n_frames, int level_begin, int level_end);
 int orbx_build_blur_tiles(const OrbxLevels &levels, uint16_t *out);
 void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLevels &levels, const OrbxBuffers &b,
                         int n_frames, size_t sort_lds_bytes);

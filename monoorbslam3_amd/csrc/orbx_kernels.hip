@@ -582,9 +582,9 @@ __global__ __launch_bounds__(256) void k_blur_cols(FastSrc src, const OrbxLevels
 #define BE_ROWS 8
 __global__ __launch_bounds__(64) void k_blur_edges(FastSrc src, const OrbxLevels *__restrict__ levels,
                                                    uint8_t *__restrict__ arena, size_t arena_fs,
-                                                   const int *__restrict__ taps)
+                                                   const int *__restrict__ taps, int level_begin)
 {
-    const int frame = blockIdx.y, level = blockIdx.z;
+    const int frame = blockIdx.y, level = level_begin + blockIdx.z;
     const OrbxLevel &lv = levels->lv[level];
     const int w = lv.w, h = lv.h, pitch = src.pitch[level];
     const int task = blockIdx.x * 64 + threadIdx.x;
@@ -606,24 +606,34 @@ __global__ __launch_bounds__(64) void k_blur_edges(FastSrc src, const OrbxLevels
     blur_strip<true>(S, pitch, w, h, D, lv.pitch, x, ys, min(ys + BE_ROWS, h), k, K0, K1, ksum > 256);
 }
 
+// levels [level_begin, level_end) of the blurred pyramid; the tile list is level-major
 void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                       const OrbxLevels &levels, const OrbxBuffers &b, const void *d_tiles, int n_tiles, const int *taps7,
-                      int n_frames)
+                      int n_frames, int level_begin, int level_end)
 {
-    if (n_tiles <= 0) return;
+    if (n_tiles <= 0 || level_begin >= level_end) return;
     FastSrc src;
     for (int l = 0; l < levels.n_levels; ++l) {
         src.base[l] = l == 0 ? l0 : b.img_arena + levels.lv[l].raw_off;
         src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
         src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
     }
-    hipLaunchKernelGGL(k_blur_cols, dim3(orbx_xcd_grid(n_tiles, n_frames)), dim3(256), 0, s, src, d_levels,
-                       reinterpret_cast<const BlurTile *>(d_tiles), b.img_arena, b.img_frame_stride, taps7, n_tiles, n_frames);
-    int max_h = 1;
-    for (int l = 0; l < levels.n_levels; ++l) max_h = levels.lv[l].h > max_h ? levels.lv[l].h : max_h;
+    int first = 0, count = 0, max_h = 1;
+    for (int l = 0; l < level_end; ++l) {
+        const int nt = ((levels.lv[l].h + BL_H - 1) / BL_H) * ((levels.lv[l].w + BL_W - 1) / BL_W);
+        if (l < level_begin) first += nt;
+        else {
+            count += nt;
+            max_h = levels.lv[l].h > max_h ? levels.lv[l].h : max_h;
+        }
+    }
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_blur_cols, dim3(orbx_xcd_grid(count, n_frames)), dim3(256), 0, s, src, d_levels,
+                       reinterpret_cast<const BlurTile *>(d_tiles) + first, b.img_arena, b.img_frame_stride, taps7, count,
+                       n_frames);
     const int tasks = 3 * ((max_h + BE_ROWS - 1) / BE_ROWS);
-    hipLaunchKernelGGL(k_blur_edges, dim3((tasks + 63) / 64, n_frames, levels.n_levels), dim3(64), 0, s, src, d_levels,
-                       b.img_arena, b.img_frame_stride, taps7);
+    hipLaunchKernelGGL(k_blur_edges, dim3((tasks + 63) / 64, n_frames, level_end - level_begin), dim3(64), 0, s, src, d_levels,
+                       b.img_arena, b.img_frame_stride, taps7, level_begin);
 }
 
 int orbx_build_blur_tiles(const OrbxLevels &levels, uint16_t *out /* 4 per tile, or NULL to count */)
