@@ -222,3 +222,44 @@ def test_golden_fixtures_through_the_c_abi(oracle_mod):
     assert np.array_equal(un["x"], z["un_x"]) and np.array_equal(un["y"], z["un_y"])
     assert np.array_equal(start, z["cell_start"]) and np.array_equal(items, z["cell_items"])
     assert ORBMatcher.ComputeDistinctiveDescriptors(z["g_desc"], z["g_off"]).tolist() == z["medoid"].tolist()
+
+
+def test_stream_layout_variants_give_identical_results(tmp_path):
+    """The internal stream layouts (ORBX_STREAMS / ORBX_SIDE_BLUR / ORBX_EARLY_FAST, read at handle creation) only change
+    what overlaps with what: every variant must return the default layout's bytes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "variant.py"
+    script.write_text(
+        "import sys, hashlib\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from monoorbslam3_amd import synth\n"
+        "from monoorbslam3_amd.extractor import ORBExtractor\n"
+        "B, W, H = 24, 640, 360\n"
+        "fr = torch.from_numpy(synth.make_frames(B, W, H, seed=5)).cuda()\n"
+        "ex = ORBExtractor(800, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)\n"
+        "cap = ex.max_keypoints(W, H)\n"
+        "kp = torch.zeros((B, cap, 28), dtype=torch.uint8, device='cuda')\n"
+        "de = torch.zeros((B, cap, 32), dtype=torch.uint8, device='cuda')\n"
+        "n = torch.zeros(B, dtype=torch.int32, device='cuda')\n"
+        "s = torch.cuda.Stream()\n"
+        "for _ in range(2):\n"
+        "    ex.extract_batch_device(fr.data_ptr(), B, W, H, W, W * H, kp.data_ptr(), de.data_ptr(), cap, n.data_ptr(), s.cuda_stream)\n"
+        "s.synchronize()\n"
+        "h = hashlib.sha256()\n"
+        "nn = n.cpu().numpy()\n"
+        "for f in range(B):\n"
+        "    h.update(kp[f, :nn[f]].cpu().numpy().tobytes()); h.update(de[f, :nn[f]].cpu().numpy().tobytes())\n"
+        "print(int(nn.sum()), h.hexdigest())\n" % root)
+    results = {}
+    for name, env in (("default", {}), ("streams3", {"ORBX_STREAMS": "3"}), ("no_side", {"ORBX_SIDE_BLUR": "0"}),
+                      ("blur_after_fast", {"ORBX_SIDE_BLUR": "2"}), ("no_early_fast", {"ORBX_EARLY_FAST": "0"}),
+                      ("early_blur", {"ORBX_EARLY_FAST": "2"})):
+        e = dict(os.environ)
+        e.update(env)
+        results[name] = subprocess.check_output([sys.executable, str(script)], env=e, text=True).strip().splitlines()[-1]
+    assert len(set(results.values())) == 1, results
+    assert int(results["default"].split()[0]) > 24 * 500
