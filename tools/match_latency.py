@@ -20,12 +20,15 @@ mp0 = np.full(n, -1, np.int32)
 m = ORBMatcher(0.7, True)
 
 
-def timeit(fn, reps=20):
+def timeit(fn, reps=21):
+    """median of `reps` calls in ms (single calls are occasionally hit by a host-side hiccup of tens of ms)"""
     fn()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         fn()
-    return (time.perf_counter() - t0) / reps * 1e3
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2] * 1e3
 
 
 for bits, label in ((0, "dense: one node, 2000x2000 pairs"), (4, "16 nodes (~125/node)"), (10, "~1000 nodes (~2/node)")):
