@@ -217,7 +217,10 @@ __global__ __launch_bounds__(256) void k_hamming_lists(const uint8_t *__restrict
 // The K smallest (distance << 16 | position-in-list) keys of every query's candidate list, one wave per query.
 // Candidates whose byte in `cand_free` is 0 are not considered.  Lists longer than 65535 are not supported here
 // (the caller falls back to the full distance lists).  Missing entries are 0xFFFFFFFF.
-#define TOPK 4
+// K = 8 for short candidate lists, 16 when a list is long (many queries then compete for the same few candidates and
+// the sequential pass would otherwise run out of entries and recompute rows on the host: 0.92 ms at K = 4, 0.37 at 8,
+// 0.24 at 16 for one dense 2000 x 2000 node)
+template <int TOPK>
 __global__ __launch_bounds__(256) void k_topk_lists(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
                                                     const int32_t *__restrict__ q_idx,
                                                     const int32_t *__restrict__ c_begin,
@@ -466,9 +469,13 @@ static int hamming_lists(orbm_ctx *c, const uint8_t *a, int na, const uint8_t *b
 // top-K keys per query (see k_topk_lists); `cand_free` has nb bytes (1 = candidate may be used), may be NULL
 static int topk_lists(orbm_ctx *c, const uint8_t *a, int na, const uint8_t *b, int nb, const std::vector<int32_t> &q_idx,
                       const std::vector<int32_t> &c_begin, const std::vector<int32_t> &c_len, const int32_t *c_idx,
-                      size_t n_cidx, const uint8_t *cand_free, std::vector<uint32_t> &out)
+                      size_t n_cidx, const uint8_t *cand_free, std::vector<uint32_t> &out, int *k_out)
 {
     const int nq = (int)q_idx.size();
+    int max_len = 0;
+    for (int len : c_len) max_len = std::max(max_len, len);
+    const int TOPK = max_len > 256 ? 16 : 8;
+    *k_out = TOPK;
     out.assign((size_t)nq * TOPK, 0xFFFFFFFFu);
     if (nq == 0 || n_cidx == 0) return ORBX_OK;
     M_TRY(hipSetDevice(c->device));
@@ -492,9 +499,14 @@ static int topk_lists(orbm_ctx *c, const uint8_t *a, int na, const uint8_t *b, i
         M_TRY(hipMemcpyAsync(c->col_ok.p, cand_free, (size_t)nb, hipMemcpyHostToDevice, s));
         d_free = (const uint8_t *)c->col_ok.p;
     }
-    hipLaunchKernelGGL(k_topk_lists, dim3((nq + 3) / 4), dim3(256), 0, s, (const uint8_t *)c->a.p, (const uint8_t *)c->b.p,
-                       (const int32_t *)c->q_idx.p, (const int32_t *)c->c_begin.p, (const int32_t *)c->c_len.p, nq,
-                       (const int32_t *)c->c_idx.p, d_free, (uint32_t *)c->out.p);
+    if (TOPK == 16)
+        hipLaunchKernelGGL(k_topk_lists<16>, dim3((nq + 3) / 4), dim3(256), 0, s, (const uint8_t *)c->a.p, (const uint8_t *)c->b.p,
+                           (const int32_t *)c->q_idx.p, (const int32_t *)c->c_begin.p, (const int32_t *)c->c_len.p, nq,
+                           (const int32_t *)c->c_idx.p, d_free, (uint32_t *)c->out.p);
+    else
+        hipLaunchKernelGGL(k_topk_lists<8>, dim3((nq + 3) / 4), dim3(256), 0, s, (const uint8_t *)c->a.p, (const uint8_t *)c->b.p,
+                           (const int32_t *)c->q_idx.p, (const int32_t *)c->c_begin.p, (const int32_t *)c->c_len.p, nq,
+                           (const int32_t *)c->c_idx.p, d_free, (uint32_t *)c->out.p);
     M_TRY(hipGetLastError());
     M_TRY(hipMemcpyAsync(out.data(), c->out.p, (size_t)nq * TOPK * 4, hipMemcpyDeviceToHost, s));
     M_TRY(hipStreamSynchronize(s));
@@ -668,10 +680,10 @@ extern "C" int orbm_search_by_bow(orbm_t *c, float nn_ratio, int check_orientati
     for (int j = 0; j < n2; ++j) free0[j] = frame_mp[j] == -1;
     std::vector<uint32_t> topk;
     std::vector<uint16_t> dist;
-    int rc;
+    int rc, TOPK = 8;
     if (!long_list)
         rc = topk_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, reinterpret_cast<const int32_t *>(fv2->indices),
-                        (size_t)fv2->offsets[fv2->n_nodes], free0.data(), topk);
+                        (size_t)fv2->offsets[fv2->n_nodes], free0.data(), topk, &TOPK);
     else
         rc = hamming_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.out_begin,
                            reinterpret_cast<const int32_t *>(fv2->indices), (size_t)fv2->offsets[fv2->n_nodes], q.n_out, dist);
@@ -749,10 +761,10 @@ extern "C" int orbm_search_for_triangulation(orbm_t *c, int check_orientation, c
     for (int j = 0; j < n2; ++j) free0[j] = !has_mp2[j];
     std::vector<uint32_t> topk;
     std::vector<uint16_t> dist;
-    int rc;
+    int rc, TOPK = 8;
     if (!long_list)
         rc = topk_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, reinterpret_cast<const int32_t *>(fv2->indices),
-                        (size_t)fv2->offsets[fv2->n_nodes], free0.data(), topk);
+                        (size_t)fv2->offsets[fv2->n_nodes], free0.data(), topk, &TOPK);
     else
         rc = hamming_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.out_begin,
                            reinterpret_cast<const int32_t *>(fv2->indices), (size_t)fv2->offsets[fv2->n_nodes], q.n_out, dist);
