@@ -67,7 +67,10 @@ typedef struct orbba_lm_result {
     double *pose_R;  /* n_poses x 9, optimised (fixed poses unchanged) */
     double *pose_t;  /* n_poses x 3 */
     double *points;  /* n_points x 3 */
-    double *chi2;    /* n_edges: e^T Omega e at the final estimate (inactive edges included, as e->chi2() at :917) */
+    double *chi2;    /* n_edges: e^T Omega e at the final estimate, also for edges that options.edge_active switches off.
+                      * orbba_local_bundle_adjustment overwrites the entries of the edges it demoted after its first
+                      * round with their first-round value: g2o never recomputes the error of a level-1 edge, so that is
+                      * what e->chi2() returns at Optimize.cpp:919 */
     int32_t iterations, trials; /* outer LM iterations run, linear solves tried */
     double lambda;              /* final damping */
     double chi2_initial, chi2_final; /* activeRobustChi2 before / after */
@@ -80,7 +83,9 @@ typedef struct orbba_lm_result {
 int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o, orbba_lm_result *r, int device);
 
 /* Optimize.cpp:892-922: optimize(5) with Huber; edges with chi2 > 5.991 go to level 1 and the kernel is dropped;
- * optimize(10); outlier[e] = final chi2 > 5.991 (the observations the reference then erases).  outlier may be NULL. */
+ * optimize(10); outlier[e] = 1 for every edge demoted after the first round (its stale e->chi2() stays above 5.991, see
+ * orbba_lm_result.chi2) and for every still-active edge whose chi2 at the final estimate exceeds 5.991 -- the
+ * observations the reference then erases (:917-935).  outlier may be NULL. */
 int orbba_local_bundle_adjustment(const orbba_problem *p, orbba_lm_result *r, uint8_t *outlier, int device);
 
 /* Optimize::poseOptimize (modules/Backend/Optimize.cpp:444-545) for a batch of frames at once: per frame one

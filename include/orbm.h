@@ -122,6 +122,22 @@ int orbm_search_by_projection_points(orbm_t *h, float nn_ratio,
                                      const void *kps2, const uint8_t *desc2, int n2, int img_w, int img_h,
                                      int32_t *frame_mp, int *n_matches, int32_t *counters);
 
+/* static ORBMatcher::SearchByProjection(keyFrame, mapPoints, Map *pointMap, th) -- the map-point fuse that
+ * LocalMapping.cpp:282,301 calls (modules/ORB/ORBMatcher.h:44-45, ORBMatcher.cpp:524-592).  This entry point is the part
+ * of the loop body that reads no MapPoint / KeyFrame state: for map point i with q_ok[i] = 1 (the caller evaluated
+ * :534-552: projection in front of the camera and in the image, distance invariance, viewing angle) it walks
+ * KeyFrame::getFeaturesInArea(p.x, p.y, radius, predictLevel-1, predictLevel) (KeyFrame.cpp:181-211, STRICT window
+ * test), drops key points whose squared re-projection error exceeds 5.991 * sigma2[octave] (:566-567, float against
+ * double) and returns the closest descriptor with distance < TH_LOW + 1 (:560, :569-574, first on ties):
+ * best_idx[i] = key-point index or -1, best_dist[i] = its distance (TH_LOW + 1 when none).  q_radius[i] =
+ * th * scale_factor[predictLevel] (:555), sigma2 = ORBExtractor::getSquareSigmas() (n_levels entries).
+ * The caller replays :534 (null / bad / already observed, evaluated live) and :577-591 (addObservation / replace)
+ * in map-point order on its own objects -- see compat/ORBMatcher.h. */
+int orbm_search_fuse(orbm_t *h, const uint8_t *q_desc, const float *q_xy, const float *q_radius,
+                     const int32_t *q_level, const uint8_t *q_ok, int nq,
+                     const void *kps, const uint8_t *desc, int n, int img_w, int img_h,
+                     const float *sigma2, int n_levels, int32_t *best_idx, int32_t *best_dist, int *n_found);
+
 /* MapPoint::computeDescriptor (modules/BasicObject/MapPoint.cpp:103-152) for n_groups map points at once.
  * Group g = the descriptors desc[off[g] .. off[g+1]) of one point's observations (the caller skips bad key frames,
  * :115-120).  best_idx[g] = index inside the group of the descriptor with the least median Hamming distance to the

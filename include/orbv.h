@@ -55,7 +55,8 @@ int orbv_transform_features_device(orbv_t *h, const uint8_t *d_desc, int n, int 
                                    uint32_t *d_node, double *d_weight, void *stream);
 
 /* transform(features, BowVector, FeatureVector, levelsup) (:1127-1201) for a batch of frames.  Device pointers:
- *   d_desc [n_frames][cap][32], d_n [n_frames] (each <= min(cap, ORBV_MAX_FEATURES))
+ *   d_desc [n_frames][cap][32], d_n [n_frames] (each <= cap; cap > ORBV_MAX_FEATURES is refused with
+ *   ORBX_E_UNSUPPORTED, a count above cap is clamped to cap as orbx_extract_batch_device clamps its records)
  *   d_bow_ids / d_bow_vals [n_frames][cap], d_n_words [n_frames]          BowVector, ascending word id
  *   d_fv_nodes [n_frames][cap], d_fv_off [n_frames][cap + 1], d_fv_idx [n_frames][cap], d_n_fv [n_frames]
  *                                                                        FeatureVector as CSR, ascending node id,

@@ -94,8 +94,12 @@ int orbx_extract_batch(orbx_t *h, const uint8_t *imgs, int n_frames, int width, 
 
 /* Same, but every pointer is DEVICE memory (inputs already resident in HBM, the
  * bench path) and the work is enqueued on `stream` (a hipStream_t, NULL = the
- * handle's own stream) without a host synchronisation.  d_n_out[f] may exceed
- * cap; only min(n,cap) records are written. */
+ * handle's own stream) without a host synchronisation.  There is no host-visible
+ * status for a frame that found more key points than `cap` (the host-pointer calls
+ * return ORBX_E_CAPACITY): d_n_out[f] then holds the FULL count, > cap, and only the
+ * first cap records are written -- a consumer must use min(d_n_out[f], cap), as every
+ * device entry point of this library does, or size cap with orbx_max_keypoints(),
+ * which no frame can exceed. */
 int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_imgs, int n_frames, int width, int height,
                               int stride, size_t frame_stride, orbx_kp *d_out_kp, uint8_t *d_out_desc,
                               int cap, int32_t *d_n_out, void *stream);

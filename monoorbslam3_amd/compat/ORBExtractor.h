@@ -46,7 +46,7 @@ namespace mono_orb_slam3 {
             cfg.device = -1;
             check(orbx_create(&cfg, &handle_));
             n_features = nFeatures, ini_th_fast = iniThFast, min_th_fast = minThFast;
-            publishTables(); // the reference keeps the pyramid tables in static members written by this ctor
+            publishTables(scaleFactor); // the reference keeps the pyramid tables in static members written by this ctor
         }
 
         // reference ORBExtractor.h:32 / ORBExtractor.cpp:477-493 (the 2N "initial" extractor, Tracking.cpp:24)
@@ -149,12 +149,12 @@ namespace mono_orb_slam3 {
             u_max.assign(um, um + 16);
         }
 
-        void publishTables() {
+        void publishTables(float scaleFactor) {
             int L = 0;
             float sf[ORBX_MAX_LEVELS], isf[ORBX_MAX_LEVELS], ss[ORBX_MAX_LEVELS], iss[ORBX_MAX_LEVELS], lsf = 0;
             check(orbx_tables(handle_, &L, sf, isf, ss, iss, &lsf, nullptr, nullptr));
             n_levels = L;
-            scale_factor = L > 1 ? sf[1] : 1.f;
+            scale_factor = scaleFactor; // stored unconditionally, also for one level (ORBExtractor.cpp:427)
             log_sale_factor = lsf;
             scale_factors.assign(sf, sf + L);
             inv_scale_factors.assign(isf, isf + L);

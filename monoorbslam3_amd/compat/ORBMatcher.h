@@ -5,8 +5,11 @@
 // SearchForTriangulation, and (inside the reference tree, where Camera / Pose exist) the three const
 // SearchByProjection overloads.  The Hamming brute force runs in HIP (include/orbm.h); the side effects on
 // Frame::map_points / matches12 are applied here so that the reference's objects stay the owners.
-// The static fuse SearchByProjection(keyFrame, mapPoints, Map*, th) (ORBMatcher.cpp:524-592) rewires
-// observations and replaces MapPoints per match; it keeps the reference's own implementation.
+// The static fuse SearchByProjection(keyFrame, mapPoints, Map*, th) (ORBMatcher.h:44-45, ORBMatcher.cpp:524-592) gets its
+// per-point window search from orbm_search_fuse and replays the observation rewiring (:577-591) here, in map-point
+// order, on the reference's own MapPoint / KeyFrame objects.  ComputeThreeMaxima (ORBMatcher.h:48) forwards to
+// orbm_three_maxima.  With these two the header declares every member of the reference's class, so the bodies in
+// modules/ORB/ORBMatcher.cpp are no longer compiled (drop the file from the target).
 //
 // Build: in a real integration include the reference's BasicObject headers before this one.  For this
 // repo's checks define ORBX_SHIM_USE_REF_MIRROR to get minimal mirror types (ref_mirror.h).
@@ -22,6 +25,7 @@
 
 #ifdef ORBX_SHIM_USE_REF_MIRROR
 #include "ref_mirror.h"
+#include "ORBExtractor.h" // the reference reaches it through BasicObject/Frame.h
 #else
 #include "BasicObject/Frame.h"
 #include "BasicObject/Map.h"
@@ -105,10 +109,9 @@ namespace mono_orb_slam3 {
             return n;
         }
 
-#ifndef ORBX_SHIM_USE_REF_MIRROR
-        // The window searches need the reference's Camera / Pose / MapPoint classes, so they are only compiled inside
-        // the reference tree (not in this repo's mirror-type checks).  The projection maths is copied call for call
-        // from the reference; candidate gathering, Hamming distances and the greedy pass run behind the C ABI.
+        // The projection maths below follows the reference call for call (it needs its Camera / Pose / MapPoint classes;
+        // this repo's checks run it on the mirror types of ref_mirror.h); candidate gathering, Hamming distances and the
+        // greedy pass run behind the C ABI.
 
         // reference ORBMatcher.h:28-30 / ORBMatcher.cpp:203-274
         [[nodiscard]] int SearchByProjection(const std::shared_ptr<Frame> &lastFrame, const std::shared_ptr<Frame> &curFrame,
@@ -156,10 +159,77 @@ namespace mono_orb_slam3 {
                            << counters[2] << "\n";                                                // :411-412
             return n;
         }
-#endif
+
+        // reference ORBMatcher.h:44-45 / ORBMatcher.cpp:524-592 (LocalMapping.cpp:282,301).  Static, like the reference's.
+        static int SearchByProjection(const std::shared_ptr<KeyFrame> &keyFrame,
+                                      const std::vector<std::shared_ptr<MapPoint>> &mapPoints, Map *pointMap, float th = 3) {
+            (void) pointMap; // the reference does not read it either (:524-592); MapPoint::replace holds its own Map*
+            const Camera *camera = Camera::getCamera();
+            const Pose Tcw = keyFrame->getPose();
+            const Eigen::Vector3f Ow = keyFrame->getCameraCenter();
+            const int nq = (int) mapPoints.size(), n1 = keyFrame->num_kps;
+            std::vector<unsigned char> desc((size_t) nq * 32, 0), ok((size_t) nq, 0);
+            std::vector<float> xy((size_t) nq * 2, 0.f), radius((size_t) nq, 0.f);
+            std::vector<int32_t> level((size_t) nq, 0);
+            // :534-556 for every point, except the three tests on mutable state (null / bad / already observed), which are
+            // evaluated live in the replay loop below: nothing computed here is changed by an earlier point's rewiring
+            for (int i = 0; i < nq; ++i) {
+                const std::shared_ptr<MapPoint> &mp = mapPoints[i];
+                if (mp == nullptr) continue;
+                const Eigen::Vector3f Pw = mp->getPos();
+                const Eigen::Vector3f Pc = Tcw.R * Pw + Tcw.t;                      // :537
+                if (Pc[2] < 0) continue;
+                const cv::Point2f p = camera->project(Pc);
+                if (!camera->isInImage(p)) continue;                               // :540-541
+                const Eigen::Vector3f OP = Pw - Ow;
+                const float distance = OP.norm();
+                const float maxDistance = mp->getMaxDistanceInvariance();
+                const float minDistance = mp->getMinDistanceInvariance();
+                if (distance < minDistance || distance > maxDistance) continue;    // :547
+                const Eigen::Vector3f Pn = mp->getAverageDirection();
+                if (OP.dot(Pn) < 0.5 * distance) continue;                         // :550
+                const int predictLevel = mp->predictScaleLevel(distance);
+                ok[i] = 1;
+                level[i] = predictLevel;
+                radius[i] = th * ORBExtractor::getScaleFactor(predictLevel);       // :553
+                xy[2 * i] = p.x, xy[2 * i + 1] = p.y;
+                const cv::Mat d = mp->getDescriptor();
+                std::memcpy(&desc[(size_t) i * 32], d.ptr(), 32);
+            }
+            const std::vector<float> sigma2 = ORBExtractor::getSquareSigmas();
+            std::vector<int32_t> bestIdx((size_t) nq, -1), bestDist((size_t) nq, 0);
+            int found = 0;
+            check(orbm_search_fuse(handle(), desc.data(), xy.data(), radius.data(), level.data(), ok.data(), nq,
+                                   keyFrame->key_points.data(), rows(keyFrame->descriptors), n1, imageCols(*keyFrame),
+                                   imageRows(*keyFrame), sigma2.data(), (int) sigma2.size(), bestIdx.data(),
+                                   bestDist.data(), &found));
+            int numMatch = 0;
+            for (int i = 0; i < nq; ++i) {
+                const std::shared_ptr<MapPoint> &mp = mapPoints[i];
+                if (mp == nullptr || mp->isBad() || mp->isObserveKeyFrame(keyFrame)) continue; // :534, live
+                if (!ok[i] || bestIdx[i] < 0) continue;                                        // :535-558, :577
+                const int bestIdx1 = bestIdx[i];
+                std::shared_ptr<MapPoint> mp1 = keyFrame->getMapPoint(bestIdx1);                // :578
+                if (mp1 == nullptr) {
+                    mp->addObservation(keyFrame, bestIdx1);
+                    keyFrame->addMapPoint(mp, bestIdx1);
+                } else if (!mp1->isBad()) {
+                    if (mp1->getNumObs() > mp->getNumObs()) mp->replace(mp1);
+                    else mp1->replace(mp);
+                }
+                numMatch++;                                                                     // :588
+            }
+            return numMatch;
+        }
 
     protected:
-#ifndef ORBX_SHIM_USE_REF_MIRROR
+        // reference ORBMatcher.h:48 / ORBMatcher.cpp:594-622
+        static void ComputeThreeMaxima(std::vector<int> *histo, int &ind1, int &ind2, int &ind3) {
+            int32_t sizes[ORBM_HISTO_LENGTH];
+            for (int i = 0; i < ORBM_HISTO_LENGTH; ++i) sizes[i] = (int32_t) histo[i].size();
+            orbm_three_maxima(sizes, ORBM_HISTO_LENGTH, &ind1, &ind2, &ind3);
+        }
+
         int projectionFromFrame(int nq, const std::vector<std::shared_ptr<MapPoint>> &mapPoints,
                                 const std::vector<cv::KeyPoint> &keyPoints, const std::shared_ptr<Frame> &curFrame,
                                 float th) const {
@@ -196,7 +266,7 @@ namespace mono_orb_slam3 {
                 if (fmp[j] >= 0 && fmp[j] != OCCUPIED) curFrame->map_points[j] = mapPoints[fmp[j]]; // :245
             return n;
         }
-#endif
+
         // DBoW2::FeatureVector (an ordered map node -> feature indices) flattened for the C ABI
         struct Csr {
             std::vector<uint32_t> ids, idx;

@@ -725,9 +725,15 @@ extern "C" int orbba_local_bundle_adjustment(const orbba_problem *p, orbba_lm_re
     r->iterations += r1.iterations;
     r->trials += r1.trials;
     r->chi2_initial = r1.chi2_initial;
+    // An edge demoted to level 1 at :899-902 is not part of optimize(10)'s active set: g2o never calls computeError()
+    // on it again, so e->chi2() at :919 still evaluates the error vector of the first round -- above 5.991 by
+    // construction -- and the observation is always erased, whatever its residual at the final estimate would be
+    // (poseOptimize has an explicit computeError() for exactly that reason, Optimize.cpp:510; this loop has none).
+    for (int e = 0; e < NE; ++e)
+        if (!active[e]) chi2v[e] = chi[e];
     if (user_chi) std::copy(chi2v.begin(), chi2v.end(), user_chi);
     if (outlier)
-        for (int e = 0; e < NE; ++e) outlier[e] = chi2v[e] > 5.991; // :917-921
+        for (int e = 0; e < NE; ++e) outlier[e] = !active[e] || chi2v[e] > 5.991; // :917-921
     return ORBX_OK;
 }
 

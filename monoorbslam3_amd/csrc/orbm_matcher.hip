@@ -925,7 +925,9 @@ struct FrameGrid {
         }
     }
     // Frame::getFeaturesInArea (Frame.cpp:97-127), appended to `out`
-    void area(const orbx_kp *kps, float x, float y, float r, int minLevel, int maxLevel, std::vector<int32_t> &out) const
+    // strict = KeyFrame::getFeaturesInArea (KeyFrame.cpp:181-211: `< r`), otherwise Frame's (`<= r`)
+    void area(const orbx_kp *kps, float x, float y, float r, int minLevel, int maxLevel, std::vector<int32_t> &out,
+              bool strict = false) const
     {
         const int minCX = std::max(0, orb_floor_f(x - r) / G), maxCX = std::min(cols - 1, orb_floor_f(x + r) / G);
         if (minCX > maxCX) return;
@@ -939,7 +941,8 @@ struct FrameGrid {
                         if (kps[j].octave < minLevel) continue;
                         if (maxLevel >= 0 && kps[j].octave > maxLevel) continue;
                     }
-                    if (fabsf(kps[j].x - x) <= r && fabsf(kps[j].y - y) <= r) out.push_back(j);
+                    const float ax = fabsf(kps[j].x - x), ay = fabsf(kps[j].y - y);
+                    if (strict ? (ax < r && ay < r) : (ax <= r && ay <= r)) out.push_back(j);
                 }
     }
 };
@@ -1045,5 +1048,59 @@ extern "C" int orbm_search_by_projection_points(orbm_t *c, float nn_ratio, const
     }
     if (counters) { counters[0] = n_out; counters[1] = fail1; counters[2] = fail2; }
     *n_matches = num;
+    return ORBX_OK;
+}
+
+// static ORBMatcher::SearchByProjection(keyFrame, mapPoints, Map*, th) -- the "fuse" of LocalMapping.cpp:282,301
+// (modules/ORB/ORBMatcher.cpp:524-592).  Per map point: KeyFrame window (strict test, levels predictLevel-1 ..
+// predictLevel, :554-556), chi-square gate on the re-projection error (:566-567), closest descriptor with
+// dist < TH_LOW + 1 (:560, :569-574).  Nothing here depends on the observation rewiring of :578-589, which the caller
+// replays in map-point order on its own objects.
+extern "C" int orbm_search_fuse(orbm_t *c, const uint8_t *q_desc, const float *q_xy, const float *q_radius,
+                                const int32_t *q_level, const uint8_t *q_ok, int nq, const void *kpsv,
+                                const uint8_t *desc, int n, int img_w, int img_h, const float *sigma2, int n_levels,
+                                int32_t *best_idx, int32_t *best_dist, int *n_found)
+{
+    if (!c || !q_desc || !q_xy || !q_radius || !q_level || !q_ok || !kpsv || !desc || !sigma2 || !best_idx || !best_dist ||
+        !n_found || n_levels < 1)
+        return orbx_set_error(ORBX_E_ARG, "null argument");
+    *n_found = 0;
+    for (int i = 0; i < nq; ++i) { best_idx[i] = -1; best_dist[i] = ORBM_TH_LOW + 1; }
+    if (nq <= 0 || n <= 0) return ORBX_OK;
+    const orbx_kp *kps = (const orbx_kp *)kpsv;
+    for (int j = 0; j < n; ++j)
+        if (kps[j].octave < 0 || kps[j].octave >= n_levels) return orbx_set_error(ORBX_E_ARG, "key-point octave outside the sigma2 table");
+    FrameGrid grid(kps, n, img_w, img_h);
+    WindowQueries q;
+    std::vector<int32_t> all;
+    for (int i = 0; i < nq; ++i) {
+        if (!q_ok[i]) continue;
+        all.clear();
+        grid.area(kps, q_xy[2 * i], q_xy[2 * i + 1], q_radius[i], q_level[i] - 1, q_level[i], all, true);
+        const size_t begin = q.c_idx.size();
+        const float px = q_xy[2 * i], py = q_xy[2 * i + 1];
+        for (int32_t j : all) {
+            const float e2 = (px - kps[j].x) * (px - kps[j].x) + (py - kps[j].y) * (py - kps[j].y);
+            if ((double)e2 > 5.991 * (double)sigma2[kps[j].octave]) continue; // :566-567
+            q.c_idx.push_back(j);
+        }
+        if (q.c_idx.size() == begin) continue;
+        q.q_idx.push_back(i); q.c_begin.push_back((int32_t)begin); q.c_len.push_back((int32_t)(q.c_idx.size() - begin));
+    }
+    std::vector<uint16_t> dist;
+    int rc = hamming_lists(c, q_desc, nq, desc, n, q.q_idx, q.c_begin, q.c_len, q.c_begin, q.c_idx.data(), q.c_idx.size(),
+                           q.c_idx.size(), dist);
+    if (rc) return rc;
+    int found = 0;
+    for (size_t k = 0; k < q.q_idx.size(); ++k) {
+        int bestDist = ORBM_TH_LOW + 1, bestIdx1 = -1;
+        for (int t = 0; t < q.c_len[k]; ++t) {
+            const int d = dist[q.c_begin[k] + t];
+            if (d < bestDist) { bestDist = d; bestIdx1 = q.c_idx[q.c_begin[k] + t]; }
+        }
+        best_idx[q.q_idx[k]] = bestIdx1; best_dist[q.q_idx[k]] = bestDist;
+        if (bestIdx1 != -1) ++found;
+    }
+    *n_found = found;
     return ORBX_OK;
 }

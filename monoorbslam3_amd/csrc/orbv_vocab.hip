@@ -458,6 +458,10 @@ extern "C" int orbv_transform_device(orbv_t *c, int n_frames, const uint8_t *d_d
     if (!c || !d_desc || !d_n || !d_bow_ids || !d_bow_vals || !d_n_words || !d_fv_nodes || !d_fv_off || !d_fv_idx || !d_n_fv)
         return orbx_set_error(ORBX_E_ARG, "null argument");
     if (n_frames < 0 || cap <= 0) return orbx_set_error(ORBX_E_ARG, "n_frames must be >= 0 and cap positive");
+    // the counts live on the device, so a frame with more features than the grouping kernel can sort cannot be
+    // reported from here: refuse a capacity that would allow one, like the host path refuses the count itself
+    if (cap > ORBV_MAX_FEATURES)
+        return orbx_set_error(ORBX_E_UNSUPPORTED, "cap exceeds ORBV_MAX_FEATURES features per frame");
     if (check_levelsup(levelsup)) return ORBX_E_ARG;
     if (n_frames == 0) return ORBX_OK;
     V_TRY(hipSetDevice(c->device));

@@ -50,6 +50,7 @@ def _mlib():
                                                       C.POINTER(i32)]),
             "orbm_search_by_projection_points": (i32, [vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp,
                                                        C.POINTER(i32), vp]),
+            "orbm_search_fuse": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp, C.POINTER(i32)]),
             "orbm_distinctive_descriptors": (i32, [vp, vp, vp, i32, vp]),
             "orbm_distinctive_descriptors_device": (i32, [vp, vp, vp, i32, vp, vp]),
             "orbm_three_maxima": (None, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
@@ -256,3 +257,21 @@ class ORBMatcher:
                                                             _vp(qk), len(qd), _vp(k2), _vp(d2), len(k2), img_w, img_h,
                                                             _vp(mp), C.byref(n), _vp(cnt)))
         return n.value, mp, tuple(cnt.tolist())
+
+    # -- static SearchByProjection(keyFrame, mapPoints, Map*, th): the fuse (ORBMatcher.cpp:524-592) ------------
+    def SearchFuse(self, q_desc, q_xy, q_radius, q_level, q_ok, kps, desc, img_w, img_h, sigma2):
+        """Per-point core of the fuse: (best_idx, best_dist, n_found); the observation rewiring stays with the caller."""
+        qd = np.ascontiguousarray(q_desc, dtype=np.uint8)
+        qx = np.ascontiguousarray(q_xy, dtype=np.float32)
+        qr = np.ascontiguousarray(q_radius, dtype=np.float32)
+        ql = np.ascontiguousarray(q_level, dtype=np.int32)
+        qk = np.ascontiguousarray(q_ok, dtype=np.uint8)
+        k = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+        d = np.ascontiguousarray(desc, dtype=np.uint8)
+        s2 = np.ascontiguousarray(sigma2, dtype=np.float32)
+        bi = np.full(len(qd), -1, np.int32)
+        bd = np.zeros(len(qd), np.int32)
+        n = C.c_int()
+        _lib.check(self._L.orbm_search_fuse(self._hd._h, _vp(qd), _vp(qx), _vp(qr), _vp(ql), _vp(qk), len(qd), _vp(k),
+                                            _vp(d), len(k), img_w, img_h, _vp(s2), len(s2), _vp(bi), _vp(bd), C.byref(n)))
+        return bi, bd, n.value

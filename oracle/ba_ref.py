@@ -186,7 +186,12 @@ def local_bundle_adjustment(cam, pose_R, pose_t, pose_fixed, points, edge_pose, 
     active = a["chi2"] <= 5.991
     b = lm_optimize(cam, a["pose_R"], a["pose_t"], pose_fixed, a["points"], edge_pose, edge_point, edge_z, edge_inv_sigma2,
                     0.0, 10, edge_active=active)
-    b["outlier"] = b["chi2"] > 5.991
+    # A level-1 edge is outside optimize(10)'s active set, so g2o does not recompute its error: e->chi2() at :919 still
+    # returns the first round's value (> 5.991) and the observation is erased even if its residual at the final estimate
+    # would pass (contrast Optimize.cpp:510, where poseOptimize calls computeError() explicitly before chi2()).
+    b["chi2_final_estimate"] = b["chi2"].copy()
+    b["chi2"] = np.where(active, b["chi2"], a["chi2"])
+    b["outlier"] = ~active | (b["chi2"] > 5.991)
     b["first_round"] = a
     return b
 

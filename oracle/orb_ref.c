@@ -1279,3 +1279,71 @@ int orbref_search_by_projection_points(float nn_ratio, const uint8_t *q_desc, co
     free(cand); orbref_grid_free(g);
     return numMatch;
 }
+
+/* ---- KeyFrame::getFeaturesInArea: modules/BasicObject/KeyFrame.cpp:181-211.  Same walk as Frame's, but the window test
+ * is STRICT (`abs(kp.pt.x - x) < r`, :204) where Frame.cpp:120 uses `<=`. ---- */
+int orbref_keyframe_features_in_area(const orbref_grid *g, const orbref_kp *kps, float x, float y, float r,
+                                     int min_level, int max_level, int32_t *out, int cap)
+{
+    int minCellX = orbref_floor_f(x - r) / GRID_SIZE; if (minCellX < 0) minCellX = 0;
+    int maxCellX = orbref_floor_f(x + r) / GRID_SIZE; if (maxCellX > g->cols - 1) maxCellX = g->cols - 1;
+    if (minCellX > maxCellX) return 0;
+    int minCellY = orbref_floor_f(y - r) / GRID_SIZE; if (minCellY < 0) minCellY = 0;
+    int maxCellY = orbref_floor_f(y + r) / GRID_SIZE; if (maxCellY > g->rows - 1) maxCellY = g->rows - 1;
+    if (minCellY > maxCellY) return 0;
+    const int check = min_level > 0 || max_level >= 0;
+    int n = 0;
+    for (int cx = minCellX; cx <= maxCellX; ++cx)
+        for (int cy = minCellY; cy <= maxCellY; ++cy) {
+            int c = cx * g->rows + cy;
+            for (int k = g->cell_start[c]; k < g->cell_start[c + 1]; ++k) {
+                int idx = g->cell_items[k];
+                const orbref_kp *kp = &kps[idx];
+                if (check) {
+                    if (kp->octave < min_level) continue;
+                    if (max_level >= 0 && kp->octave > max_level) continue;
+                }
+                if (fabsf(kp->x - x) < r && fabsf(kp->y - y) < r) { if (n < cap) out[n] = idx; ++n; }
+            }
+        }
+    return n;
+}
+
+/* ---- static SearchByProjection(keyFrame, mapPoints, Map*, th) ("fuse"): modules/ORB/ORBMatcher.cpp:524-592.
+ * Restated here is everything of the loop body that does not touch MapPoint / KeyFrame state: for the map point i
+ * whose projection passed :535-552 (q_ok), the window (:554-556: radius th * scale(predictLevel), levels
+ * predictLevel-1 .. predictLevel, KeyFrame grid), the chi-square gate on the re-projection error (:566-567, a float
+ * against the double product 5.991 * sigma2) and the closest descriptor below TH_LOW + 1 (:560, :569-574, first one
+ * on ties).  best_idx[i] = -1 where the reference would `continue` (:558) or keep bestIdx1 == -1 (:577).
+ * The observation rewiring of :578-589 stays with the caller; it never changes what a later point's window or
+ * descriptor are (a point whose descriptor is recomputed by replace(), MapPoint.cpp:261, is from then on observed by
+ * the key frame or bad, and is skipped at :534). ---- */
+int orbref_search_fuse(const uint8_t *q_desc, const float *q_xy, const float *q_radius, const int32_t *q_level,
+                       const uint8_t *q_ok, int nq, const orbref_kp *kps, const uint8_t *desc, int n, int img_w,
+                       int img_h, const float *sigma2, int32_t *best_idx, int32_t *best_dist)
+{
+    int found = 0;
+    orbref_grid *g = orbref_grid_build(kps, n, img_w, img_h);
+    int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    for (int i = 0; i < nq; ++i) {
+        best_idx[i] = -1; best_dist[i] = TH_LOW + 1;
+        if (!q_ok[i]) continue;
+        const int predictLevel = q_level[i];
+        const float px = q_xy[2 * i], py = q_xy[2 * i + 1];
+        int nc = orbref_keyframe_features_in_area(g, kps, px, py, q_radius[i], predictLevel - 1, predictLevel, cand, n);
+        if (nc == 0) continue;
+        int bestDist = TH_LOW + 1, bestIdx1 = -1;
+        for (int k = 0; k < nc; ++k) {
+            const int idx1 = cand[k];
+            const orbref_kp *kp = &kps[idx1];
+            const float squareError2 = (px - kp->x) * (px - kp->x) + (py - kp->y) * (py - kp->y);
+            if ((double)squareError2 > 5.991 * (double)sigma2[kp->octave]) continue;
+            const int dist = orbref_hamming(desc + 32 * (size_t)idx1, q_desc + 32 * (size_t)i);
+            if (dist < bestDist) { bestDist = dist; bestIdx1 = idx1; }
+        }
+        best_idx[i] = bestIdx1; best_dist[i] = bestDist;
+        if (bestIdx1 != -1) found++;
+    }
+    free(cand); orbref_grid_free(g);
+    return found;
+}

@@ -209,6 +209,16 @@ int orbref_search_by_projection_points(float nn_ratio, const uint8_t *q_desc, co
                                        const uint8_t *desc2, int n2, int img_w, int img_h, int32_t *frame_mp,
                                        int32_t *counters);
 
+/* KeyFrame::getFeaturesInArea (modules/BasicObject/KeyFrame.cpp:181-211): strict window test */
+int orbref_keyframe_features_in_area(const orbref_grid *g, const orbref_kp *kps, float x, float y, float r,
+                                     int min_level, int max_level, int32_t *out, int cap);
+/* static SearchByProjection(keyFrame, mapPoints, Map*, th) (modules/ORB/ORBMatcher.cpp:524-592), the part that reads no
+ * MapPoint / KeyFrame state: per map point the closest key point of the window; see include/orbm.h orbm_search_fuse.
+ * Returns the number of points with a candidate. */
+int orbref_search_fuse(const uint8_t *q_desc, const float *q_xy, const float *q_radius, const int32_t *q_level,
+                       const uint8_t *q_ok, int nq, const orbref_kp *kps, const uint8_t *desc, int n, int img_w,
+                       int img_h, const float *sigma2, int32_t *best_idx, int32_t *best_dist);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,8 @@ def lib():
         L.orbref_search_by_projection_points.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                          C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                          C.c_int, C.c_void_p, C.c_void_p]
+        L.orbref_search_fuse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -343,6 +345,23 @@ def search_by_projection_points(nn_ratio, q_desc, q_xy, q_radius, q_level, q_ok,
     n = lib().orbref_search_by_projection_points(nn_ratio, _p(qd), _p(qx), _p(qr), _p(ql), _p(qk), len(qd), _p(k2),
                                                  _p(d2), len(k2), img_w, img_h, _p(mp), _p(cnt))
     return n, mp, tuple(cnt.tolist())
+
+
+def search_fuse(q_desc, q_xy, q_radius, q_level, q_ok, kps, desc, img_w, img_h, sigma2):
+    """Per-point core of the static fuse SearchByProjection (ORBMatcher.cpp:524-592): (best_idx, best_dist, n_found)."""
+    qd = np.ascontiguousarray(q_desc, dtype=np.uint8)
+    qx = np.ascontiguousarray(q_xy, dtype=np.float32)
+    qr = np.ascontiguousarray(q_radius, dtype=np.float32)
+    ql = np.ascontiguousarray(q_level, dtype=np.int32)
+    qk = np.ascontiguousarray(q_ok, dtype=np.uint8)
+    k = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+    d = np.ascontiguousarray(desc, dtype=np.uint8)
+    s2 = np.ascontiguousarray(sigma2, dtype=np.float32)
+    bi = np.full(len(qd), -1, np.int32)
+    bd = np.zeros(len(qd), np.int32)
+    n = lib().orbref_search_fuse(_p(qd), _p(qx), _p(qr), _p(ql), _p(qk), len(qd), _p(k), _p(d), len(k), img_w, img_h,
+                                 _p(s2), _p(bi), _p(bd))
+    return bi, bd, n
 
 
 def parse_vocabulary_text(path):

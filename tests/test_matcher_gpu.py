@@ -264,3 +264,128 @@ def test_distinctive_descriptors(oracle_mod):
     assert list(got) == want
     with pytest.raises(Exception):
         ORBMatcher.ComputeDistinctiveDescriptors(np.zeros((1025, 32), np.uint8), np.array([0, 1025], np.int32))
+
+
+def test_best2_device_many_problems(oracle_mod):
+    """orbm_best2_device the way bench.py drives it: several (A, B) problems in one launch, per-problem counts below
+    the strides, device pointers.  Every row equals the oracle's sequential strict-'<' scan (ORBMatcher.cpp:148-162);
+    includes a query whose only candidates are at distance 256, empty problems and masked rows / candidates."""
+    import torch
+    from monoorbslam3_amd import _lib
+    from monoorbslam3_amd.matcher import MatcherHandle, _mlib
+    rng = np.random.RandomState(2026)
+    n_pairs, a_stride, b_stride = 5, 2051, 2100
+    na = np.array([2000, 1, 0, 777, 2051], np.int32)
+    nb = np.array([1999, 300, 500, 0, 2100], np.int32)
+    A = rng.randint(0, 256, (n_pairs, a_stride, 32)).astype(np.uint8)
+    B = rng.randint(0, 256, (n_pairs, b_stride, 32)).astype(np.uint8)
+    for p in range(n_pairs):  # correlated pairs so that best and second differ a lot, plus exact duplicates (ties)
+        m = min(na[p], nb[p])
+        if m:
+            flips = np.packbits(rng.uniform(size=(m, 256)) < 0.08, axis=1, bitorder="little")
+            B[p, :m] = (A[p, :m] ^ flips)[rng.permutation(m)]
+        if nb[p] > 20:
+            B[p, 17] = B[p, 5]
+    B[1, :300] = A[1, 0] ^ 255          # problem 1: every candidate at distance 256 from the only query
+    row_ok = np.ones((n_pairs, a_stride), np.uint8)
+    col_ok = np.ones((n_pairs, b_stride), np.uint8)
+    row_ok[0, ::7] = 0
+    col_ok[0, ::5] = 0
+    col_ok[4, 100:1500] = 0
+    dev = torch.device("cuda", 0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    dA, dB, dna, dnb, drow, dcol = t(A), t(B), t(na), t(nb), t(row_ok), t(col_ok)
+    mh = MatcherHandle(device=0)
+    L = _mlib()
+    for masks in (False, True):
+        d_bi = torch.full((n_pairs, a_stride), -7, dtype=torch.int32, device=dev)
+        d_bd = torch.full((n_pairs, a_stride), -7, dtype=torch.int16, device=dev)
+        d_sd = torch.full((n_pairs, a_stride), -7, dtype=torch.int16, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.orbm_best2_device(mh._h, n_pairs, dA.data_ptr(), a_stride, dna.data_ptr(), a_stride, dB.data_ptr(),
+                                       b_stride, dnb.data_ptr(), b_stride, drow.data_ptr() if masks else None,
+                                       dcol.data_ptr() if masks else None, d_bi.data_ptr(), d_bd.data_ptr(),
+                                       d_sd.data_ptr(), st))
+        torch.cuda.synchronize()
+        bi, bd, sd = d_bi.cpu().numpy(), d_bd.cpu().numpy().view(np.uint16), d_sd.cpu().numpy().view(np.uint16)
+        for p in range(n_pairs):
+            cand = np.arange(nb[p]) if not masks else np.nonzero(col_ok[p, :nb[p]])[0]
+            r_bi, r_bd, r_sd = oracle_mod.best2(A[p, :na[p]], B[p][cand])
+            r_bi = np.where(r_bi >= 0, cand[np.maximum(r_bi, 0)] if len(cand) else -1, -1)
+            if masks:
+                dead = row_ok[p, :na[p]] == 0
+                r_bi[dead], r_bd[dead], r_sd[dead] = -1, 256, 256
+            assert np.array_equal(bi[p, :na[p]], r_bi), (masks, p)
+            assert np.array_equal(bd[p, :na[p]], r_bd), (masks, p)
+            assert np.array_equal(sd[p, :na[p]], r_sd), (masks, p)
+            # rows between the count and the stride are written as "no candidate", never left stale
+            assert (bi[p, na[p]:] == -1).all() and (bd[p, na[p]:] == 256).all() and (sd[p, na[p]:] == 256).all()
+    assert bi[1, 0] == -1 and bd[1, 0] == 256  # a 256-distance candidate never beats the initial 256
+
+
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_bow_dense_2000x2000(oracle_mod, check_ori):
+    """BASELINE config 3: one vocabulary node holding all 2000 x 2000 descriptors (the dense Hamming brute force)."""
+    from monoorbslam3_amd.matcher import ORBMatcher
+    a, b, _ = synth.make_descriptor_pair(2000, seed=31)
+    rng = np.random.RandomState(8)
+    ang1 = rng.uniform(0, 360, len(a)).astype(np.float32)
+    ang2 = (ang1[rng.permutation(len(a))] + rng.normal(0, 20, len(a))).astype(np.float32) % 360
+    ok = (rng.uniform(size=len(a)) > 0.1).astype(np.uint8)
+    mp0 = np.where(rng.uniform(size=len(b)) > 0.95, 9, -1).astype(np.int32)
+    fv1 = synth.feature_vector_by_prefix(a, 0)
+    fv2 = synth.feature_vector_by_prefix(b, 0)
+    assert len(fv1[0]) == 1 and fv1[1][-1] == 2000
+    m = ORBMatcher(0.7, check_ori)
+    n_got, mp_got = m.SearchByBow(a, ang1, ok, fv1, b, ang2, mp0, fv2)
+    n_ref, mp_ref = oracle_mod.search_by_bow(0.7, check_ori, a, ang1, ok, fv1, b, ang2, mp0, fv2)
+    assert n_got == n_ref and np.array_equal(mp_got, mp_ref)
+    assert n_got > (100 if check_ori else 1000)
+
+
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_for_triangulation_dense_2000x2000(oracle_mod, check_ori):
+    from monoorbslam3_amd.matcher import ORBMatcher
+    a, b, _ = synth.make_descriptor_pair(2000, seed=32)
+    rng = np.random.RandomState(9)
+    ang1 = rng.uniform(0, 360, len(a)).astype(np.float32)
+    ang2 = rng.uniform(0, 360, len(b)).astype(np.float32)
+    h1 = (rng.uniform(size=len(a)) > 0.8).astype(np.uint8)
+    h2 = (rng.uniform(size=len(b)) > 0.8).astype(np.uint8)
+    fv1 = synth.feature_vector_by_prefix(a, 0)
+    fv2 = synth.feature_vector_by_prefix(b, 0)
+    m = ORBMatcher(0.6, check_ori)
+    n_got, m_got = m.SearchForTriangulation(a, ang1, h1, fv1, b, ang2, h2, fv2)
+    n_ref, m_ref = oracle_mod.search_for_triangulation(check_ori, a, ang1, h1, fv1, b, ang2, h2, fv2)
+    assert n_got == n_ref and np.array_equal(m_got, m_ref)
+    assert n_got > (50 if check_ori else 500)
+
+
+def test_search_fuse(oracle_mod):
+    """Per-point core of the static fuse SearchByProjection(keyFrame, mapPoints, Map*, th) (ORBMatcher.cpp:524-592):
+    KeyFrame window with the strict test, chi-square gate, closest descriptor at distance <= TH_LOW."""
+    from monoorbslam3_amd.matcher import ORBMatcher
+    w, h, k1, d1, k2, d2 = _two_views()
+    rng = np.random.RandomState(15)
+    n1 = len(k1)
+    sigma2 = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32) ** 2
+    # map points = the key frame's own features seen again: jittered projection, a few descriptor bits flipped
+    q_xy = np.stack([k1["x"] + rng.normal(0, 1.2, n1) * (1.2 ** k1["octave"]),
+                     k1["y"] + rng.normal(0, 1.2, n1) * (1.2 ** k1["octave"])], axis=1).astype(np.float32)
+    flips = np.packbits(rng.uniform(size=(n1, 256)) < 0.06, axis=1, bitorder="little")
+    q_desc = d1 ^ flips
+    q_level = np.clip(k1["octave"] + rng.randint(0, 2, n1), 0, 7).astype(np.int32)
+    q_radius = (3.0 * (np.float32(1.2) ** q_level)).astype(np.float32)
+    q_ok = (rng.uniform(size=n1) > 0.15).astype(np.uint8)
+    # exact-boundary cases for the strict window test: a projection exactly `radius` away from its key point
+    q_xy[0] = (k1["x"][0] + q_radius[0], k1["y"][0])
+    q_xy[1] = (k1["x"][1] + np.float32(0.5) * q_radius[1], k1["y"][1])
+    q_ok[:2] = 1
+    m = ORBMatcher()
+    bi, bd, n = m.SearchFuse(q_desc, q_xy, q_radius, q_level, q_ok, k1, d1, w, h, sigma2)
+    r_bi, r_bd, r_n = oracle_mod.search_fuse(q_desc, q_xy, q_radius, q_level, q_ok, k1, d1, w, h, sigma2)
+    assert n == r_n and np.array_equal(bi, r_bi) and np.array_equal(bd, r_bd)
+    assert n > 500 and (bi[q_ok == 0] == -1).all() and (bd[bi >= 0] <= 50).all() and (bd[bi < 0] == 51).all()
+    # without candidates / without key points
+    e_bi, e_bd, e_n = m.SearchFuse(q_desc[:3], q_xy[:3], q_radius[:3], q_level[:3], np.zeros(3, np.uint8), k1, d1, w, h, sigma2)
+    assert e_n == 0 and (e_bi == -1).all()
