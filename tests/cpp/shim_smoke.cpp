@@ -3,8 +3,10 @@
 // (counts, keypoints, descriptors, matches) that tests/test_shim_gpu.py compares with the ctypes path.
 #define ORBX_SHIM_USE_CV_MIRROR
 #define ORBX_SHIM_USE_REF_MIRROR
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "ORBExtractor.h"
 #include "ORBMatcher.h"
@@ -62,6 +64,59 @@ int main(int argc, char **argv) {
     ORBMatcher m06(0.6f, false);
     const int n_tri = m06.SearchForTriangulation(kf, kf2, m_tri);
 
+    // ---- the static fuse (LocalMapping.cpp:282,301) on mirror MapPoints: map points = the key frame's own features seen
+    // again (projection exactly representable, so the Python side reproduces it bit for bit), some slots already
+    // taken, some points null / bad / listed twice
+    auto elsewhere = [] { // another key frame that observes a point in its slot 0
+        auto k = std::make_shared<KeyFrame>();
+        k->map_points.assign(1, nullptr);
+        return k;
+    };
+    Camera *cam = Camera::instance();
+    cam->width = W, cam->height = H, cam->fx = 512.f, cam->fy = 512.f, cam->cx = 376.f, cam->cy = 240.f;
+    auto kf3 = std::make_shared<KeyFrame>();
+    fill(*kf3, initial, ia, 6);
+    const int n3 = kf3->num_kps;
+    std::vector<std::shared_ptr<MapPoint>> fusePoints;
+    for (int i = 0; i < n3; ++i) {
+        if (i % 11 == 3) { fusePoints.push_back(nullptr); continue; }
+        auto mp = std::make_shared<MapPoint>();
+        const cv::KeyPoint &kp = kf3->key_points[i];
+        const float u = std::floor(kp.pt.x * 8.f) / 8.f + float((i * 37) % 17 - 8) / 8.f;
+        const float v = std::floor(kp.pt.y * 8.f) / 8.f + float((i * 53) % 13 - 6) / 8.f;
+        mp->pos = Eigen::Vector3f((u - cam->cx) / 128.f, (v - cam->cy) / 128.f, 4.f); // projects to exactly (u, v)
+        mp->normal = mp->pos;                                                          // OP . Pn = |OP|^2 >= 0.5 |OP|
+        mp->predict_level = std::min(kp.octave + (i % 5 == 0 ? 1 : 0), 7);
+        mp->descriptor.create(1, 32, CV_8U);
+        std::memcpy(mp->descriptor.ptr(), kf3->descriptors.ptr(i), 32);
+        mp->descriptor.ptr()[i % 32] ^= (unsigned char) (1u << (i % 8));
+        mp->descriptor.ptr()[(i * 7) % 32] ^= (unsigned char) (1u << ((i / 3) % 8));
+        mp->bad = i % 29 == 7;
+        for (int o = 0; o < i % 4; ++o) mp->addObservation(elsewhere(), 0); // numObs 0..3
+        fusePoints.push_back(mp);
+        if (i % 17 == 5) fusePoints.push_back(mp); // listed twice: the second visit finds it observed (:534)
+    }
+    std::vector<std::shared_ptr<MapPoint>> foreign; // map points the key frame holds before the fuse
+    for (int i = 0; i < n3; ++i) {
+        if (i % 6 != 1) continue;
+        auto mp = std::make_shared<MapPoint>();
+        mp->bad = i % 5 == 0;
+        for (int o = 0; o < (i / 6) % 4; ++o) mp->addObservation(elsewhere(), 0);
+        mp->addObservation(kf3, (size_t) i);
+        kf3->map_points[i] = mp;
+        foreign.push_back(mp);
+    }
+    Map point_map;
+    const int n_fuse = ORBMatcher::SearchByProjection(kf3, fusePoints, &point_map);
+    std::vector<int> fuse_slot((size_t) n3, -1), fuse_bad(fusePoints.size(), 0);
+    for (int i = 0; i < n3; ++i) {
+        if (!kf3->map_points[i]) continue;
+        fuse_slot[i] = -2; // a foreign point
+        for (size_t k = 0; k < fusePoints.size(); ++k)
+            if (fusePoints[k] == kf3->map_points[i]) { fuse_slot[i] = (int) k; break; }
+    }
+    for (size_t k = 0; k < fusePoints.size(); ++k) fuse_bad[k] = fusePoints[k] ? (int) fusePoints[k]->bad : -1;
+
     FILE *out = std::fopen(argv[2], "wb");
     int hdr[6] = {kf->num_kps, fr->num_kps, n_ini, n_bow, n_tri, ORBExtractor::getNumLevels()};
     std::fwrite(hdr, sizeof(int), 6, out);
@@ -72,6 +127,10 @@ int main(int argc, char **argv) {
     std::fwrite(m_ini.data(), sizeof(int), m_ini.size(), out);
     std::fwrite(bow_assign.data(), sizeof(int), bow_assign.size(), out);
     std::fwrite(m_tri.data(), sizeof(int), m_tri.size(), out);
+    int fhdr[3] = {n_fuse, n3, (int) fusePoints.size()};
+    std::fwrite(fhdr, sizeof(int), 3, out);
+    std::fwrite(fuse_slot.data(), sizeof(int), fuse_slot.size(), out);
+    std::fwrite(fuse_bad.data(), sizeof(int), fuse_bad.size(), out);
     std::fclose(out);
     std::printf("shim smoke: %d + %d keypoints, init %d, bow %d, tri %d, dist(0,0)=%d\n", kf->num_kps, fr->num_kps, n_ini,
                 n_bow, n_tri, ORBMatcher::DescriptorDistance(kf->descriptors.row(0), fr->descriptors.row(0)));

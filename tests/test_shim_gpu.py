@@ -41,7 +41,10 @@ def test_cpp_shim_end_to_end(oracle_mod, tmp_path):
     d2 = np.frombuffer(buf, np.uint8, 32 * n2, o).reshape(n2, 32); o += 32 * n2
     m_ini = np.frombuffer(buf, np.int32, n1, o); o += 4 * n1
     bow = np.frombuffer(buf, np.int32, n2, o); o += 4 * n2
-    m_tri = np.frombuffer(buf, np.int32, n1, o)
+    m_tri = np.frombuffer(buf, np.int32, n1, o); o += 4 * n1
+    n_fuse, n3, n_fp = np.frombuffer(buf, np.int32, 3, o); o += 12
+    fuse_slot = np.frombuffer(buf, np.int32, n3, o); o += 4 * n3
+    fuse_bad = np.frombuffer(buf, np.int32, n_fp, o)
     assert levels == 8
     # extraction: the 2N "initial" extractor of a 1000-feature one == oracle with re-quota
     orc = oracle_mod.Oracle(1000, 1.2, 8, 20, 7)
@@ -64,6 +67,81 @@ def test_cpp_shim_end_to_end(oracle_mod, tmp_path):
     r_n, r_m = oracle_mod.search_for_triangulation(False, d1, k1["angle"], ok1, fv1, d2, k2["angle"], np.zeros(n2, np.uint8), fv2)
     assert n_tri == r_n and np.array_equal(m_tri, r_m)
     assert ORBMatcher.DescriptorDistance(d1[0], d2[0]) == int(np.unpackbits(d1[0] ^ d2[0]).sum())
+    # ---- the static fuse (ORBMatcher.cpp:524-592): the C++ shim on mirror MapPoints against a Python replay of the same
+    # scene over the oracle's per-point search (the scene construction mirrors tests/cpp/shim_smoke.cpp)
+    f32 = np.float32
+    assert n3 == n1
+    uid = iter(range(1, 1 << 30))
+    pts = []          # per listed point: None, or dict(i = feature, bad, obs = {key frame id: slot}); "K" = the key frame
+    for i in range(n1):
+        if i % 11 == 3:
+            pts.append(None)
+            continue
+        mp = dict(i=i, bad=(i % 29 == 7), obs={next(uid): 0 for _ in range(i % 4)})
+        pts.append(mp)
+        if i % 17 == 5:
+            pts.append(mp)
+    assert len(pts) == n_fp
+    slots = {}        # key-frame slot -> the point object it holds
+    for i in range(n1):
+        if i % 6 == 1:
+            mp = dict(i=-1, bad=(i % 5 == 0), obs={next(uid): 0 for _ in range((i // 6) % 4)}, foreign=True)
+            mp["obs"]["K"] = i
+            slots[i] = mp
+    nq = len(pts)
+    q_desc = np.zeros((nq, 32), np.uint8); q_xy = np.zeros((nq, 2), f32); q_radius = np.zeros(nq, f32)
+    q_level = np.zeros(nq, np.int32); q_ok = np.zeros(nq, np.uint8)
+    sf = np.ones(8, f32)
+    for l in range(1, 8):
+        sf[l] = sf[l - 1] * f32(1.2)
+    for k, mp in enumerate(pts):
+        if mp is None:
+            continue
+        i = mp["i"]
+        u = np.floor(k1["x"][i] * f32(8)) / f32(8) + f32((i * 37) % 17 - 8) / f32(8)
+        v = np.floor(k1["y"][i] * f32(8)) / f32(8) + f32((i * 53) % 13 - 6) / f32(8)
+        if not (0 <= u < w and 0 <= v < h):
+            continue
+        lvl = min(int(k1["octave"][i]) + (1 if i % 5 == 0 else 0), 7)
+        d = d1[i].copy()
+        d[i % 32] ^= 1 << (i % 8)
+        d[(i * 7) % 32] ^= 1 << ((i // 3) % 8)
+        q_desc[k], q_xy[k], q_level[k], q_radius[k], q_ok[k] = d, (u, v), lvl, f32(3) * sf[lvl], 1
+    r_bi, r_bd, _ = oracle_mod.search_fuse(q_desc, q_xy, q_radius, q_level, q_ok, k1, d1, w, h, sf * sf)
+
+    def replace(loser, winner):           # MapPoint::replace (MapPoint.cpp:233-264): observations move to the winner
+        obs, loser["obs"], loser["bad"] = loser["obs"], {}, True
+        for kf, idx in obs.items():
+            if kf not in winner["obs"]:
+                winner["obs"][kf] = idx
+                if kf == "K":
+                    slots[idx] = winner
+            elif kf == "K":
+                del slots[idx]
+
+    num = 0
+    for k, mp in enumerate(pts):
+        if mp is None or mp["bad"] or "K" in mp["obs"]:      # :534, live
+            continue
+        if not q_ok[k] or r_bi[k] < 0:
+            continue
+        b = int(r_bi[k])
+        mp1 = slots.get(b)
+        if mp1 is None:
+            mp["obs"]["K"] = b
+            slots[b] = mp
+        elif not mp1["bad"]:
+            if len(mp1["obs"]) > len(mp["obs"]):
+                replace(mp, mp1)
+            else:
+                replace(mp1, mp)
+        num += 1
+    want_slot = np.full(n1, -1, np.int32)
+    for s_, holder in slots.items():
+        want_slot[s_] = -2 if holder.get("foreign") else next(k for k, q in enumerate(pts) if q is holder)
+    want_bad = np.array([-1 if q is None else int(q["bad"]) for q in pts], np.int32)
+    assert n_fuse == num and n_fuse > 300
+    assert np.array_equal(fuse_slot, want_slot) and np.array_equal(fuse_bad, want_bad)
 
 
 def test_cpp_frame_records_end_to_end(oracle_mod, tmp_path):
