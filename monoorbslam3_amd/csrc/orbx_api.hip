@@ -48,6 +48,8 @@ struct orbx_ctx {
     OrbxTap *d_xtap[ORBX_MAX_LEVELS], *d_ytap[ORBX_MAX_LEVELS];
     int *d_umax, *d_taps;
     uint16_t *d_fast_cells; int n_fast_cells;
+    uint16_t *d_fast_strips; int n_fast_strips, n_fast_strips0; // strips of all levels / of level 0
+    int fast_variant;                                           // 2 = strips (default), 1 = one wave per cell
     uint16_t *d_blur_tiles; int n_blur_tiles;
     uint8_t *d_l0_stage; size_t l0_stage_fs;
     orbx_kp *d_out_kp; uint8_t *d_out_desc; int32_t *d_out_n; int out_cap;
@@ -301,6 +303,15 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
             c->n_fast_cells = nc;
         }
         {
+            const int ns = orbx_build_fast_strips(c->levels, 0, c->levels.n_levels, nullptr);
+            std::vector<uint16_t> st((size_t)std::max(ns, 1) * 4);
+            orbx_build_fast_strips(c->levels, 0, c->levels.n_levels, st.data());
+            HIP_TRY(dev_alloc(&c->d_fast_strips, st.size()));
+            HIP_TRY(hipMemcpy(c->d_fast_strips, st.data(), st.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            c->n_fast_strips = ns;
+            c->n_fast_strips0 = orbx_build_fast_strips(c->levels, 0, 1, nullptr);
+        }
+        {
             const int nt = orbx_build_blur_tiles(c->levels, nullptr);
             std::vector<uint16_t> tl((size_t)std::max(nt, 1) * 4);
             orbx_build_blur_tiles(c->levels, tl.data());
@@ -379,6 +390,8 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
         c->side_blur = e ? atoi(e) : 1;
         const char *f = getenv("ORBX_EARLY_FAST");
         c->early_fast = f ? atoi(f) : 1;
+        const char *fv = getenv("ORBX_FAST_VARIANT");
+        c->fast_variant = fv ? atoi(fv) : 2;
     }
     {
         const char *e = getenv("ORBX_STREAMS");
@@ -421,7 +434,7 @@ extern "C" void orbx_destroy(orbx_t *c)
     OrbxBuffers &b = c->buf;
     void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.pcode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
                     b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.kp_ang, b.sel_count, c->d_levels, c->d_umax, c->d_taps,
-                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n, c->d_fast_cells, c->d_blur_tiles};
+                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n, c->d_fast_cells, c->d_fast_strips, c->d_blur_tiles};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         if (c->d_xtap[l]) (void)hipFree(c->d_xtap[l]);
@@ -509,12 +522,20 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         else { *p = b.img_arena + LV.lv[l].raw_off; *fs = b.img_frame_stride; *pitch = LV.lv[l].pitch; }
     };
     const bool side_ok = !t && c->side_blur && slot >= 0;
-    const int n_cells0 = LV.lv[0].n_cols * LV.lv[0].n_rows; // the cell list is level-major
-    const bool early = side_ok && c->early_fast && L > 1 && n_cells0 > 0 && n_cells0 < c->n_fast_cells;
+    // FAST work units (strips of cells, or single cells for ORBX_FAST_VARIANT=1); both lists are level-major
+    const bool strips = c->fast_variant != 1;
+    const uint16_t *d_units = strips ? c->d_fast_strips : c->d_fast_cells;
+    const int n_units = strips ? c->n_fast_strips : c->n_fast_cells;
+    const int n_cells0 = strips ? c->n_fast_strips0 : LV.lv[0].n_cols * LV.lv[0].n_rows;
+    auto launch_fast = [&](hipStream_t st, const uint16_t *units, int n) {
+        if (strips) orbx_launch_fast_strips(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, units, n, n_frames);
+        else orbx_launch_fast(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, units, n, n_frames);
+    };
+    const bool early = side_ok && c->early_fast && L > 1 && n_cells0 > 0 && n_cells0 < n_units;
     if (early) {
         HIP_TRY(hipEventRecord(c->ev_start[slot], s)); // candidate counters are zero from here on
         HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_start[slot], 0));
-        orbx_launch_fast(c->side[slot], d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_cells, n_cells0, n_frames);
+        launch_fast(c->side[slot], d_units, n_cells0);
         HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
         if (c->early_fast > 1) // level 0 needs no pyramid for its blur either
             orbx_launch_blur(c->side[slot], d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps,
@@ -539,11 +560,10 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     };
     if (side && c->side_blur == 1) { int rc = fork_blur(); if (rc) return rc; } // next to FAST
     if (early) {
-        orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_cells + 4 * n_cells0,
-                         c->n_fast_cells - n_cells0, n_frames);
+        launch_fast(s, d_units + 4 * n_cells0, n_units - n_cells0);
         HIP_TRY(hipStreamWaitEvent(s, c->ev_fast0[slot], 0));
     } else {
-        orbx_launch_fast(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_fast_cells, c->n_fast_cells, n_frames);
+        launch_fast(s, d_units, n_units);
     }
     if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
     if (side && c->side_blur != 1) { int rc = fork_blur(); if (rc) return rc; } // next to the quadtree and orientation

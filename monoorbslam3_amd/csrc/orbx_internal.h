@@ -68,6 +68,10 @@ void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int sr
 void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                       const OrbxLevels &levels, const OrbxBuffers &b, const void *d_cells, int n_cells, int n_frames);
 int orbx_build_fast_cells(const OrbxLevels &levels, uint16_t *out);
+// strips of up to three cells (one wave each), level-major; levels [level_begin, level_end)
+int orbx_build_fast_strips(const OrbxLevels &levels, int level_begin, int level_end, uint16_t *out);
+void orbx_launch_fast_strips(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
+                             const OrbxLevels &levels, const OrbxBuffers &b, const void *d_strips, int n_strips, int n_frames);
 void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                       const OrbxLevels &levels, const OrbxBuffers &b, const void *d_tiles, int n_tiles, const int *taps7,
                       int n_frames, int level_begin, int level_end);

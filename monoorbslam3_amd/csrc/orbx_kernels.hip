@@ -362,6 +362,370 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// FAST, second formulation: one WAVE per STRIP of up to FS_K horizontally adjacent cells, all stages at full lanes.
+//   1. the strip's (ch + 6) x (30 K + 7) tile goes L2 -> LDS twice: raw bytes, and bytes >> 2 ("6-bit tile");
+//   2. dense compass test on the 6-bit tile, FOUR pixels per 32-bit operation (SWAR): with p6 = p >> 2 and
+//      t6 = ceil((T - 2) / 4), V - p > T implies V6 - p6 >= t6, so bit 7 of the byte (V6 + 128 - t6) - p6 is a
+//      superset flag of "darker"; no byte ever borrows (6-bit operands), so plain v_sub / v_add / v_or / v_and
+//      -- the cheap VALU class on gfx950 (tools/microbench/valu_ops2.hip) -- do the work.  Items (row, 4-pixel
+//      group) with a survivor are queued (one ballot per 256 pixels);
+//   3. queued items take the full 16-point test in the same SWAR form: 32 flags, then "9 contiguous of 16" as
+//      2 -> 4 -> 8 -> 9 AND-doubling on the even ring positions (47 logic operations per polarity for four pixels).
+//      What passes is a superset of the corners of about 1.15 x their number; those pixels are queued;
+//   4. queued pixels get the exact strength from the raw tile (17 byte gathers, min3/max3 windows), 64 at a time;
+//      corners (S >= T) go to a score map and a list;
+//   5. strict 3x3 NMS from the score map (one empty column between cells, so a neighbour in the next cell reads 0),
+//      ONE returning atomic per strip, keepers to global memory.
+// Stages 2-4 run as a rolling pipeline (a stage fires as soon as 64 entries wait), so their lanes are full whatever
+// the corner density.  A cell left without a keeper is redone at the min threshold (reference :604-607).
+// ---------------------------------------------------------------------------------------------
+#ifndef FS_K
+#define FS_K 2                       // cells per strip (at most)
+#endif
+#define FS_W (FS_K * ORBX_CELL)      // region columns of a full strip
+#define FS_G ((FS_W + 3) / 4)        // 4-pixel groups of a full strip
+#define FS_LG (FS_G <= 8 ? 8 : FS_G <= 16 ? 16 : 32) // lanes per tile row in the dense stage (a power of two >= FS_G)
+#define FS_R (64 / FS_LG)            // rows per dense iteration
+#define FS_NQ ((FS_W + 7 + 7) / 8)   // 8-byte items per tile row (<= 16)
+#define FS_TP (FS_NQ * 8 + 8)        // tile pitch: 4 + FS_W + 3 bytes, +8 so that consecutive rows start 2 banks apart
+#define FS_TROWS (36 + FS_R)         // the dense stage may look one iteration past the last cell row
+#define FS_SP ((FS_W + FS_K + 2 + 3) / 4 * 4) // score-map pitch; score column = region column + cell index + 1
+#define FS_IQ 128                    // item ring (at most 63 left over + 64 new)
+#define FS_CQ 512                    // pixel ring (at most 63 left over + 256 new)
+#define FS_LIST (128 * FS_K)         // scored corners of a pass kept for the NMS sweep; more -> dense sweep
+struct __attribute__((aligned(8))) FastStrip { // 8-byte aligned: one scalar load per strip
+    uint16_t level, cy, cx0, ncells;
+};
+// The queues are written and read by the one wave of the workgroup, and a wave's LDS instructions execute in issue
+// order: what is needed between a producer and a consumer stage is only that the compiler keeps that order.
+#define FS_WAVE_ORDER() asm volatile("" ::: "memory")
+
+// bit 7 of every byte set <=> at least 9 contiguous (cyclic) of the 16 flags x[k] have bit 7 set in that byte
+__device__ __forceinline__ uint32_t swar_arc9(const uint32_t x[16])
+{
+    uint32_t a[8], q[8], any = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) a[s] = x[2 * s] & x[2 * s + 1];           // 2 from 2s
+#pragma unroll
+    for (int s = 0; s < 8; ++s) q[s] = a[s] & a[(s + 1) & 7];             // 4 from 2s
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const uint32_t o = q[s] & q[(s + 2) & 7];                         // 8 from 2s
+        any |= o & (x[(2 * s + 8) & 15] | x[(2 * s + 15) & 15]);          // ... plus the one after or the one before
+    }
+    return any;
+}
+// bytes 0..n-1 = 0xFF (n <= 0: none, n >= 4: all)
+__device__ __forceinline__ uint32_t byte_prefix_mask(int n)
+{
+    return n <= 0 ? 0u : (n >= 4 ? 0xFFFFFFFFu : ((1u << (8 * n)) - 1u));
+}
+__device__ __forceinline__ int wave_rank(u64 mk)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+}
+
+__global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels *__restrict__ levels,
+                                                   const FastStrip *__restrict__ strips, u64 *__restrict__ cand,
+                                                   size_t cand_fs, int *__restrict__ cand_count, int n_strips,
+                                                   int n_frames)
+{
+    __shared__ __align__(16) uint8_t tile[FS_TROWS * FS_TP];
+#ifdef FS_T6_TILE // a second tile holding the bytes >> 2: fewer instructions, but the occupancy lost to its LDS costs more
+#define FS_T6(p) (*(p))
+    __shared__ __align__(16) uint8_t tile6[FS_TROWS * FS_TP];
+#else
+#define FS_T6(p) ((*(p) >> 2) & 0x3F3F3F3Fu)
+    uint8_t *const tile6 = tile;
+#endif
+    __shared__ __align__(16) uint8_t score[32 * FS_SP];
+    __shared__ uint32_t iq[FS_IQ];
+    __shared__ uint16_t cq[FS_CQ];
+    __shared__ uint32_t list[FS_LIST];
+    __shared__ int s_cellkeep[FS_K];
+
+    int frame, strip_id;
+    if (!xcd_remap(n_strips, n_frames, &frame, &strip_id)) return;
+    const FastStrip st = strips[strip_id];
+    const int lane = threadIdx.x;
+    const int level = st.level;
+    const OrbxLevel &lv = levels->lv[level];
+    const int x0 = ORBX_EDGE + st.cx0 * ORBX_CELL, y0 = ORBX_EDGE + st.cy * ORBX_CELL;
+    const int Ws = min(ORBX_CELL * (int)st.ncells, lv.w - ORBX_EDGE - x0); // region columns of this strip
+    const int ch = min(ORBX_CELL, lv.h - ORBX_EDGE - y0);
+    const int th = ch + 6;
+    const int pitch = src.pitch[level];
+    const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level] + (size_t)(y0 - 3) * pitch + (x0 - 4);
+
+    for (int i = lane; i < 32 * FS_SP / 16; i += 64) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
+    if (lane < FS_K) s_cellkeep[lane] = 0;
+    {
+        // tile column tc <-> level x = x0 - 4 + tc; region columns are tc in [4, 4 + Ws); the ring of the last region
+        // column ends at tc = Ws + 6.  Lane = (8-byte item tx, row ty mod 4); nine row groups, all requested before the
+        // first is stored (row and item clamped instead of branching: surplus lanes repeat the last row / item).  The
+        // bytes an item may hold beyond Ws + 6 are never looked at for a region pixel, and the loads stay inside the
+        // frame (the tile's last row is at most h - 17 and its last byte at most w - 8 of that row).
+        const int n_q = (Ws + 14) >> 3;
+        const int tx = min(lane & 15, n_q - 1) * 8, ty0 = lane >> 4;
+        unsigned long long v[9];
+        int dst[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int ty = min(ty0 + 4 * k, th - 1);
+            dst[k] = ty * FS_TP + tx;
+            v[k] = reinterpret_cast<const UnalignedU64b *>(S + (size_t)(ty * pitch + tx))->v;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            *reinterpret_cast<unsigned long long *>(&tile[dst[k]]) = v[k];
+#ifdef FS_T6_TILE
+            *reinterpret_cast<unsigned long long *>(&tile6[dst[k]]) = (v[k] >> 2) & 0x3F3F3F3F3F3F3F3FULL;
+#endif
+        }
+    }
+    __syncthreads();
+
+    int iq_head = 0, iq_tail = 0, cq_head = 0, cq_tail = 0, list_n = 0;
+    int thr = 0;
+    uint32_t Kd = 0; // per byte 128 - t6
+    bool both_possible = false; // t6 == 0: a pixel can pass the 6-bit arc test in both polarities
+
+    // ---- stage 4: exact strength of `n` queued pixels (n <= 64)
+    auto stage_score = [&](int n) {
+        const bool live = lane < n;
+        const int e = cq[(cq_head + min(lane, n - 1)) & (FS_CQ - 1)];
+        cq_head += n;
+        // bit 15: the arc test passed the pixel as a BRIGHT corner candidate.  A corner at T >= 0 is dark or bright, never
+        // both (two 9-arcs of a 16-ring share two pixels), and its strength is its own polarity's arc measure; with
+        // every byte complemented the bright measure is the dark one, so one window pass serves either polarity.
+        const int r = (e >> 8) & 31, tc = e & 127, F = (e & 0x8000) ? 255 : 0;
+        const uint8_t *t = &tile[r * FS_TP + tc - 3]; // ring pixel (dx, dy) at t[(dy + 3) * FS_TP + dx + 3]
+#define FS_PX(dx, dy) ((int)t[((dy) + 3) * FS_TP + (dx) + 3] ^ F)
+        int p[16];
+        p[0] = FS_PX(0, 3);    p[1] = FS_PX(1, 3);    p[2] = FS_PX(2, 2);    p[3] = FS_PX(3, 1);
+        p[4] = FS_PX(3, 0);    p[5] = FS_PX(3, -1);   p[6] = FS_PX(2, -2);   p[7] = FS_PX(1, -3);
+        p[8] = FS_PX(0, -3);   p[9] = FS_PX(-1, -3);  p[10] = FS_PX(-2, -2); p[11] = FS_PX(-3, -1);
+        p[12] = FS_PX(-3, 0);  p[13] = FS_PX(-3, 1);  p[14] = FS_PX(-2, 2);  p[15] = FS_PX(-1, 3);
+        const int v = FS_PX(0, 0);
+#undef FS_PX
+        // S + 1 = V - min_k max_{arc k} p for a dark corner, arcs of 9 as 3 x 3
+        int hi3[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) hi3[k] = max(max(p[k], p[(k + 1) & 15]), p[(k + 2) & 15]);
+        int a = 1 << 20;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a = min(a, max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]));
+        const int sc = v - a - 1;
+        const bool corner = live && sc >= thr;
+        const int c = tc - 4;
+        const int scol = c + ((c * 2185) >> 16) + 1; // c / 30 for c < 150
+        if (corner) score[(r + 1) * FS_SP + scol] = (uint8_t)sc;
+        const u64 mk = __ballot(corner);
+        const int pos = list_n + wave_rank(mk);
+        if (corner && pos < FS_LIST) list[pos] = (uint32_t)r | ((uint32_t)c << 8) | ((uint32_t)sc << 16);
+        list_n += (int)__popcll(mk); // may exceed FS_LIST: the NMS then sweeps the score map instead
+    };
+    // ---- stage 3: the full 16-point test of `n` queued items on the 6-bit tile, four pixels per operation
+    auto stage_arc = [&](int n) {
+        const uint32_t e = iq[(iq_head + min(lane, n - 1)) & (FS_IQ - 1)];
+        iq_head += n;
+        const int r = e & 31, g = (e >> 8) & 31;
+        const uint32_t mc = lane < n ? (e & 0x80808080u) : 0u; // the item's compass survivors
+        const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile6[r * FS_TP + 4 * g]); // (row r - 3, column tc - 4)
+        uint32_t cm[7], c0[7], cp[7];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) { cm[d] = FS_T6(t + d * (FS_TP / 4)); c0[d] = FS_T6(t + d * (FS_TP / 4) + 1); cp[d] = FS_T6(t + d * (FS_TP / 4) + 2); }
+        // ring pixel k of the four pixels = the row's bytes shifted by dx: right shifts take bytes from cp, left from cm
+#define FS_SHR(d, n_) __builtin_amdgcn_alignbyte(cp[d], c0[d], n_)
+#define FS_SHL(d, n_) __builtin_amdgcn_alignbyte(c0[d], cm[d], 4 - (n_))
+        uint32_t R[16];
+        R[0] = c0[6];         R[1] = FS_SHR(6, 1);  R[2] = FS_SHR(5, 2);  R[3] = FS_SHR(4, 3);
+        R[4] = FS_SHR(3, 3);  R[5] = FS_SHR(2, 3);  R[6] = FS_SHR(1, 2);  R[7] = FS_SHR(0, 1);
+        R[8] = c0[0];         R[9] = FS_SHL(0, 1);  R[10] = FS_SHL(1, 2); R[11] = FS_SHL(2, 3);
+        R[12] = FS_SHL(3, 3); R[13] = FS_SHL(4, 3); R[14] = FS_SHL(5, 2); R[15] = FS_SHL(6, 1);
+#undef FS_SHR
+#undef FS_SHL
+        const uint32_t Vd = c0[3] + Kd, Vb = Kd - c0[3];
+        uint32_t x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = Vd - R[k];   // bit 7: darker (superset)
+        const uint32_t md = swar_arc9(x) & mc; // a 9-arc holds two adjacent compass points: nothing outside mc can pass
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = Vb + R[k];   // bit 7: brighter (superset)
+        const uint32_t mb = swar_arc9(x) & mc;
+        const uint32_t m = md | mb;
+        // pixel entry: row << 8 | tile column, bit 15 = candidate of a BRIGHT corner (the exact stage then evaluates that
+        // polarity only).  With t6 >= 1 no pixel passes both; at thresholds 0..2 (t6 = 0) the dark entry is queued too.
+        const uint32_t ent = (uint32_t)(r << 8) | (uint32_t)(4 * g + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool hit = (m >> (8 * j + 7)) & 1u;
+            const u64 mk = __ballot(hit);
+            const uint32_t tag = (j == 0 ? (mb << 8) : (mb >> (8 * j - 8))) & 0x8000u;
+            if (hit) cq[(cq_tail + wave_rank(mk)) & (FS_CQ - 1)] = (uint16_t)((ent + j) | tag);
+            cq_tail += (int)__popcll(mk);
+        }
+        if (both_possible) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool hit = ((md & mb) >> (8 * j + 7)) & 1u;
+                const u64 mk = __ballot(hit);
+                if (hit) cq[(cq_tail + wave_rank(mk)) & (FS_CQ - 1)] = (uint16_t)(ent + j);
+                cq_tail += (int)__popcll(mk);
+            }
+        }
+    };
+
+    // One pass = everything up to the keepers of the region columns [col_lo, col_hi) at threshold `thr`.
+    auto run_pass = [&](int col_lo, int col_hi) {
+        const int t6 = min(max((thr + 1) >> 2, 0), 64); // ceil((thr - 2) / 4) for thr >= 0
+        Kd = 0x01010101u * (uint32_t)(128 - t6);
+        both_possible = t6 == 0;
+        const int arc_batch = both_possible ? 32 : 64; // a batch of items queues at most 256 pixel entries
+        iq_head = iq_tail = cq_head = cq_tail = 0;
+        list_n = 0;
+        // ---- stage 2: compass test.  Lane = (group of four region columns, row mod FS_R), fixed for the pass: the
+        // validity mask and every address offset are per-lane constants, a step advances FS_R rows.
+        {
+            const int g_lo = col_lo >> 2, g_hi = (col_hi + 3) >> 2;
+            const int g = min(g_lo + (lane & (FS_LG - 1)), g_hi - 1), rsub = lane / FS_LG;
+            const uint32_t vm = (g_lo + (lane & (FS_LG - 1)) < g_hi)
+                                    ? (0x80808080u & byte_prefix_mask(col_hi - 4 * g) & ~byte_prefix_mask(col_lo - 4 * g)) : 0u;
+            const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile6[rsub * FS_TP + 4 * g]); // (row r - 3, column tc - 4)
+            uint32_t ent = (uint32_t)rsub | ((uint32_t)g << 8);
+            for (int r0 = 0; r0 < ch; r0 += FS_R, t += FS_R * (FS_TP / 4), ent += FS_R) {
+                const uint32_t up = FS_T6(t + 1), cm = FS_T6(t + 3 * (FS_TP / 4)), c0 = FS_T6(t + 3 * (FS_TP / 4) + 1),
+                               cp = FS_T6(t + 3 * (FS_TP / 4) + 2), dn = FS_T6(t + 6 * (FS_TP / 4) + 1);
+                const uint32_t E = __builtin_amdgcn_alignbyte(cp, c0, 3), Wv = __builtin_amdgcn_alignbyte(c0, cm, 1);
+                const uint32_t Vd = c0 + Kd, Vb = Kd - c0;
+                // a 9-arc holds two adjacent compass points: (S or N) and (E or W), all darker or all brighter
+                uint32_t m = ((Vd - dn) | (Vd - up)) & ((Vd - E) | (Vd - Wv));
+                m |= ((Vb + dn) | (Vb + up)) & ((Vb + E) | (Vb + Wv));
+                m &= (r0 + rsub < ch) ? vm : 0u;
+                const bool surv = m != 0;
+                const u64 mk = __ballot(surv);
+                if (surv) iq[(iq_tail + wave_rank(mk)) & (FS_IQ - 1)] = m | ent;
+                iq_tail += (int)__popcll(mk);
+                FS_WAVE_ORDER();
+                while (iq_tail - iq_head >= 64) {
+                    stage_arc(arc_batch);
+                    FS_WAVE_ORDER();
+                    while (cq_tail - cq_head >= 64) { stage_score(64); FS_WAVE_ORDER(); }
+                }
+            }
+        }
+        while (iq_tail > iq_head) {
+            stage_arc(min(iq_tail - iq_head, arc_batch));
+            FS_WAVE_ORDER();
+            while (cq_tail - cq_head >= 64) { stage_score(64); FS_WAVE_ORDER(); }
+        }
+        while (cq_tail > cq_head) { stage_score(min(cq_tail - cq_head, 64)); FS_WAVE_ORDER(); }
+
+        // ---- stage 5: strict 3x3 NMS inside each cell, then the keepers leave
+        auto is_max = [&](int r, int c, int sc) -> bool {
+            const uint8_t *sp = &score[r * FS_SP + c + ((c * 2185) >> 16)]; // (row - 1, column - 1) of the 3 x 3 block
+            return sc > sp[0] && sc > sp[1] && sc > sp[2] && sc > sp[FS_SP] && sc > sp[FS_SP + 2] && sc > sp[2 * FS_SP] &&
+                   sc > sp[2 * FS_SP + 1] && sc > sp[2 * FS_SP + 2];
+        };
+        int n_keep = 0;
+        const bool listed = list_n <= FS_LIST;
+        if (listed) {
+            // keepers are compacted in place: a batch is read before it is written, at positions <= the ones just read
+            for (int i0 = 0; i0 < list_n; i0 += 64) {
+                const int i = min(i0 + lane, list_n - 1);
+                const uint32_t e = list[i];
+                const int r = e & 255, c = (e >> 8) & 255, sc = e >> 16;
+                const bool keep = i0 + lane < list_n && is_max(r, c, sc);
+                if (keep) s_cellkeep[(c * 2185) >> 16] = 1;
+                const u64 mk = __ballot(keep);
+                FS_WAVE_ORDER();
+                if (keep) list[n_keep + wave_rank(mk)] = e;
+                n_keep += (int)__popcll(mk);
+            }
+        } else {
+            // more corners than the list holds (rare): count by sweeping the score map itself
+            const int Wp = col_hi - col_lo, n_scan = ch * Wp;
+            for (int i0 = 0; i0 < n_scan; i0 += 64) {
+                const int i = min(i0 + lane, n_scan - 1), r = i / Wp, c = col_lo + i - r * Wp;
+                const int sc = score[(r + 1) * FS_SP + c + ((c * 2185) >> 16) + 1];
+                const bool keep = i0 + lane < n_scan && sc >= thr && sc > 0 && is_max(r, c, sc);
+                if (keep) s_cellkeep[(c * 2185) >> 16] = 1;
+                n_keep += (int)__popcll(__ballot(keep));
+            }
+        }
+        if (n_keep == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], n_keep);
+        base = __builtin_amdgcn_readfirstlane(base);
+        u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + base;
+        const uint32_t xb = st.cx0 * ORBX_CELL, yb = st.cy * ORBX_CELL;
+        if (listed) {
+            FS_WAVE_ORDER();
+            for (int i = lane; i < n_keep; i += 64) {
+                const uint32_t e = list[i];
+                out[i] = (u64)((xb + ((e >> 8) & 255)) | ((yb + (e & 255)) << 16)) | ((u64)(e >> 16) << 32);
+            }
+        } else {
+            const int Wp = col_hi - col_lo, n_scan = ch * Wp;
+            int w = 0;
+            for (int i0 = 0; i0 < n_scan; i0 += 64) {
+                const int i = min(i0 + lane, n_scan - 1), r = i / Wp, c = col_lo + i - r * Wp;
+                const int sc = score[(r + 1) * FS_SP + c + ((c * 2185) >> 16) + 1];
+                const bool keep = i0 + lane < n_scan && sc >= thr && sc > 0 && is_max(r, c, sc);
+                const u64 mk = __ballot(keep);
+                if (keep) out[w + wave_rank(mk)] = (u64)((xb + c) | ((yb + r) << 16)) | ((u64)(uint32_t)sc << 32);
+                w += (int)__popcll(mk);
+            }
+        }
+    };
+
+    thr = levels->ini_th;
+    run_pass(0, Ws);
+    __syncthreads();
+    // reference :604-607: a cell without a keeper at the ini threshold is redone at the min threshold
+    thr = levels->min_th;
+    for (int k = 0; k * ORBX_CELL < Ws; ++k) {
+        if (s_cellkeep[k]) continue;
+        run_pass(k * ORBX_CELL, min((k + 1) * ORBX_CELL, Ws));
+        __syncthreads();
+    }
+}
+
+int orbx_build_fast_strips(const OrbxLevels &levels, int level_begin, int level_end, uint16_t *out /* 4 per strip, or NULL */)
+{
+    int n = 0;
+    for (int l = level_begin; l < level_end && l < levels.n_levels; ++l) {
+        const OrbxLevel &v = levels.lv[l];
+        if (v.n_cols <= 0) continue;
+        // strips of a cell row: as equal as possible, none wider than FS_K cells
+        const int ns = (v.n_cols + FS_K - 1) / FS_K;
+        for (int cy = 0; cy < v.n_rows; ++cy)
+            for (int s = 0; s < ns; ++s) {
+                const int c0 = (int)((long long)v.n_cols * s / ns), c1 = (int)((long long)v.n_cols * (s + 1) / ns);
+                if (out) { out[4 * n] = (uint16_t)l; out[4 * n + 1] = (uint16_t)cy; out[4 * n + 2] = (uint16_t)c0; out[4 * n + 3] = (uint16_t)(c1 - c0); }
+                ++n;
+            }
+    }
+    return n;
+}
+
+void orbx_launch_fast_strips(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
+                             const OrbxLevels &levels, const OrbxBuffers &b, const void *d_strips, int n_strips, int n_frames)
+{
+    if (n_strips <= 0) return;
+    FastSrc src;
+    for (int l = 0; l < levels.n_levels; ++l) {
+        src.base[l] = l == 0 ? l0 : b.img_arena + levels.lv[l].raw_off;
+        src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
+        src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
+    }
+    hipLaunchKernelGGL(k_fast_strip, dim3(orbx_xcd_grid(n_strips, n_frames)), dim3(64), 0, s, src, d_levels,
+                       reinterpret_cast<const FastStrip *>(d_strips), b.cand, b.cand_frame_stride, b.cand_count, n_strips,
+                       n_frames);
+}
+
 int orbx_build_fast_cells(const OrbxLevels &levels, uint16_t *out /* 4 per cell, or NULL to count */)
 {
     int n = 0;

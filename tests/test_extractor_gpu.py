@@ -154,6 +154,23 @@ def test_other_constructor_arguments(oracle_mod, nf, sf, levels, ini, mn):
     _check_frame(ex, orc, img, kps, desc, stages=True)
 
 
+@pytest.mark.parametrize("ini,mn,kind", [(5, 2, "noise"), (2, 1, "noise"), (2, 1, "scene"), (3, 3, "noise"), (40, 1, "scene"),
+                                         (254, 200, "noise")])
+def test_fast_dense_corners_and_tiny_thresholds(oracle_mod, ini, mn, kind):
+    """The FAST kernel's rare paths: i.i.d. noise at low thresholds makes nearly every pixel a corner (more corners per
+    strip than its LDS list holds -> the NMS sweeps the score map), thresholds 0..2 make the 6-bit arc test pass pixels
+    in both polarities, thresholds near 255 pass nothing.  Candidates, key points and descriptors stay the oracle's."""
+    w, h, nf = 500, 300, 1500
+    ex, orc = _mk(oracle_mod, nf, w, h, ini=ini, mn=mn)
+    if kind == "noise":
+        img = np.random.RandomState(ini * 31 + mn).randint(0, 256, (h, w)).astype(np.uint8)
+    else:
+        img = synth.make_frames(1, w, h, seed=4242 + ini)[0]
+    kps, desc = ex(img)
+    _check_frame(ex, orc, img, kps, desc, stages=True)
+    assert (len(kps) == 0) == (ini == 254)
+
+
 def test_blur_tap_variant_and_handle_reuse(oracle_mod):
     """the plain-rounded (sum 257) Gaussian tap set, and one handle used for several frame sizes in turn"""
     from monoorbslam3_amd.extractor import ORBExtractor
