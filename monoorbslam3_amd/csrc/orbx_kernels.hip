@@ -365,8 +365,8 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
 
 // ---------------------------------------------------------------------------------------------
 // FAST, second formulation: one WAVE per STRIP of up to FS_K horizontally adjacent cells, all stages at full lanes.
-//   1. the strip's (ch + 6) x (30 K + 7) tile goes L2 -> LDS twice: raw bytes, and bytes >> 2 ("6-bit tile");
-//   2. dense compass test on the 6-bit tile, FOUR pixels per 32-bit operation (SWAR): with p6 = p >> 2 and
+//   1. the strip's (ch + 6) x (30 K + 7) tile goes L2 -> LDS;
+//   2. dense compass test on 6-bit pixels, FOUR pixels per 32-bit operation (SWAR): with p6 = p >> 2 and
 //      t6 = ceil((T - 2) / 4), V - p > T implies V6 - p6 >= t6, so bit 7 of the byte (V6 + 128 - t6) - p6 is a
 //      superset flag of "darker"; no byte ever borrows (6-bit operands), so plain v_sub / v_add / v_or / v_and
 //      -- the cheap VALU class on gfx950 (tools/microbench/valu_ops2.hip) -- do the work.  Items (row, 4-pixel
@@ -433,13 +433,6 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
                                                    int n_frames)
 {
     __shared__ __align__(16) uint8_t tile[FS_TROWS * FS_TP];
-#ifdef FS_T6_TILE // a second tile holding the bytes >> 2: fewer instructions, but the occupancy lost to its LDS costs more
-#define FS_T6(p) (*(p))
-    __shared__ __align__(16) uint8_t tile6[FS_TROWS * FS_TP];
-#else
-#define FS_T6(p) ((*(p) >> 2) & 0x3F3F3F3Fu)
-    uint8_t *const tile6 = tile;
-#endif
     __shared__ __align__(16) uint8_t score[32 * FS_SP];
     __shared__ uint32_t iq[FS_IQ];
     __shared__ uint16_t cq[FS_CQ];
@@ -480,9 +473,6 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             *reinterpret_cast<unsigned long long *>(&tile[dst[k]]) = v[k];
-#ifdef FS_T6_TILE
-            *reinterpret_cast<unsigned long long *>(&tile6[dst[k]]) = (v[k] >> 2) & 0x3F3F3F3F3F3F3F3FULL;
-#endif
         }
     }
     __syncthreads();
@@ -533,21 +523,25 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         iq_head += n;
         const int r = e & 31, g = (e >> 8) & 31;
         const uint32_t mc = lane < n ? (e & 0x80808080u) : 0u; // the item's compass survivors
-        const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile6[r * FS_TP + 4 * g]); // (row r - 3, column tc - 4)
+        const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile[r * FS_TP + 4 * g]); // (row r - 3, column tc - 4)
         uint32_t cm[7], c0[7], cp[7];
 #pragma unroll
-        for (int d = 0; d < 7; ++d) { cm[d] = FS_T6(t + d * (FS_TP / 4)); c0[d] = FS_T6(t + d * (FS_TP / 4) + 1); cp[d] = FS_T6(t + d * (FS_TP / 4) + 2); }
-        // ring pixel k of the four pixels = the row's bytes shifted by dx: right shifts take bytes from cp, left from cm
-#define FS_SHR(d, n_) __builtin_amdgcn_alignbyte(cp[d], c0[d], n_)
-#define FS_SHL(d, n_) __builtin_amdgcn_alignbyte(c0[d], cm[d], 4 - (n_))
+        for (int d = 0; d < 7; ++d) { cm[d] = t[d * (FS_TP / 4)]; c0[d] = t[d * (FS_TP / 4) + 1]; cp[d] = t[d * (FS_TP / 4) + 2]; }
+        // ring pixel k of the four pixels = the row's bytes shifted by dx (right shifts take bytes from cp, left ones from
+        // cm) and reduced to 6 bits: one v_alignbit by 8 dx + 2 bits and one mask
+#define FS_SHR(d, n_) (__builtin_amdgcn_alignbit(cp[d], c0[d], 8 * (n_) + 2) & 0x3F3F3F3Fu)
+#define FS_SHL(d, n_) (__builtin_amdgcn_alignbit(c0[d], cm[d], 8 * (4 - (n_)) + 2) & 0x3F3F3F3Fu)
+#define FS_SH0(d) ((c0[d] >> 2) & 0x3F3F3F3Fu)
         uint32_t R[16];
-        R[0] = c0[6];         R[1] = FS_SHR(6, 1);  R[2] = FS_SHR(5, 2);  R[3] = FS_SHR(4, 3);
+        R[0] = FS_SH0(6);     R[1] = FS_SHR(6, 1);  R[2] = FS_SHR(5, 2);  R[3] = FS_SHR(4, 3);
         R[4] = FS_SHR(3, 3);  R[5] = FS_SHR(2, 3);  R[6] = FS_SHR(1, 2);  R[7] = FS_SHR(0, 1);
-        R[8] = c0[0];         R[9] = FS_SHL(0, 1);  R[10] = FS_SHL(1, 2); R[11] = FS_SHL(2, 3);
+        R[8] = FS_SH0(0);     R[9] = FS_SHL(0, 1);  R[10] = FS_SHL(1, 2); R[11] = FS_SHL(2, 3);
         R[12] = FS_SHL(3, 3); R[13] = FS_SHL(4, 3); R[14] = FS_SHL(5, 2); R[15] = FS_SHL(6, 1);
+        const uint32_t V6 = FS_SH0(3);
 #undef FS_SHR
 #undef FS_SHL
-        const uint32_t Vd = c0[3] + Kd, Vb = Kd - c0[3];
+#undef FS_SH0
+        const uint32_t Vd = V6 + Kd, Vb = Kd - V6;
         uint32_t x[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = Vd - R[k];   // bit 7: darker (superset)
@@ -593,12 +587,13 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
             const int g = min(g_lo + (lane & (FS_LG - 1)), g_hi - 1), rsub = lane / FS_LG;
             const uint32_t vm = (g_lo + (lane & (FS_LG - 1)) < g_hi)
                                     ? (0x80808080u & byte_prefix_mask(col_hi - 4 * g) & ~byte_prefix_mask(col_lo - 4 * g)) : 0u;
-            const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile6[rsub * FS_TP + 4 * g]); // (row r - 3, column tc - 4)
+            const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile[rsub * FS_TP + 4 * g]); // (row r - 3, column tc - 4)
             uint32_t ent = (uint32_t)rsub | ((uint32_t)g << 8);
             for (int r0 = 0; r0 < ch; r0 += FS_R, t += FS_R * (FS_TP / 4), ent += FS_R) {
-                const uint32_t up = FS_T6(t + 1), cm = FS_T6(t + 3 * (FS_TP / 4)), c0 = FS_T6(t + 3 * (FS_TP / 4) + 1),
-                               cp = FS_T6(t + 3 * (FS_TP / 4) + 2), dn = FS_T6(t + 6 * (FS_TP / 4) + 1);
-                const uint32_t E = __builtin_amdgcn_alignbyte(cp, c0, 3), Wv = __builtin_amdgcn_alignbyte(c0, cm, 1);
+                const uint32_t M6 = 0x3F3F3F3Fu;
+                const uint32_t cm = t[3 * (FS_TP / 4)], cr = t[3 * (FS_TP / 4) + 1], cp = t[3 * (FS_TP / 4) + 2];
+                const uint32_t up = (t[1] >> 2) & M6, dn = (t[6 * (FS_TP / 4) + 1] >> 2) & M6, c0 = (cr >> 2) & M6;
+                const uint32_t E = __builtin_amdgcn_alignbit(cp, cr, 26) & M6, Wv = __builtin_amdgcn_alignbit(cr, cm, 10) & M6;
                 const uint32_t Vd = c0 + Kd, Vb = Kd - c0;
                 // a 9-arc holds two adjacent compass points: (S or N) and (E or W), all darker or all brighter
                 uint32_t m = ((Vd - dn) | (Vd - up)) & ((Vd - E) | (Vd - Wv));
