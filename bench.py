@@ -61,29 +61,51 @@ def algorithmic_bytes(ex, w, h, kp_per_frame):
 
 
 def cpu_baseline(frames, n_features, threads, match):
-    """The C oracle (restatement of the reference's CPU extractor and best/second-best loop) on the host cores: the
-    same work as one GPU step -- extract every frame, then match it against its predecessor."""
+    """the C oracle (restatement of the reference's CPU extractor and best/second-best loop) on the
+    host cores, doing the same work as a GPU step per frame -- extract, then match against the predecessor.
+    (i) one thread, 20 warm-up + 200 timed frames, per-frame median / p10 / p90; (ii) all `threads` threads, one frame
+    stream per thread.  Built -O3 -march=native on this box when gcc is present (oracle/Makefile `native`), else the
+    portable -O2 build."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import orb_ref_py
+    build = orb_ref_py.build_native() if hasattr(orb_ref_py, "build_native") else "-O2"
     orb_ref_py.build()
-    orc = [orb_ref_py.Oracle(n_features, 1.2, 8, 20, 7) for _ in range(threads)]
-    orc[0].extract(frames[0])  # warm-up
 
-    def work(t):
-        n, prev = 0, None
-        for i in range(t, len(frames), threads):
-            _, desc, _ = orc[t].extract(frames[i])
+    def run(orc, idx, warm):
+        lat, prev = [], None
+        for k, i in enumerate(idx):
+            t0 = time.perf_counter()
+            _, desc, _ = orc.extract(frames[i % len(frames)])
             if match and prev is not None:
                 orb_ref_py.best2(prev, desc)
             prev = desc
-            n += 1
-        return n
+            if k >= warm:
+                lat.append(time.perf_counter() - t0)
+        return lat
 
+    def pct(lat):
+        a = np.sort(np.asarray(lat)) * 1e3
+        return {"ms_median": round(float(np.median(a)), 2), "ms_p10": round(float(np.percentile(a, 10)), 2),
+                "ms_p90": round(float(np.percentile(a, 90)), 2), "frames": len(a)}
+
+    one = run(orb_ref_py.Oracle(n_features, 1.2, 8, 20, 7), range(220), 20)
+    one_stats = pct(one)
+    one_stats["frames_per_s"] = round(len(one) / sum(one), 2)
+    per = max(8, int(4.0 / max(np.median(one), 1e-3)))  # about 4 s of wall time on every thread
+    orcs = [orb_ref_py.Oracle(n_features, 1.2, 8, 20, 7) for _ in range(threads)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as pool:  # ctypes releases the GIL during the C call
-        done = sum(pool.map(work, range(threads)))
-    dt = time.perf_counter() - t0
-    return done / dt, done, dt
+        lats = list(pool.map(lambda t: run(orcs[t], range(t * per, t * per + per + 2), 2), range(threads)))
+    wall = time.perf_counter() - t0
+    allc = pct([x for lat in lats for x in lat])
+    done = sum(len(lat) for lat in lats)
+    allc["frames_per_s"] = round(done / max(sum(lat) for lat in lats), 2)  # timed frames over the slowest thread's timed span
+    return {"value": allc["frames_per_s"], "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "C oracle (restatement of the reference's CPU code, not the OpenCV-backed original), %s; per frame: "
+                      "extraction%s; one thread: 20 warm-up + %d timed frames; %d threads: %d timed frames each, %.1f s wall"
+                      % (build, " + best/second-best match against the previous frame" if match else "", len(one),
+                         threads, per, wall),
+            "one_thread": one_stats, "all_threads": allc}
 
 
 def main():
@@ -91,11 +113,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="resident frames per GPU per step (throughput saturates from ~512)")
-    ap.add_argument("--width", type=int, default=1242)
-    ap.add_argument("--height", type=int, default=375)
+    ap.add_argument("--batch", type=int, default=None, help="resident frames per GPU per step (default 512 for config 2: "
+                                                            "throughput saturates there; 1 for config 4)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4],
+                    help="BASELINE.json configuration: 2 = KITTI 1242x375 / 2000 features, a resident batch per GPU (the "
+                         "metric's configuration, default); 4 = 1920x1080 stream, ONE frame per GPU per step (8 concurrent "
+                         "frames sharded 1/GPU at --gpus 8), gathered to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-match", action="store_true", help="time extraction only")
     ap.add_argument("--records", action="store_true",
                     help="also build complete frame records per step: undistortion + grid (orbf) and bag of words on a "
@@ -104,6 +132,13 @@ def main():
                     help="collective backend; gloo + --share-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank computes on cuda:0")
     args = ap.parse_args()
+    if args.config == 4:
+        dw, dh, db = 1920, 1080, 1
+    else:
+        dw, dh, db = 1242, 375, 512
+    args.width = args.width or dw
+    args.height = args.height or dh
+    args.batch = args.batch or db
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -193,8 +228,10 @@ def main():
             _lib.check(ML.orbm_best2_device(mh._h, B - 1, d_desc[i].data_ptr(), cap, d_n[i].data_ptr(), cap,
                                             d_desc[i].data_ptr() + cap * 32, cap, d_n[i].data_ptr() + 4, cap, None, None,
                                             d_bidx[i].data_ptr(), d_bd[i].data_ptr(), d_sd[i].data_ptr(), st))
+        # the batch's last frame: against frame 0, or (one frame per step, config 4) against the previous step's frame
+        o = i if B > 1 else (i + 1) % NBUF
         _lib.check(ML.orbm_best2_device(mh._h, 1, d_desc[i].data_ptr() + (B - 1) * cap * 32, cap,
-                                        d_n[i].data_ptr() + 4 * (B - 1), cap, d_desc[i].data_ptr(), cap, d_n[i].data_ptr(),
+                                        d_n[i].data_ptr() + 4 * (B - 1), cap, d_desc[o].data_ptr(), cap, d_n[o].data_ptr(),
                                         cap, None, None, d_bidx[i].data_ptr() + 4 * (B - 1) * cap,
                                         d_bd[i].data_ptr() + 2 * (B - 1) * cap, d_sd[i].data_ptr() + 2 * (B - 1) * cap, st))
 
@@ -248,6 +285,61 @@ def main():
         dt = float(t.item())
     fps = world * B * args.steps / dt
 
+    # ---- PCIe-inclusive rate (SURVEY 8d "report both"; never `value`): the same steps, but every batch arrives from
+    # pinned host memory (H2D of level 0) and its records -- counts, 28-byte key points, 32-byte descriptors at their fixed
+    # capacity -- go back to pinned host memory (D2H).  Two input / output sets, copies on their own stream, so the
+    # transfers of batch k+1 / k-1 overlap the kernels of batch k.
+    e2e = None
+    if world == 1 and not args.no_end_to_end:
+        h_in = torch.from_numpy(np.ascontiguousarray(frames.cpu().numpy())).pin_memory()
+        d_in = [torch.empty_like(frames) for _ in range(NBUF)]
+        h_out = [(torch.empty((B,), dtype=torch.int32).pin_memory(), torch.empty((B, cap, 28), dtype=torch.uint8).pin_memory(),
+                  torch.empty((B, cap, 32), dtype=torch.uint8).pin_memory()) for _ in range(NBUF)]
+        cp_in, cp_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        ev_in = [torch.cuda.Event() for _ in range(NBUF)]
+        ev_free = [torch.cuda.Event() for _ in range(NBUF)]
+        ev_done = [torch.cuda.Event() for _ in range(NBUF)]
+
+        def e2e_step(k):
+            i = k % NBUF
+            cp_in.wait_event(ev_free[i])                      # the extraction that last read d_in[i] has finished
+            with torch.cuda.stream(cp_in):
+                d_in[i].copy_(h_in, non_blocking=True)
+                ev_in[i].record(cp_in)
+            side.wait_event(ev_in[i])
+            side.wait_event(ev_matched[i])
+            side.wait_event(ev_done[i])                       # the D2H that last read output set i has finished
+            ex.extract_batch_device(d_in[i].data_ptr(), B, W, H, W, W * H, d_kp[i].data_ptr(), d_desc[i].data_ptr(), cap,
+                                    d_n[i].data_ptr(), stream)
+            ev_free[i].record(side)
+            ev_extracted[i].record(side)
+            if not args.no_match:
+                mstream.wait_event(ev_extracted[i])
+                match(i, mstream.cuda_stream)
+            ev_matched[i].record(mstream)
+            cp_out.wait_event(ev_extracted[i])
+            with torch.cuda.stream(cp_out):
+                h_out[i][0].copy_(d_n[i], non_blocking=True)
+                h_out[i][1].copy_(d_kp[i], non_blocking=True)
+                h_out[i][2].copy_(d_desc[i], non_blocking=True)
+                ev_done[i].record(cp_out)
+
+        for k in range(args.warmup):
+            e2e_step(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            e2e_step(k)
+        torch.cuda.synchronize()
+        dte = time.perf_counter() - t0
+        h2d, d2h = B * W * H, B * (4 + cap * 60)
+        e2e = {"value": round(B * args.steps / dte, 2), "unit": "frames/s", "ms_per_step": round(dte / args.steps * 1e3, 4),
+               "h2d_bytes_per_step": int(h2d), "d2h_bytes_per_step": int(d2h),
+               "pcie_GBps": round((h2d + d2h) * args.steps / dte / 1e9, 2),
+               "note": "inputs from pinned host memory, records (fixed capacity) back to pinned host memory, double-buffered "
+                       "on copy streams; PCIe-bound -- `value` is the HBM-resident rate"}
+        assert int(h_out[(args.steps - 1) % NBUF][0][0]) > 0
+
     # ---- per-stage HIP-event timing on the launch stream (untimed extra steps)
     ex.set_stage_timing(True)
     acc = {}
@@ -273,38 +365,53 @@ def main():
     acc_all["match_best2"] = match_ms
     alg["match_best2"] = int(2 * round(kp_mean) * 32 + round(kp_mean) * 8)
     stage_gbs["match_best2"] = alg["match_best2"] * B / (match_ms * 1e-3) / 1e9 if match_ms > 0 else None
-    # `roofline` is reported for the dominant kernel of the extraction stream (FAST at every configuration measured).
-    # The best-2 match runs concurrently on its own stream, moves almost no bytes (VALU popcount work) and is within a few
-    # per cent of FAST in time, so letting it take the slot would flip the reported kernel from run to run; it has its own
-    # fields (match_ms, match_gpairs_per_s, match_frac_of_valu_popcount_peak, valu_issue).
-    dominant = max(acc, key=lambda k: acc[k])
+    # `roofline` is reported for the kernel that takes the most time among ALL stages of a step, the match included
+    # (stage times: HIP events on the launch stream, one stream, no overlap -- see stages_ms_note).
     acc = acc_all
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
+    dominant = max(acc, key=lambda k: acc[k])
+    # HBM bytes / VALU instructions per stage from separate rocprofv3 --pmc passes (tools/profile_round.sh).  They are
+    # REPLAYED from files under profiles/, not measured in this run: each carries the hash of the kernel sources it was
+    # collected on, and is dropped from the line when the sources have changed since.
+    from monoorbslam3_amd._lib import kernels_sha16
+    src_hash = kernels_sha16()
+
+    def replayed(name):
+        path = os.path.join(ROOT, "profiles", name)
         try:
-            tj = json.load(open(tpath))
-            if tj.get("batch") == B and dominant in tj.get("bytes_per_launch", {}):
-                traffic = tj["bytes_per_launch"][dominant]
+            j = json.load(open(path))
         except Exception:
-            traffic = None
-    # VALU instructions per stage per step from a rocprofv3 --pmc SQ_INSTS_VALU pass (tools/pmc_valu.py): the bound these
-    # integer kernels actually sit under is VALU issue, calibrated at VALU_PEAK_GWINST on this chip
+            return None, None
+        if j.get("batch") != B:
+            return None, "profiles/%s is for batch %s" % (name, j.get("batch"))
+        if j.get("kernels_sha16") != src_hash:
+            return None, "profiles/%s is stale (kernel sources changed since it was collected)" % name
+        return j, "profiles/%s (rocprofv3 --pmc pass of an earlier run of this command on the same kernel sources %s; replayed)" % (name, src_hash)
+
+    tj, traffic_source = replayed("pmc_traffic.json")
+    traffic = tj["bytes_per_launch"].get(dominant) if tj else None
+    vj, valu_source = replayed("pmc_valu.json")
     valu = None
-    vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
-    if os.path.exists(vpath):
-        try:
-            vj = json.load(open(vpath))
-            if vj.get("batch") == B:
-                valu = {k: {"wave_instr_per_step": int(n),
-                            "achieved_gwinst_s": round(n / (acc[k] * 1e-3) / 1e9, 1),
-                            "frac_of_calibrated_peak": round(n / (acc[k] * 1e-3) / 1e9 / VALU_PEAK_GWINST, 3)}
-                        for k, n in vj.get("wave_instr_per_step", {}).items() if k in acc and acc[k] > 0}
-        except Exception:
-            valu = None
+    if vj:
+        valu = {k: {"wave_instr_per_step": int(n),
+                    "achieved_gwinst_s": round(n / (acc[k] * 1e-3) / 1e9, 1),
+                    "frac_of_calibrated_peak": round(n / (acc[k] * 1e-3) / 1e9 / VALU_PEAK_GWINST, 3)}
+                for k, n in vj.get("wave_instr_per_step", {}).items() if k in acc and acc[k] > 0}
     fb_ms = acc["fast"] + acc["orient_desc"]
     fast_brief_gbs = 2 * P * B / (fb_ms * 1e-3) / 1e9
     pairs = float((counts.astype(np.float64) * np.roll(counts, -1)).sum())
+
+    def roof(k):
+        """Achieved algorithmic HBM bytes per second of stage k against the 8 TB/s peak.  Every stage here is bounded by
+        integer VALU issue before it is bounded by HBM; `limiter` says so where the instruction
+        counts are available."""
+        g = stage_gbs.get(k)
+        r = {"kernel": k, "bound": "hbm", "achieved": round(g, 1) if g else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(g / HBM_PEAK_GBS, 4) if g else None,
+             "traffic": (tj["bytes_per_launch"].get(k) if tj else None), "traffic_source": traffic_source,
+             "algorithmic_bytes_per_launch": int(alg[k] * B), "launch_ms": round(acc[k], 4)}
+        if valu and k in valu:
+            r["limiter"] = {"kind": "valu_issue", "frac_of_calibrated_peak": valu[k]["frac_of_calibrated_peak"]}
+        return r
 
     out = {
         "metric": baseline_metric(),
@@ -319,12 +426,18 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": "KITTI 1242x375, 2000 feat, 8-level pyramid scale 1.2, FAST 20/7; extract + "
-                               "2000x2000 Hamming best-2 per frame" + (" + frame records (undistort, grid, bag of words)" if args.records else "")
-                               if (W, H, NF) == (1242, 375, 2000) else
-                               "%dx%d, %d feat" % (W, H, NF),
+        "config": {"workload": ("KITTI 1242x375, 2000 feat, 8-level pyramid scale 1.2, FAST 20/7; extract + "
+                                "2000x2000 Hamming best-2 per frame" + (" + frame records (undistort, grid, bag of words)" if args.records else "")
+                                if (W, H, NF) == (1242, 375, 2000) else
+                                "Batched synthetic 1920x1080 stream, 2000 feat, %d concurrent frame(s) sharded %d/GPU, RCCL gather "
+                                "over xGMI; extract + Hamming best-2 against the previous frame" % (world * B, B)
+                                if (W, H, NF) == (1920, 1080, 2000) else "%dx%d, %d feat" % (W, H, NF)),
+                   "baseline_config": args.config,
                    "frames_per_gpu_per_step": B, "width": W, "height": H, "n_features": NF,
-                   "match": not args.no_match, "records": bool(args.records), "parallelism": "frames sharded 1 batch/GPU, one gather of records to rank 0 per step"},
+                   "match": not args.no_match, "records": bool(args.records),
+                   "parallelism": ("frames sharded %d per GPU per step over %d GPU(s), one gather of the fixed-capacity records "
+                                   "to rank 0 per step" % (B, world)) if world > 1 else
+                                  "%d resident frame(s) on one GPU, no collective" % B},
         "keypoints_per_frame": round(kp_mean, 1),
         "records": ({"words_per_frame": round(float(rec["n_words"][0].float().mean().item()), 1),
                      "fv_nodes_per_frame": round(float(rec["n_fv"][0].float().mean().item()), 1),
@@ -332,34 +445,27 @@ def main():
                     if rec else None),
         "stages_ms": {k: round(v, 4) for k, v in acc.items()},
         "match_ms": round(match_ms, 4),
-        "match_gpairs_per_s": round(pairs / (match_ms * 1e-3) / 1e9, 2) if match_ms > 0 else None,
-        "match_frac_of_valu_popcount_peak": round((pairs * 16 / 64) / (match_ms * 1e-3) / (VALU_PEAK_GWINST * 1e9), 3)
-        if match_ms > 0 else None,
         "stage_algorithmic_GBps": {k: (round(v, 1) if v else None) for k, v in stage_gbs.items()},
-        "roofline": {
-            "kernel": dominant, "bound": "hbm",
-            "achieved": round(stage_gbs[dominant], 1) if stage_gbs[dominant] else None,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(stage_gbs[dominant] / HBM_PEAK_GBS, 4) if stage_gbs[dominant] else None,
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg[dominant] * B,
-            "launch_ms": round(acc[dominant], 4),
-        },
-        "valu_issue": {"peak_gwinst_s": VALU_PEAK_GWINST, "stages": valu},
+        "stages_ms_note": "HIP events around each stage with every kernel on ONE stream (orbx_set_stage_timing), extra untimed "
+                          "steps; the timed steps overlap FAST / blur / match on three streams, so the stages sum to more "
+                          "than ms_per_step",
+        "roofline": roof(dominant),
+        "roofline_fast": roof("fast"),
+        "roofline_match": dict(roof("match_best2"), valu_popcount={
+            "pairs_per_step": int(pairs), "gpairs_per_s": round(pairs / (match_ms * 1e-3) / 1e9, 2) if match_ms > 0 else None,
+            "frac_of_calibrated_xor_bcnt_peak": round((pairs * 16 / 64) / (match_ms * 1e-3) / (VALU_PEAK_GWINST * 1e9), 3)
+            if match_ms > 0 else None,
+            "note": "16 VALU lane-operations per 256-bit pair at least (8 xor + 8 popcount); peak = %.1f G wave-instructions/s "
+                    "measured with tools/microbench/valu_peak.hip" % VALU_PEAK_GWINST}),
         "roofline_fast_plus_brief": {"bound": "hbm", "achieved": round(fast_brief_gbs, 1), "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": round(fast_brief_gbs / HBM_PEAK_GBS, 4),
                                      "algorithmic_bytes_per_frame": 2 * P},
+        "valu_issue": {"peak_gwinst_s": VALU_PEAK_GWINST, "stages": valu, "source": valu_source},
     }
+    if e2e is not None:
+        out["value_end_to_end"] = e2e
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = min(16, os.cpu_count() or 1)
-        n_cpu = threads * 24  # about 20-30 s of CPU work in total, a couple of seconds of wall time
-        cf = base[np.arange(n_cpu) % n_distinct]
-        v, done, cdt = cpu_baseline(cf, NF, threads, not args.no_match)
-        out["cpu_baseline"] = {"value": round(v, 2), "unit": "frames/s", "cores": threads, "kind": "port",
-                               "sample": "%d frames of the same synthetic workload, extraction%s, C oracle (restatement of "
-                                         "the reference's CPU code, -O2), %.1f s wall on %d threads"
-                                         % (done, "" if args.no_match else " + best/second-best match against the "
-                                            "previous frame", cdt, threads)}
+        out["cpu_baseline"] = cpu_baseline(base, NF, min(16, os.cpu_count() or 1), not args.no_match)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

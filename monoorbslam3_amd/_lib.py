@@ -73,3 +73,14 @@ def lib():
 def check(rc):
     if rc != 0:
         raise OrbxError(rc, lib().orbx_last_error().decode("utf-8", "replace"))
+
+
+def kernels_sha16():
+    """First 16 hex digits of the sha256 over the kernel sources (csrc/*.hip, *.h): ties a profile to the code it measured."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]

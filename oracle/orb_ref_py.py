@@ -48,6 +48,19 @@ def build(force=False):
     return _LIB
 
 
+def build_native():
+    """Rebuild the oracle -O3 -march=native for THIS machine and make lib() use it (bench.py's cpu_baseline leg only: the
+    tests keep the portable -O2 build).  Returns a description of the build that is loaded."""
+    global _LIB, _lib
+    native = os.path.join(_HERE, "liborb_ref_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])
+    except Exception:
+        return "gcc -O2 (the -march=native build failed on this machine)"
+    _LIB, _lib = native, None
+    return "gcc -O3 -march=native -ffp-contract=off"
+
+
 _lib = None
 
 

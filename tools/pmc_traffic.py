@@ -8,10 +8,14 @@ Usage: pmc_traffic.py <fetch_dir> <write_dir> <batch> <out.json>"""
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
 
-STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_blur_cols": "blur", "k_octree_lds": "octree",
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from monoorbslam3_amd._lib import kernels_sha16  # noqa: E402  (hash of the kernel sources the counters belong to)
+
+STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_fast_strip": "fast", "k_blur_cols": "blur", "k_octree_lds": "octree",
          "k_orient": "orient_desc", "k_orient_desc": "orient_desc", "k_best2": "match_best2"}
 # per-step totals = sum over all dispatches of a kernel / number of steps in the run; a step has exactly one quadtree launch
 STEP_MARKER = "k_octree_lds"
@@ -38,7 +42,7 @@ def main():
             per_step = sum(v) / n_steps  # resize: 7 launches, FAST: 2 (level 0 early + the rest), best-2: 2 per step
             res[STAGE[k]] += per_step * 1024 * (2 if label == "fetch" else 1)
             detail["%s.%s_KB" % (k, label)] = round(per_step, 1)
-    json.dump({"batch": batch, "unit": "bytes per stage per step (all launches of the stage); fetch = 2 x FETCH_SIZE",
+    json.dump({"batch": batch, "kernels_sha16": kernels_sha16(), "unit": "bytes per stage per step (all launches of the stage); fetch = 2 x FETCH_SIZE",
                "bytes_per_launch": {k: int(v) for k, v in res.items()}, "detail": detail}, open(out, "w"), indent=1)
     print(json.dumps({k: int(v) for k, v in res.items()}))
 

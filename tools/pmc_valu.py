@@ -4,10 +4,14 @@ per stage per step (all launches of the stage).  Usage: pmc_valu.py <pmc_dir> <b
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
 
-STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_blur_cols": "blur", "k_blur_edges": "blur",
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from monoorbslam3_amd._lib import kernels_sha16  # noqa: E402  (hash of the kernel sources the counters belong to)
+
+STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_fast_strip": "fast", "k_blur_cols": "blur", "k_blur_edges": "blur",
          "k_octree_lds": "octree", "k_octree": "octree", "k_orient": "orient_desc", "k_orient_desc": "orient_desc",
          "k_best2": "match_best2"}
 STEP_MARKER = "k_octree_lds"  # exactly one launch per step: per-step totals = sum over all dispatches / its count
@@ -28,7 +32,7 @@ def main():
         per_step = sum(v) / n_steps  # resize: 7 launches per step, FAST and best-2: 2
         res[STAGE[k]] += per_step
         detail[k] = round(per_step)
-    json.dump({"batch": batch, "unit": "VALU wave-instructions per stage per step (SQ_INSTS_VALU, all launches)",
+    json.dump({"batch": batch, "kernels_sha16": kernels_sha16(), "unit": "VALU wave-instructions per stage per step (SQ_INSTS_VALU, all launches)",
                "wave_instr_per_step": {k: int(v) for k, v in res.items()}, "detail": detail}, open(out, "w"), indent=1)
     print(json.dumps(dict(res)))
 
