@@ -199,6 +199,153 @@ __global__ __launch_bounds__(256) void k_best2(const uint8_t *__restrict__ a, si
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same best / second-best search on the MATRIX pipe (an experiment the VALU kernel above stays the parity twin of).
+// For bit vectors a (candidate) and b (query):  hamming(a, b) = popcount(b) - sum_k a_k * (2 b_k - 1),
+// so with the candidates unpacked to 0/1 bytes and the queries to +1/-1 bytes one v_mfma_i32_32x32x32_i8 chain (8 steps
+// of 32 bits) leaves  popcount(b) - hamming  for 32 candidates x 32 queries in the accumulators, exact in i32.  Orientation: candidates are the rows (A operand), queries the columns (B operand): a lane then owns ONE
+// query and 16 candidates per tile, so the running two-smallest-keys state lives in the lane and needs no cross-lane
+// step until the very end.  Any bit -> k assignment works as long as both operands use the same one (a dot product does
+// not care about the order of its terms); here step t takes descriptor dword t, lane half h and byte i of operand
+// dword j take bit 8 i + j + 4 h.
+//   workgroup = 8 waves = 256 queries; the candidate set streams through LDS 64 descriptors at a time, unpacked by the
+//   whole workgroup (2 VALU per dword), double-buffered; per 32 x 32 tile a wave issues 8 ds_read_b128 + 8 MFMA and
+//   3 VALU per accumulator register (key = (256 - acc) << 22 | (tile, register), then the med3 / min update) instead of the
+//   19 per pair-lane of the VALU kernel.
+// ---------------------------------------------------------------------------------------------
+typedef int bm_v4i __attribute__((ext_vector_type(4)));
+typedef int bm_v16i __attribute__((ext_vector_type(16)));
+#define BM_WAVES 8
+#define BM_TC 128  // candidates per stage (four 32-row MFMA tiles)
+#define BM_ROWB 272 // bytes per unpacked candidate in LDS: 256 + 16 so that the 32 rows of a tile fall in different banks
+// a * m + c with 24-bit signed factors; c is wave-uniform (a VOP3 instruction of gfx9 reads at most one SGPR)
+__device__ __forceinline__ uint32_t bm_mad24(int a, int m, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(m), "s"(c));
+    return d;
+}
+__global__ __launch_bounds__(BM_WAVES * 64) void k_best2_mfma(const uint8_t *__restrict__ a, size_t a_stride,
+                                                              const int32_t *__restrict__ na_p, int na_max,
+                                                              const uint8_t *__restrict__ b, size_t b_stride,
+                                                              const int32_t *__restrict__ nb_p, int nb_max,
+                                                              const uint8_t *__restrict__ row_ok,
+                                                              int32_t *__restrict__ best_idx, uint16_t *__restrict__ best,
+                                                              uint16_t *__restrict__ second)
+{
+    __shared__ __align__(16) uint8_t sb[2][BM_TC * BM_ROWB];
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int na = na_p ? min(na_p[p], na_max) : na_max, nb = nb_p ? min(nb_p[p], nb_max) : nb_max;
+    const int row0 = blockIdx.x * (BM_WAVES * 32) + wave * 32;
+    const uint8_t *A = a + (size_t)p * a_stride * 32;
+    const uint8_t *B = b + (size_t)p * b_stride * 32;
+
+    // ---- this lane's query as the B operand of the 8 steps: +1 / -1 bytes, and -popcount as the accumulator seed
+    bm_v4i bq[8];
+    int pcq = 0;
+    {
+        const int row = min(row0 + n, max(na_max - 1, 0)); // clamped rows are computed but never stored
+        const uint32_t *pq = reinterpret_cast<const uint32_t *>(A + (size_t)row * 32);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint32_t w = na_max > 0 ? pq[t] : 0u;
+            pcq += __popc(w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t d = (w >> (j + 4 * h)) & 0x01010101u;
+                bq[t][j] = (int)(((d ^ 0x01010101u) * 0xFFu) | d);
+            }
+        }
+    }
+    // hamming = popcount(query) - acc, and the popcount is the same for everything a lane sees: the running state orders
+    // candidates by key = (256 - acc) << 22 | (tile * 16 + register) and the popcount comes in at the very end
+    const uint32_t SENT = 0xFFFFFFFFu;
+    uint32_t k1 = SENT, k2 = SENT; // the two smallest keys seen so far
+
+    // ---- staging: thread = (candidate tid / 8 (+ 64) of the stage, descriptor dword tid % 8) -> 32 unpacked bytes each
+    const int sr = tid >> 3, st = tid & 7;
+    auto stage = [&](int step, int buf) {
+        uint32_t w[BM_TC / 64];
+#pragma unroll
+        for (int q = 0; q < BM_TC / 64; ++q) {
+            const int j = step * BM_TC + 64 * q + sr;
+            w[q] = j < nb ? reinterpret_cast<const uint32_t *>(B + (size_t)j * 32)[st] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < BM_TC / 64; ++q) {
+            uint4 lo, hi;
+            lo.x = w[q] & 0x01010101u;        lo.y = (w[q] >> 1) & 0x01010101u; lo.z = (w[q] >> 2) & 0x01010101u; lo.w = (w[q] >> 3) & 0x01010101u;
+            hi.x = (w[q] >> 4) & 0x01010101u; hi.y = (w[q] >> 5) & 0x01010101u; hi.z = (w[q] >> 6) & 0x01010101u; hi.w = (w[q] >> 7) & 0x01010101u;
+            uint4 *dst = reinterpret_cast<uint4 *>(&sb[buf][(64 * q + sr) * BM_ROWB + st * 32]);
+            dst[0] = lo; dst[1] = hi;
+        }
+    };
+    const int n_steps = (nb + BM_TC - 1) / BM_TC;
+    const int mult = -(1 << 22);
+    if (n_steps > 0) stage(0, 0);
+    __syncthreads();
+    for (int s = 0; s < n_steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < n_steps) stage(s + 1, buf ^ 1);
+#pragma unroll
+        for (int pair = 0; pair < BM_TC / 64; ++pair) { // two tiles at a time: the second one's MFMAs run under the first one's update
+            bm_v16i acc[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const uint8_t *src = &sb[buf][((2 * pair + sub) * 32 + n) * BM_ROWB + h * 16];
+                const bm_v16i zero = {};
+                acc[sub] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const bm_v4i *>(src), bq[0], zero, 0, 0, 0);
+#pragma unroll
+                for (int t = 1; t < 8; ++t)
+                    acc[sub] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const bm_v4i *>(src + t * 32), bq[t], acc[sub], 0, 0, 0);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int tile = (BM_TC / 32) * s + 2 * pair + sub, nvalid = nb - tile * 32; // candidates of this tile that exist
+                const uint32_t kbase = (256u << 22) + (uint32_t)tile * 16u;
+                if (nvalid >= 32) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t k = bm_mad24(acc[sub][r], mult, kbase + r);
+                        k2 = med3_u32(k, k1, k2);
+                        k1 = min(k, k1);
+                    }
+                } else if (nvalid > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        uint32_t k = bm_mad24(acc[sub][r], mult, kbase + r);
+                        if ((r & 3) + 8 * (r >> 2) + 4 * h >= nvalid) k = SENT; // accumulator row of register r (C/D layout)
+                        k2 = med3_u32(k, k1, k2);
+                        k1 = min(k, k1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the lane pair (n, n + 32) holds one query's two halves: turn (tile, register) into the candidate index, merge
+    {
+        const uint32_t r = k1 & 15u, tile = (k1 & 0x3FFFFFu) >> 4;
+        if (k1 != SENT) k1 = (k1 & ~0x3FFFFFu) | (tile * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h);
+        const uint32_t o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32);
+        k2 = min(min(k2, o2), max(k1, o1));
+        k1 = min(k1, o1);
+    }
+    const int row = row0 + n;
+    if (h == 0 && row < na_max) {
+        const size_t orow = (size_t)p * a_stride + row;
+        const bool live = row < na && (!row_ok || row_ok[orow]);
+        // key >> 22 = 256 - acc = 256 - popcount(query) + hamming
+        const uint32_t d1 = k1 == SENT ? 256u : (k1 >> 22) + (uint32_t)pcq - 256u;
+        const uint32_t ss = k2 == SENT ? 256u : (k2 >> 22) + (uint32_t)pcq - 256u;
+        // a 256-distance candidate never beats the initial 256 of the reference loop
+        best_idx[orow] = (live && d1 < 256) ? (int32_t)(k1 & 0x3FFFFFu) : -1;
+        best[orow] = live ? (uint16_t)min(d1, 256u) : (uint16_t)256;
+        second[orow] = live ? (uint16_t)min(ss, 256u) : (uint16_t)256;
+    }
+}
+
 // distances for explicit candidate lists; one wave per query
 __global__ __launch_bounds__(256) void k_hamming_lists(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
                                                        const int32_t *__restrict__ q_idx,
@@ -393,6 +540,16 @@ extern "C" int orbm_best2_device(orbm_t *c, int n_pairs, const uint8_t *d_a, siz
     if (nb_max >= (1 << 23)) return orbx_set_error(ORBX_E_UNSUPPORTED, "more than 2^23 candidates per problem");
     if (na_max == 0) return ORBX_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // the matrix-pipe kernel takes every problem without a candidate mask and fewer than 2^19 * 32 candidates;
+    // ORBM_BEST2=valu keeps everything on the VALU kernel (its parity twin)
+    static const bool use_mfma = [] { const char *e = getenv("ORBM_BEST2"); return !(e && strcmp(e, "valu") == 0); }();
+    if (use_mfma && !d_col_ok && nb_max < (1 << 22)) {
+        dim3 grid((na_max + BM_WAVES * 32 - 1) / (BM_WAVES * 32), n_pairs);
+        hipLaunchKernelGGL(k_best2_mfma, grid, dim3(BM_WAVES * 64), 0, s, d_a, a_stride, d_na, na_max, d_b, b_stride, d_nb,
+                           nb_max, d_row_ok, d_best_idx, d_best, d_second);
+        M_TRY(hipGetLastError());
+        return ORBX_OK;
+    }
     dim3 grid((na_max + 4 * B2_ROWS - 1) / (4 * B2_ROWS), n_pairs);
     hipLaunchKernelGGL(k_best2, grid, dim3(256), 0, s, d_a, a_stride, d_na, na_max, d_b, b_stride, d_nb, nb_max,
                        d_row_ok, d_col_ok, d_best_idx, d_best, d_second);
