@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank computes on cuda:0")
+    ap.add_argument("--gather", default="torch", choices=["torch", "c-abi"],
+                    help="N > 1: the record gather through torch.distributed (default) or through the library's own RCCL "
+                         "entry point orbd_gather_records (include/orbd.h)")
     args = ap.parse_args()
     if args.config == 4:
         dw, dh, db = 1920, 1080, 1
@@ -217,8 +220,18 @@ def main():
     # N > 1: one gather of the fixed-capacity records to rank 0 per step, on its own stream so that the xGMI
     # transfer of batch k overlaps the extraction of batch k+1 (everything is drained before the clock stops)
     cstream = torch.cuda.Stream(device=dev) if world > 1 else None
+    xc, xc_out = None, None
+    if world > 1 and args.gather == "c-abi" and args.backend == "nccl":
+        from monoorbslam3_amd.dist import RecordExchange
+        uid = [RecordExchange.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        xc = RecordExchange(rank, world, uid[0], device=local_rank)
+        if rank == 0:
+            xc_out = [(torch.empty((world, B), dtype=torch.int32, device=dev),
+                       torch.empty((world, B, cap, 28), dtype=torch.uint8, device=dev),
+                       torch.empty((world, B, cap, 32), dtype=torch.uint8, device=dev)) for _ in range(NBUF)]
     recv = None
-    if world > 1 and rank == 0:
+    if world > 1 and rank == 0 and xc is None:
         nbytes = pack_records(d_n[0], d_kp[0], d_desc[0]).numel()
         recv = [[torch.empty(nbytes, dtype=torch.uint8, device=coll_dev) for _ in range(world)] for _ in range(NBUF)]
 
@@ -258,7 +271,9 @@ def main():
         if world > 1:
             cstream.wait_event(ev_extracted[i])
             with torch.cuda.stream(cstream):
-                if args.backend == "nccl":
+                if xc is not None:
+                    xc.gather(d_n[i], d_kp[i], d_desc[i], root=0, stream=cstream.cuda_stream, out=xc_out[i] if rank == 0 else None)
+                elif args.backend == "nccl":
                     gather_records_to_root(d_n[i], d_kp[i], d_desc[i], recv[i] if rank == 0 else None)
                 else:  # rehearsal on a 1-GPU box: host copies through gloo
                     gather_records_to_root(d_n[i].to(coll_dev), d_kp[i].to(coll_dev), d_desc[i].to(coll_dev),

@@ -215,8 +215,12 @@ __global__ __launch_bounds__(256) void k_best2(const uint8_t *__restrict__ a, si
 // ---------------------------------------------------------------------------------------------
 typedef int bm_v4i __attribute__((ext_vector_type(4)));
 typedef int bm_v16i __attribute__((ext_vector_type(16)));
+#ifndef BM_WAVES
 #define BM_WAVES 8
+#endif
+#ifndef BM_TC
 #define BM_TC 128  // candidates per stage (four 32-row MFMA tiles)
+#endif
 #define BM_ROWB 272 // bytes per unpacked candidate in LDS: 256 + 16 so that the 32 rows of a tile fall in different banks
 // a * m + c with 24-bit signed factors; c is wave-uniform (a VOP3 instruction of gfx9 reads at most one SGPR)
 __device__ __forceinline__ uint32_t bm_mad24(int a, int m, uint32_t c)
@@ -263,21 +267,22 @@ __global__ __launch_bounds__(BM_WAVES * 64) void k_best2_mfma(const uint8_t *__r
     const uint32_t SENT = 0xFFFFFFFFu;
     uint32_t k1 = SENT, k2 = SENT; // the two smallest keys seen so far
 
-    // ---- staging: thread = (candidate tid / 8 (+ 64) of the stage, descriptor dword tid % 8) -> 32 unpacked bytes each
+    // ---- staging: thread = (candidate tid / 8 (+ multiples of the workgroup's 8 per wave) of the stage, descriptor dword
+    // tid % 8) -> 32 unpacked bytes each
     const int sr = tid >> 3, st = tid & 7;
     auto stage = [&](int step, int buf) {
-        uint32_t w[BM_TC / 64];
+        uint32_t w[BM_TC / (BM_WAVES * 8)];
 #pragma unroll
-        for (int q = 0; q < BM_TC / 64; ++q) {
-            const int j = step * BM_TC + 64 * q + sr;
+        for (int q = 0; q < BM_TC / (BM_WAVES * 8); ++q) {
+            const int j = step * BM_TC + (BM_WAVES * 8) * q + sr;
             w[q] = j < nb ? reinterpret_cast<const uint32_t *>(B + (size_t)j * 32)[st] : 0u;
         }
 #pragma unroll
-        for (int q = 0; q < BM_TC / 64; ++q) {
+        for (int q = 0; q < BM_TC / (BM_WAVES * 8); ++q) {
             uint4 lo, hi;
             lo.x = w[q] & 0x01010101u;        lo.y = (w[q] >> 1) & 0x01010101u; lo.z = (w[q] >> 2) & 0x01010101u; lo.w = (w[q] >> 3) & 0x01010101u;
             hi.x = (w[q] >> 4) & 0x01010101u; hi.y = (w[q] >> 5) & 0x01010101u; hi.z = (w[q] >> 6) & 0x01010101u; hi.w = (w[q] >> 7) & 0x01010101u;
-            uint4 *dst = reinterpret_cast<uint4 *>(&sb[buf][(64 * q + sr) * BM_ROWB + st * 32]);
+            uint4 *dst = reinterpret_cast<uint4 *>(&sb[buf][((BM_WAVES * 8) * q + sr) * BM_ROWB + st * 32]);
             dst[0] = lo; dst[1] = hi;
         }
     };

@@ -102,3 +102,84 @@ def extract_sharded(frames, extract_fn, cap, group=None, device="cpu"):
         c = int(g_counts[r, k])
         out.append((c, g_kps[r, k, :c].copy(), g_desc[r, k, :c].copy()))
     return out
+
+
+class RecordExchange:
+    """The same exchange through the C ABI (include/orbd.h): RCCL called from liborbx.so itself, for consumers without
+    torch.distributed (the reference is C++).  The 128-byte unique id comes from rank 0 (RecordExchange.unique_id())
+    and reaches the other ranks by any out-of-band means."""
+
+    def __init__(self, rank, world, unique_id, device=-1):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        L = _lib.lib()
+        vp, i32 = C.c_void_p, C.c_int
+        for name, res, args in (("orbd_create", i32, [i32, i32, vp, i32, C.POINTER(vp)]), ("orbd_destroy", None, [vp]),
+                                ("orbd_rank", i32, [vp]), ("orbd_world", i32, [vp]),
+                                ("orbd_gather_records", i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+                                ("orbd_allgather_records", i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp])):
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        self._L = L
+        self._h = vp()
+        idb = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _lib.check(L.orbd_create(rank, world, idb, device, C.byref(self._h)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        L.orbd_unique_id.restype, L.orbd_unique_id.argtypes = C.c_int, [C.c_void_p]
+        buf = (C.c_uint8 * 128)()
+        _lib.check(L.orbd_unique_id(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def shard(n_frames, rank, world):
+        """Global indices of the frames rank `rank` owns (orbd_shard_count / orbd_shard_global_index)."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        for name in ("orbd_shard_count", "orbd_shard_global_index"):
+            getattr(L, name).restype, getattr(L, name).argtypes = C.c_int, [C.c_int, C.c_int, C.c_int]
+        return [L.orbd_shard_global_index(k, rank, world) for k in range(L.orbd_shard_count(n_frames, rank, world))]
+
+    def gather(self, counts, kps, desc, root=0, stream=None, out=None):
+        """counts int32 [b], kps uint8 [b, cap, 28], desc uint8 [b, cap, 32] device tensors -> on the root
+        (counts [world, b], kps [world, b, cap, 28], desc [world, b, cap, 32]), None elsewhere.  `out` (root only): a
+        preallocated triple to receive into."""
+        b, cap = kps.shape[0], kps.shape[1]
+        if self.rank == root and out is None:
+            out = (torch.empty((self.world, b), dtype=torch.int32, device=kps.device),
+                   torch.empty((self.world, b, cap, KP_BYTES), dtype=torch.uint8, device=kps.device),
+                   torch.empty((self.world, b, cap, DESC_BYTES), dtype=torch.uint8, device=kps.device))
+        st = stream if stream is not None else torch.cuda.current_stream(kps.device).cuda_stream
+        p = (lambda t: t.data_ptr()) if out is not None else (lambda t: None)
+        self._lib.check(self._L.orbd_gather_records(self._h, root, b, cap, counts.data_ptr(), kps.data_ptr(), desc.data_ptr(),
+                                                    p(out[0]) if out else None, p(out[1]) if out else None,
+                                                    p(out[2]) if out else None, st))
+        return out
+
+    def allgather(self, counts, kps, desc, stream=None):
+        b, cap = kps.shape[0], kps.shape[1]
+        out = (torch.empty((self.world, b), dtype=torch.int32, device=kps.device),
+               torch.empty((self.world, b, cap, KP_BYTES), dtype=torch.uint8, device=kps.device),
+               torch.empty((self.world, b, cap, DESC_BYTES), dtype=torch.uint8, device=kps.device))
+        st = stream if stream is not None else torch.cuda.current_stream(kps.device).cuda_stream
+        self._lib.check(self._L.orbd_allgather_records(self._h, b, cap, counts.data_ptr(), kps.data_ptr(), desc.data_ptr(),
+                                                       out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), st))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.orbd_destroy(self._h)
+            self._h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -109,3 +109,29 @@ def test_sharded_extract_world2(n_frames):
 def test_shard_indices():
     assert D.shard_indices(10, 1, 4) == [1, 5, 9]
     assert D.unshard_order(5, 2) == [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2)]
+
+
+def test_c_abi_sharding_arithmetic_matches_the_torch_path():
+    """orbd_shard_count / orbd_shard_global_index (include/orbd.h) = monoorbslam3_amd.dist.shard_indices: frame i of a
+    global batch goes to rank i % world."""
+    from monoorbslam3_amd import dist as D
+    for n in (0, 1, 7, 8, 9, 512):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for rank in range(world):
+                mine = D.RecordExchange.shard(n, rank, world)
+                assert mine == D.shard_indices(n, rank, world)
+                seen += mine
+            assert sorted(seen) == list(range(n))
+
+
+def test_c_abi_exchange_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    from monoorbslam3_amd import dist as D
+    from monoorbslam3_amd._lib import OrbxError
+    with pytest.raises(OrbxError, match="no HIP device"):
+        D.RecordExchange.unique_id()
+    with pytest.raises(OrbxError, match="no HIP device"):
+        D.RecordExchange(0, 1, bytes(128))

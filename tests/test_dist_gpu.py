@@ -43,3 +43,34 @@ def test_rccl_gather_paths_world1():
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def test_c_abi_record_exchange_world1():
+    """include/orbd.h: RCCL driven from liborbx.so itself (no torch.distributed): unique id, communicator, gather to
+    the root and all-gather of real extraction records on a side stream.  One GPU here, so world = 1; the N > 1 path
+    is the same grouped send / recv with more peers."""
+    from monoorbslam3_amd import dist as D, synth
+    from monoorbslam3_amd.extractor import ORBExtractor
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    w, h, B = 640, 240, 3
+    frames = torch.from_numpy(synth.make_frames(B, w, h, seed=5)).to(dev)
+    ex = ORBExtractor(500, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    cap = ex.max_keypoints(w, h)
+    d_kp = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    ex.extract_batch_device(frames.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(),
+                            side.cuda_stream)
+    xc = D.RecordExchange(0, 1, D.RecordExchange.unique_id(), device=0)
+    assert (xc._L.orbd_rank(xc._h), xc._L.orbd_world(xc._h)) == (0, 1)
+    got = xc.gather(d_n, d_kp, d_desc, root=0, stream=side.cuda_stream)
+    allg = xc.allgather(d_n, d_kp, d_desc, stream=side.cuda_stream)
+    side.synchronize()
+    assert int(d_n.min()) > 100
+    for g in (got, allg):
+        assert torch.equal(g[0][0], d_n) and torch.equal(g[1][0], d_kp) and torch.equal(g[2][0], d_desc)
+    with pytest.raises(Exception):
+        xc.gather(d_n, d_kp, d_desc, root=3)
+    xc.close()
