@@ -3,7 +3,8 @@
  *
  * Drop-in boundary for the reference's ORBMatcher
  * (modules/ORB/ORBMatcher.h:12-52, modules/ORB/ORBMatcher.cpp).  The 256-bit
- * Hamming brute force of every Search* routine runs as HIP kernels; the greedy,
+ * Hamming brute force of every Search* routine runs as HIP kernels (the dense best / second-best search on the
+ * matrix pipe; the window searches with Frame::grid and getFeaturesInArea on the device as well); the greedy,
  * order-dependent resolution (which mutates Frame/KeyFrame/MapPoint objects in
  * the reference) consumes the device-computed distances on the host so that the
  * results are identical to the reference's sequential loops.
@@ -137,6 +138,23 @@ int orbm_search_fuse(orbm_t *h, const uint8_t *q_desc, const float *q_xy, const 
                      const int32_t *q_level, const uint8_t *q_ok, int nq,
                      const void *kps, const uint8_t *desc, int n, int img_w, int img_h,
                      const float *sigma2, int n_levels, int32_t *best_idx, int32_t *best_dist, int *n_found);
+
+/* Frame / KeyFrame::getFeaturesInArea (modules/BasicObject/Frame.cpp:97-127, KeyFrame.cpp:181-211) plus the descriptor
+ * distance of every hit, for nq queries against ONE device-resident frame record: d_kps / d_desc as written by
+ * orbx_extract_batch_device (undistorted key points: orbf's d_kp_un), d_cell_start / d_cell_items = the CSR grid of
+ * orbf_frame_post_device (grid_cols x grid_rows cells of 40 px, cell id = cx * grid_rows + cy).  Query q: centre
+ * d_q_xy[2q..], radius d_q_radius[q], levels d_q_min_level[q] .. d_q_max_level[q] with the reference's beCheckLevel rule
+ * (Frame.cpp:107), d_q_ok[q] = 0 switches it off.  strict != 0 = KeyFrame's `< r` test; d_sigma2 != NULL drops hits whose
+ * squared distance to the centre exceeds 5.991 * d_sigma2[octave] (the fuse, ORBMatcher.cpp:566-567).
+ * d_lists[q * cap + p] = distance << 22 | key-point index for the p-th hit in the reference's list order (cx outer, cy
+ * inner, ascending index inside a cell), p < cap; d_counts[q] = the full list length (may exceed cap), -1 for a query
+ * that is off.  Every pointer is device memory; enqueued on `stream` (NULL = the handle's).  This is the primitive under
+ * the four window searches above, which wrap it with one staging copy each way when called with host pointers. */
+int orbm_window_lists_device(orbm_t *h, const void *d_kps, const uint8_t *d_desc, const int32_t *d_cell_start,
+                             const int32_t *d_cell_items, int grid_cols, int grid_rows, const uint8_t *d_q_desc,
+                             const float *d_q_xy, const float *d_q_radius, const int32_t *d_q_min_level,
+                             const int32_t *d_q_max_level, const uint8_t *d_q_ok, int nq, int strict,
+                             const float *d_sigma2, int cap, int32_t *d_counts, uint32_t *d_lists, void *stream);
 
 /* MapPoint::computeDescriptor (modules/BasicObject/MapPoint.cpp:103-152) for n_groups map points at once.
  * Group g = the descriptors desc[off[g] .. off[g+1]) of one point's observations (the caller skips bad key frames,

@@ -449,6 +449,148 @@ __global__ __launch_bounds__(64) void k_medoid(const uint8_t *__restrict__ desc,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Window searches on a device-resident grid: Frame::grid + Frame / KeyFrame::getFeaturesInArea
+// (modules/BasicObject/Frame.cpp:33-51, :97-127; KeyFrame.cpp:181-211) and the Hamming distances of every window,
+// without the key points ever visiting the host.
+// ---------------------------------------------------------------------------------------------
+#define ORBM_GRID 40 // Frame::GRID_SIZE (modules/BasicObject/Frame.h:18)
+
+// Frame.cpp:33-51: the 40-px grid as CSR, cell id = cx * rows + cy (grid[cx][cy]), items of a cell in ascending key-point
+// index (the push_back order of :45-50).  One workgroup per frame; the same counting sort as k_frame_post.
+#define GB_T 1024 // one workgroup builds the grid of a frame
+__global__ __launch_bounds__(GB_T) void k_grid_build(const orbx_kp *__restrict__ kps, int n, int img_w, int img_h, int cols,
+                                                    int rows, int32_t *__restrict__ cell_start,
+                                                    int32_t *__restrict__ cell_items, int32_t *__restrict__ cell_of,
+                                                    int32_t *__restrict__ tmp, int32_t *__restrict__ zero_me)
+{
+    extern __shared__ int32_t g_lds[]; // start[nc + 1], cursor[nc]
+    __shared__ int32_t wave_sum[GB_T / 64];
+    const int tid = threadIdx.x, nc = cols * rows;
+    if (tid == 0 && zero_me) *zero_me = 0; // the next kernel's pool counter
+    int32_t *start = g_lds, *cursor = g_lds + nc + 1;
+    for (int c = tid; c < nc; c += GB_T) cursor[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += GB_T) {
+        const int x = orb_floor_f(kps[i].x), y = orb_floor_f(kps[i].y); // Frame::PosInGrid (Frame.cpp:89-94)
+        int c = -1;
+        if (x >= 0 && x < img_w && y >= 0 && y < img_h) {
+            c = (x / ORBM_GRID) * rows + (y / ORBM_GRID);
+            atomicAdd(&cursor[c], 1);
+        }
+        cell_of[i] = c;
+    }
+    __syncthreads();
+    const int per = (nc + GB_T - 1) / GB_T, c0 = min(tid * per, nc), c1 = min(c0 + per, nc);
+    int local = 0;
+    for (int c = c0; c < c1; ++c) local += cursor[c];
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += t;
+    }
+    if ((tid & 63) == 63) wave_sum[tid >> 6] = incl;
+    __syncthreads();
+    int base = incl - local;
+    for (int w = 0; w < (tid >> 6); ++w) base += wave_sum[w];
+    for (int c = c0; c < c1; ++c) {
+        const int cnt = cursor[c];
+        start[c] = base; cell_start[c] = base; cursor[c] = 0;
+        base += cnt;
+    }
+    if (tid == GB_T - 1) { start[nc] = base; cell_start[nc] = base; }
+    __syncthreads();
+    for (int i = tid; i < n; i += GB_T) { // unordered fill, then the rank inside the cell = number of smaller indices
+        const int c = cell_of[i];
+        if (c >= 0) tmp[start[c] + atomicAdd(&cursor[c], 1)] = i;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += GB_T) {
+        const int c = cell_of[i];
+        if (c < 0) continue;
+        const int b = start[c], e = start[c + 1];
+        int rank = 0;
+        for (int t = b; t < e; ++t) rank += tmp[t] < i;
+        cell_items[b + rank] = i;
+    }
+}
+
+// One wave per query: getFeaturesInArea(x, y, r, min_level, max_level) in the reference's order (cx outer, cy inner,
+// cell items ascending: for one cx the cells minCY..maxCY are one contiguous run of the CSR) and the distance of every
+// hit.  out[q * cap + p] = distance << 22 | key-point index for list position p < cap; counts[q] = the full list
+// length (> cap: the caller's buffer was too small), -1 for a query that is switched off.
+//   strict   : KeyFrame::getFeaturesInArea's `< r` window test (KeyFrame.cpp:204) instead of Frame's `<= r`
+//   sigma2   : if non-NULL the fuse's chi-square gate (ORBMatcher.cpp:566-567) drops hits from the list
+__global__ __launch_bounds__(256) void k_window_lists(const orbx_kp *__restrict__ kps, const uint8_t *__restrict__ desc,
+                                                      const int32_t *__restrict__ cell_start,
+                                                      const int32_t *__restrict__ cell_items, int cols, int rows,
+                                                      const uint8_t *__restrict__ q_desc, const float *__restrict__ q_xy,
+                                                      const float *__restrict__ q_r, const int32_t *__restrict__ q_min,
+                                                      const int32_t *__restrict__ q_max, const uint8_t *__restrict__ q_ok,
+                                                      int nq, int strict, const float *__restrict__ sigma2, int cap,
+                                                      int32_t *__restrict__ counts, uint32_t *__restrict__ out,
+                                                      int32_t *__restrict__ pool_total, int32_t *__restrict__ offs)
+{
+    // pool_total == NULL: list q lives at out + q * cap.  Otherwise the lists are packed back to back into out[0 .. cap):
+    // a first sweep counts, the wave reserves its block with one atomic (offs[q]), a second sweep writes.
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    if (!q_ok[q]) { if (lane == 0) { counts[q] = -1; if (offs) offs[q] = 0; } return; }
+    const float x = q_xy[2 * q], y = q_xy[2 * q + 1], r = q_r[q];
+    const int min_level = q_min[q], max_level = q_max[q];
+    const int minCX = max(0, orb_floor_f(x - r) / ORBM_GRID), maxCX = min(cols - 1, orb_floor_f(x + r) / ORBM_GRID);
+    const int minCY = max(0, orb_floor_f(y - r) / ORBM_GRID), maxCY = min(rows - 1, orb_floor_f(y + r) / ORBM_GRID);
+    int pos = 0;
+    size_t base = (size_t)q * cap;
+    int limit = cap;
+    if (minCX <= maxCX && minCY <= maxCY) {
+        const Desc256 dq = load_desc(q_desc + (size_t)q * 32);
+        const bool check = min_level > 0 || max_level >= 0; // beCheckLevel (Frame.cpp:107)
+        for (int sweep = pool_total ? 0 : 1; sweep < 2; ++sweep) {
+        if (sweep == 1 && pool_total) {
+            int off = 0;
+            if (lane == 0) off = atomicAdd(pool_total, pos);
+            off = __builtin_amdgcn_readfirstlane(off);
+            if (lane == 0) offs[q] = off;
+            base = (size_t)off;
+            limit = off + pos <= cap ? pos : 0; // a pool that is too small: nothing is written, the host sees total > cap
+            if (pos == 0) break;
+            pos = 0;
+        }
+        for (int cx = minCX; cx <= maxCX; ++cx) {
+            const int b = cell_start[cx * rows + minCY], e = cell_start[cx * rows + maxCY + 1];
+            for (int t0 = b; t0 < e; t0 += 64) {
+                const int t = t0 + lane;
+                bool hit = false;
+                int j = 0;
+                if (t < e) {
+                    j = cell_items[t];
+                    const orbx_kp kp = kps[j];
+                    hit = true;
+                    if (check) {
+                        if (kp.octave < min_level) hit = false;
+                        if (max_level >= 0 && kp.octave > max_level) hit = false;
+                    }
+                    const float ax = fabsf(kp.x - x), ay = fabsf(kp.y - y);
+                    hit = hit && (strict ? (ax < r && ay < r) : (ax <= r && ay <= r));
+                    if (hit && sigma2) {
+                        const float e2 = (x - kp.x) * (x - kp.x) + (y - kp.y) * (y - kp.y);
+                        if ((double)e2 > 5.991 * (double)sigma2[kp.octave]) hit = false;
+                    }
+                }
+                const unsigned long long mk = __ballot(hit);
+                const int p = pos + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                if (sweep == 1 && hit && p < limit)
+                    out[base + p] = ((uint32_t)ham256(dq, load_desc(desc + (size_t)j * 32)) << 22) | (uint32_t)j;
+                pos += (int)__popcll(mk);
+            }
+        }
+        }
+    } else if (pool_total && lane == 0) offs[q] = 0;
+    if (lane == 0) counts[q] = pos;
+}
+
+// ---------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------
 struct DevBuf {
@@ -468,10 +610,30 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// pinned host staging: one copy in, one copy out per call of a window search
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = std::max(bytes + bytes / 2, (size_t)1 << 16);
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct orbm_ctx {
     int device;
     hipStream_t stream;
     DevBuf a, b, out, q_idx, c_begin, c_len, out_begin, c_idx, row_ok, col_ok, bidx, bbest, bsecond;
+    DevBuf w_in, w_out, w_grid; // window searches: staged inputs, lists, CSR grid + scratch
+    PinBuf h_in, h_out;
+    int window_on_device = 1;   // ORBM_WINDOW=host keeps the host grid (the parity twin of the device lists)
 };
 
 extern "C" int orbm_create(int device, orbm_t **out)
@@ -489,6 +651,10 @@ extern "C" int orbm_create(int device, orbm_t **out)
         delete c;
         return orbx_set_error(ORBX_E_NO_DEVICE, "stream creation failed");
     }
+    {
+        const char *e = getenv("ORBM_WINDOW");
+        c->window_on_device = !(e && strcmp(e, "host") == 0);
+    }
     *out = c;
     return ORBX_OK;
 }
@@ -499,8 +665,9 @@ extern "C" void orbm_destroy(orbm_t *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->a, &c->b, &c->out, &c->q_idx, &c->c_begin, &c->c_len, &c->out_begin, &c->c_idx,
-                      &c->row_ok, &c->col_ok, &c->bidx, &c->bbest, &c->bsecond};
+                      &c->row_ok, &c->col_ok, &c->bidx, &c->bbest, &c->bsecond, &c->w_in, &c->w_out, &c->w_grid};
     for (DevBuf *d : bufs) d->release();
+    c->h_in.release(); c->h_out.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -978,96 +1145,8 @@ extern "C" int orbm_search_for_triangulation(orbm_t *c, int check_orientation, c
     return ORBX_OK;
 }
 
-extern "C" int orbm_search_for_initialization(orbm_t *c, float nn_ratio, int check_orientation, const void *kps1v,
-                                              const uint8_t *desc1, int n1, const void *kps2v, const uint8_t *desc2,
-                                              int n2, int img_w, int img_h, float *pre, int32_t *matches12,
-                                              int window_size, int *n_matches)
-{
-    if (!c || !kps1v || !kps2v || !desc1 || !desc2 || !pre || !matches12 || !n_matches)
-        return orbx_set_error(ORBX_E_ARG, "null argument");
-    const orbx_kp *kps1 = (const orbx_kp *)kps1v, *kps2 = (const orbx_kp *)kps2v;
-    *n_matches = 0;
-    for (int i = 0; i < n1; ++i) matches12[i] = -1;
-    if (n1 <= 0 || n2 <= 0) return ORBX_OK;
-    // Frame grid of frame2 (Frame.cpp:33-51): 40-px cells, column-major vector of vectors
-    const int G = 40;
-    const int gcols = img_w % G == 0 ? img_w / G : img_w / G + 1, grows = img_h % G == 0 ? img_h / G : img_h / G + 1;
-    std::vector<std::vector<int>> grid((size_t)gcols * grows);
-    for (int i = 0; i < n2; ++i) {
-        const int x = orb_floor_f(kps2[i].x), y = orb_floor_f(kps2[i].y);
-        if (x < 0 || x >= img_w || y < 0 || y >= img_h) continue;
-        grid[(size_t)(x / G) * grows + y / G].push_back(i);
-    }
-    // window candidates per level-0 feature of frame1 (:46-54, Frame.cpp:97-127)
-    std::vector<int32_t> q_idx, c_begin, c_len, out_begin, c_idx;
-    const float r = (float)window_size;
-    for (int idx1 = 0; idx1 < n1; ++idx1) {
-        const int level1 = kps1[idx1].octave;
-        if (level1 > 0) continue;
-        const float x = pre[2 * idx1], y = pre[2 * idx1 + 1];
-        const int minCX = std::max(0, orb_floor_f(x - r) / G), maxCX = std::min(gcols - 1, orb_floor_f(x + r) / G);
-        if (minCX > maxCX) continue;
-        const int minCY = std::max(0, orb_floor_f(y - r) / G), maxCY = std::min(grows - 1, orb_floor_f(y + r) / G);
-        if (minCY > maxCY) continue;
-        const bool check = level1 > 0 || level1 >= 0; // beCheckLevel with minLevel = maxLevel = level1
-        const size_t begin = c_idx.size();
-        for (int cx = minCX; cx <= maxCX; ++cx)
-            for (int cy = minCY; cy <= maxCY; ++cy)
-                for (int j : grid[(size_t)cx * grows + cy]) {
-                    if (check) {
-                        if (kps2[j].octave < level1) continue;
-                        if (level1 >= 0 && kps2[j].octave > level1) continue;
-                    }
-                    if (fabsf(kps2[j].x - x) <= r && fabsf(kps2[j].y - y) <= r) c_idx.push_back(j);
-                }
-        if (c_idx.size() == begin) continue;
-        q_idx.push_back(idx1); c_begin.push_back((int32_t)begin); c_len.push_back((int32_t)(c_idx.size() - begin));
-        out_begin.push_back((int32_t)begin);
-    }
-    std::vector<uint16_t> dist;
-    int rc = hamming_lists(c, desc1, n1, desc2, n2, q_idx, c_begin, c_len, out_begin, c_idx.data(), c_idx.size(),
-                           c_idx.size(), dist);
-    if (rc) return rc;
-    std::vector<int> matches21(n2, -1), matchedDist(n2, INT_MAX);
-    RotHist rh;
-    int num = 0;
-    for (size_t k = 0; k < q_idx.size(); ++k) {
-        const int idx1 = q_idx[k];
-        int bestDist = INT_MAX - 1, bestDist2 = INT_MAX, bestIdx2 = -1;
-        for (int t = 0; t < c_len[k]; ++t) {
-            const int idx2 = c_idx[c_begin[k] + t];
-            const int d = dist[out_begin[k] + t];
-            if (matchedDist[idx2] <= d) continue; // :63
-            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = idx2; }
-            else if (d < bestDist2) bestDist2 = d;
-        }
-        if (bestDist <= ORBM_TH_LOW && bestDist < orb_round_f((float)bestDist2 * nn_ratio)) { // :74
-            if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; --num; }
-            matches12[idx1] = bestIdx2;
-            matches21[bestIdx2] = idx1;
-            matchedDist[bestIdx2] = bestDist;
-            ++num;
-            if (check_orientation) rh.add(kps1[idx1].angle, kps2[bestIdx2].angle, idx1);
-        }
-    }
-    if (check_orientation) {
-        int i1, i2, i3;
-        rh.keep3(&i1, &i2, &i3);
-        for (int i = 0; i < ORBM_HISTO_LENGTH; ++i) {
-            if (i == i1 || i == i2 || i == i3) continue;
-            for (int idx1 : rh.bins[i])
-                if (matches12[idx1] >= 0) { matches12[idx1] = -1; --num; }
-        }
-    }
-    for (int idx1 = 0; idx1 < n1; ++idx1)
-        if (matches12[idx1] >= 0) { pre[2 * idx1] = kps2[matches12[idx1]].x; pre[2 * idx1 + 1] = kps2[matches12[idx1]].y; }
-    *n_matches = num;
-    return ORBX_OK;
-}
-
-
 // ---------------------------------------------------------------------------------------------
-// window searches: Frame grid + getFeaturesInArea on the host, distances on the device, greedy pass on the host
+// window searches: Frame grid + getFeaturesInArea and the distances on the device (host twin kept), greedy pass on the host
 // ---------------------------------------------------------------------------------------------
 namespace {
 // Frame::grid (Frame.cpp:33-51): 40-px cells, grid[x][y] vectors filled in key-point order
@@ -1113,6 +1192,175 @@ struct WindowQueries {
 };
 } // namespace
 
+// The candidate lists of a window search, either way: q.q_idx = queries with a non-empty window, their lists in
+// q.c_idx[q.c_begin[k] .. + q.c_len[k]) in the reference's getFeaturesInArea order, dist[] aligned with q.c_idx.
+//   device path (default): ONE pinned staging copy in, grid build + one wave per query on the device, ONE copy out;
+//   host path (ORBM_WINDOW=host, or a window longer than `cap`): FrameGrid::area on the host + k_hamming_lists.
+static int window_candidates(orbm_ctx *c, bool strict, const float *sigma2, int n_sigma, int cap, const uint8_t *q_desc,
+                             const float *q_xy, const float *q_radius, const int32_t *q_min, const int32_t *q_max,
+                             const uint8_t *q_ok, int nq, const orbx_kp *kps2, const uint8_t *desc2, int n2, int img_w,
+                             int img_h, WindowQueries &q, std::vector<uint16_t> &dist)
+{
+    q.q_idx.clear(); q.c_begin.clear(); q.c_len.clear(); q.c_idx.clear();
+    dist.clear();
+    if (nq <= 0 || n2 <= 0) return ORBX_OK;
+    const int G = ORBM_GRID;
+    const int cols = img_w % G == 0 ? img_w / G : img_w / G + 1, rows = img_h % G == 0 ? img_h / G : img_h / G + 1;
+    const int nc = cols * rows;
+    bool on_device = c->window_on_device && nc > 0 && (size_t)(2 * nc + 1) * 4 <= 60000 && n2 < (1 << 22);
+    if (on_device) {
+        M_TRY(hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        size_t o = 0;
+        const size_t o_kps = o; o = al(o + (size_t)n2 * sizeof(orbx_kp));
+        const size_t o_desc = o; o = al(o + (size_t)n2 * 32);
+        const size_t o_qd = o; o = al(o + (size_t)nq * 32);
+        const size_t o_xy = o; o = al(o + (size_t)nq * 8);
+        const size_t o_r = o; o = al(o + (size_t)nq * 4);
+        const size_t o_min = o; o = al(o + (size_t)nq * 4);
+        const size_t o_max = o; o = al(o + (size_t)nq * 4);
+        const size_t o_ok = o; o = al(o + (size_t)nq);
+        const size_t o_s2 = o; o = al(o + (size_t)std::max(n_sigma, 1) * 4);
+        M_TRY(c->h_in.need(o));
+        M_TRY(c->w_in.need(o));
+        uint8_t *hp = (uint8_t *)c->h_in.p;
+        memcpy(hp + o_kps, kps2, (size_t)n2 * sizeof(orbx_kp));
+        memcpy(hp + o_desc, desc2, (size_t)n2 * 32);
+        memcpy(hp + o_qd, q_desc, (size_t)nq * 32);
+        memcpy(hp + o_xy, q_xy, (size_t)nq * 8);
+        memcpy(hp + o_r, q_radius, (size_t)nq * 4);
+        memcpy(hp + o_min, q_min, (size_t)nq * 4);
+        memcpy(hp + o_max, q_max, (size_t)nq * 4);
+        memcpy(hp + o_ok, q_ok, (size_t)nq);
+        if (sigma2) memcpy(hp + o_s2, sigma2, (size_t)n_sigma * 4);
+        M_TRY(hipMemcpyAsync(c->w_in.p, hp, o, hipMemcpyHostToDevice, s));
+        const uint8_t *dp = (const uint8_t *)c->w_in.p;
+        const size_t g_bytes = ((size_t)nc + 1 + 3 * (size_t)n2) * 4;
+        M_TRY(c->w_grid.need(g_bytes));
+        int32_t *cell_start = (int32_t *)c->w_grid.p, *cell_items = cell_start + nc + 1, *cell_of = cell_items + n2, *tmp = cell_of + n2;
+        // device output: [total, pad x3][counts nq][offs nq][pool]; the lists are packed, `cap` entries per query on average
+        const size_t pool_cap = (size_t)nq * cap, head = 16 + (size_t)nq * 8;
+        const size_t first = std::min(pool_cap, (size_t)nq * 12 + 256); // what one copy brings back; the rest only if needed
+        M_TRY(c->w_out.need(head + pool_cap * 4));
+        M_TRY(c->h_out.need(head + pool_cap * 4));
+        int32_t *d_total = (int32_t *)c->w_out.p, *d_counts = d_total + 4, *d_offs = d_counts + nq;
+        uint32_t *d_pool = (uint32_t *)(d_offs + nq);
+        hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(GB_T), (size_t)(2 * nc + 1) * 4, s, (const orbx_kp *)(dp + o_kps), n2, img_w,
+                           img_h, cols, rows, cell_start, cell_items, cell_of, tmp, d_total);
+        hipLaunchKernelGGL(k_window_lists, dim3((nq + 3) / 4), dim3(256), 0, s, (const orbx_kp *)(dp + o_kps), dp + o_desc,
+                           cell_start, cell_items, cols, rows, dp + o_qd, (const float *)(dp + o_xy), (const float *)(dp + o_r),
+                           (const int32_t *)(dp + o_min), (const int32_t *)(dp + o_max), dp + o_ok, nq, strict ? 1 : 0,
+                           sigma2 ? (const float *)(dp + o_s2) : nullptr, (int)std::min(pool_cap, (size_t)INT_MAX), d_counts,
+                           d_pool, d_total, d_offs);
+        M_TRY(hipGetLastError());
+        M_TRY(hipMemcpyAsync(c->h_out.p, c->w_out.p, head + first * 4, hipMemcpyDeviceToHost, s));
+        M_TRY(hipStreamSynchronize(s));
+        const int32_t *h_total = (const int32_t *)c->h_out.p, *counts = h_total + 4, *offs = counts + nq;
+        const uint32_t *pool = (const uint32_t *)(offs + nq);
+        const size_t total = (size_t)std::max(h_total[0], 0);
+        if (total > pool_cap) on_device = false; // windows longer than the pool: redo on the host
+        else if (total > first) {
+            M_TRY(hipMemcpyAsync((uint8_t *)c->h_out.p + head + first * 4, (uint8_t *)c->w_out.p + head + first * 4,
+                                 (total - first) * 4, hipMemcpyDeviceToHost, s));
+            M_TRY(hipStreamSynchronize(s));
+        }
+        if (on_device) {
+            q.c_idx.reserve(total); dist.reserve(total);
+            for (int i = 0; i < nq; ++i) {
+                if (counts[i] <= 0) continue;
+                q.q_idx.push_back(i); q.c_begin.push_back((int32_t)q.c_idx.size()); q.c_len.push_back(counts[i]);
+                const uint32_t *e = pool + offs[i];
+                for (int t = 0; t < counts[i]; ++t) { q.c_idx.push_back((int32_t)(e[t] & 0x3FFFFFu)); dist.push_back((uint16_t)(e[t] >> 22)); }
+            }
+            return ORBX_OK;
+        }
+        q.q_idx.clear(); q.c_begin.clear(); q.c_len.clear(); q.c_idx.clear();
+    }
+    FrameGrid grid(kps2, n2, img_w, img_h);
+    std::vector<int32_t> all;
+    for (int i = 0; i < nq; ++i) {
+        if (!q_ok[i]) continue;
+        const size_t begin = q.c_idx.size();
+        if (!sigma2) grid.area(kps2, q_xy[2 * i], q_xy[2 * i + 1], q_radius[i], q_min[i], q_max[i], q.c_idx, strict);
+        else {
+            all.clear();
+            grid.area(kps2, q_xy[2 * i], q_xy[2 * i + 1], q_radius[i], q_min[i], q_max[i], all, strict);
+            const float px = q_xy[2 * i], py = q_xy[2 * i + 1];
+            for (int32_t j : all) {
+                const float e2 = (px - kps2[j].x) * (px - kps2[j].x) + (py - kps2[j].y) * (py - kps2[j].y);
+                if ((double)e2 > 5.991 * (double)sigma2[kps2[j].octave]) continue; // ORBMatcher.cpp:566-567
+                q.c_idx.push_back(j);
+            }
+        }
+        if (q.c_idx.size() == begin) continue;
+        q.q_idx.push_back(i); q.c_begin.push_back((int32_t)begin); q.c_len.push_back((int32_t)(q.c_idx.size() - begin));
+    }
+    return hamming_lists(c, q_desc, nq, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.c_begin, q.c_idx.data(), q.c_idx.size(),
+                         q.c_idx.size(), dist);
+}
+
+extern "C" int orbm_search_for_initialization(orbm_t *c, float nn_ratio, int check_orientation, const void *kps1v,
+                                              const uint8_t *desc1, int n1, const void *kps2v, const uint8_t *desc2,
+                                              int n2, int img_w, int img_h, float *pre, int32_t *matches12,
+                                              int window_size, int *n_matches)
+{
+    if (!c || !kps1v || !kps2v || !desc1 || !desc2 || !pre || !matches12 || !n_matches)
+        return orbx_set_error(ORBX_E_ARG, "null argument");
+    const orbx_kp *kps1 = (const orbx_kp *)kps1v, *kps2 = (const orbx_kp *)kps2v;
+    *n_matches = 0;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    if (n1 <= 0 || n2 <= 0) return ORBX_OK;
+    // window candidates per level-0 feature of frame1 (:46-54): getFeaturesInArea(prematched, windowSize, level1, level1)
+    // on frame2's grid (Frame.cpp:33-51, :97-127)
+    std::vector<uint8_t> q_ok((size_t)n1);
+    std::vector<int32_t> lv((size_t)n1);
+    std::vector<float> rad((size_t)n1, (float)window_size);
+    for (int idx1 = 0; idx1 < n1; ++idx1) { lv[idx1] = kps1[idx1].octave; q_ok[idx1] = kps1[idx1].octave <= 0; } // :48 `if (level1 > 0) continue`
+    WindowQueries wq;
+    std::vector<uint16_t> dist;
+    int rc = window_candidates(c, false, nullptr, 0, 768, desc1, pre, rad.data(), lv.data(), lv.data(), q_ok.data(), n1, kps2, desc2,
+                               n2, img_w, img_h, wq, dist);
+    const std::vector<int32_t> &q_idx = wq.q_idx, &c_begin = wq.c_begin, &c_len = wq.c_len, &c_idx = wq.c_idx, &out_begin = wq.c_begin;
+    if (rc) return rc;
+    std::vector<int> matches21(n2, -1), matchedDist(n2, INT_MAX);
+    RotHist rh;
+    int num = 0;
+    for (size_t k = 0; k < q_idx.size(); ++k) {
+        const int idx1 = q_idx[k];
+        int bestDist = INT_MAX - 1, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int t = 0; t < c_len[k]; ++t) {
+            const int idx2 = c_idx[c_begin[k] + t];
+            const int d = dist[out_begin[k] + t];
+            if (matchedDist[idx2] <= d) continue; // :63
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = idx2; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        if (bestDist <= ORBM_TH_LOW && bestDist < orb_round_f((float)bestDist2 * nn_ratio)) { // :74
+            if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; --num; }
+            matches12[idx1] = bestIdx2;
+            matches21[bestIdx2] = idx1;
+            matchedDist[bestIdx2] = bestDist;
+            ++num;
+            if (check_orientation) rh.add(kps1[idx1].angle, kps2[bestIdx2].angle, idx1);
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        rh.keep3(&i1, &i2, &i3);
+        for (int i = 0; i < ORBM_HISTO_LENGTH; ++i) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int idx1 : rh.bins[i])
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; --num; }
+        }
+    }
+    for (int idx1 = 0; idx1 < n1; ++idx1)
+        if (matches12[idx1] >= 0) { pre[2 * idx1] = kps2[matches12[idx1]].x; pre[2 * idx1 + 1] = kps2[matches12[idx1]].y; }
+    *n_matches = num;
+    return ORBX_OK;
+}
+
+
 extern "C" int orbm_search_by_projection_frame(orbm_t *c, int check_orientation, const uint8_t *q_desc,
                                                const float *q_xy, const float *q_radius, const int32_t *q_octave,
                                                const float *q_angle, const uint8_t *q_ok, int nq, const void *kps2v,
@@ -1124,18 +1372,12 @@ extern "C" int orbm_search_by_projection_frame(orbm_t *c, int check_orientation,
     *n_matches = 0;
     if (nq <= 0 || n2 <= 0) return ORBX_OK;
     const orbx_kp *kps2 = (const orbx_kp *)kps2v;
-    FrameGrid grid(kps2, n2, img_w, img_h);
     WindowQueries q;
-    for (int i = 0; i < nq; ++i) {
-        if (!q_ok[i]) continue;
-        const size_t begin = q.c_idx.size();
-        grid.area(kps2, q_xy[2 * i], q_xy[2 * i + 1], q_radius[i], q_octave[i] - 1, q_octave[i] + 1, q.c_idx);
-        if (q.c_idx.size() == begin) continue; // :230
-        q.q_idx.push_back(i); q.c_begin.push_back((int32_t)begin); q.c_len.push_back((int32_t)(q.c_idx.size() - begin));
-    }
     std::vector<uint16_t> dist;
-    int rc = hamming_lists(c, q_desc, nq, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.c_begin, q.c_idx.data(), q.c_idx.size(),
-                           q.c_idx.size(), dist);
+    std::vector<int32_t> lmin((size_t)nq), lmax((size_t)nq);
+    for (int i = 0; i < nq; ++i) { lmin[i] = q_octave[i] - 1; lmax[i] = q_octave[i] + 1; } // :226-229
+    int rc = window_candidates(c, false, nullptr, 0, 48, q_desc, q_xy, q_radius, lmin.data(), lmax.data(), q_ok, nq, kps2, desc2,
+                               n2, img_w, img_h, q, dist);
     if (rc) return rc;
     RotHist rh;
     int num = 0;
@@ -1178,18 +1420,15 @@ extern "C" int orbm_search_by_projection_points(orbm_t *c, float nn_ratio, const
     if (counters) counters[0] = counters[1] = counters[2] = 0;
     if (nq <= 0) return ORBX_OK;
     const orbx_kp *kps2 = (const orbx_kp *)kps2v;
-    FrameGrid grid(kps2, std::max(n2, 0), img_w, img_h);
     WindowQueries q;
-    for (int i = 0; i < nq; ++i) {
-        if (!q_ok[i]) { ++n_out; continue; } // :355-358
-        const size_t begin = q.c_idx.size();
-        grid.area(kps2, q_xy[2 * i], q_xy[2 * i + 1], q_radius[i], q_level[i] - 1, q_level[i], q.c_idx);
-        if (q.c_idx.size() == begin) continue; // :371
-        q.q_idx.push_back(i); q.c_begin.push_back((int32_t)begin); q.c_len.push_back((int32_t)(q.c_idx.size() - begin));
-    }
     std::vector<uint16_t> dist;
-    int rc = hamming_lists(c, q_desc, nq, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.c_begin, q.c_idx.data(), q.c_idx.size(),
-                           q.c_idx.size(), dist);
+    std::vector<int32_t> lmin((size_t)nq);
+    for (int i = 0; i < nq; ++i) {
+        if (!q_ok[i]) ++n_out; // :355-358
+        lmin[i] = q_level[i] - 1;  // :367-369
+    }
+    int rc = window_candidates(c, false, nullptr, 0, 48, q_desc, q_xy, q_radius, lmin.data(), q_level, q_ok, nq, kps2, desc2,
+                               std::max(n2, 0), img_w, img_h, q, dist);
     if (rc) return rc;
     int num = 0;
     for (size_t k = 0; k < q.q_idx.size(); ++k) {
@@ -1232,26 +1471,12 @@ extern "C" int orbm_search_fuse(orbm_t *c, const uint8_t *q_desc, const float *q
     const orbx_kp *kps = (const orbx_kp *)kpsv;
     for (int j = 0; j < n; ++j)
         if (kps[j].octave < 0 || kps[j].octave >= n_levels) return orbx_set_error(ORBX_E_ARG, "key-point octave outside the sigma2 table");
-    FrameGrid grid(kps, n, img_w, img_h);
     WindowQueries q;
-    std::vector<int32_t> all;
-    for (int i = 0; i < nq; ++i) {
-        if (!q_ok[i]) continue;
-        all.clear();
-        grid.area(kps, q_xy[2 * i], q_xy[2 * i + 1], q_radius[i], q_level[i] - 1, q_level[i], all, true);
-        const size_t begin = q.c_idx.size();
-        const float px = q_xy[2 * i], py = q_xy[2 * i + 1];
-        for (int32_t j : all) {
-            const float e2 = (px - kps[j].x) * (px - kps[j].x) + (py - kps[j].y) * (py - kps[j].y);
-            if ((double)e2 > 5.991 * (double)sigma2[kps[j].octave]) continue; // :566-567
-            q.c_idx.push_back(j);
-        }
-        if (q.c_idx.size() == begin) continue;
-        q.q_idx.push_back(i); q.c_begin.push_back((int32_t)begin); q.c_len.push_back((int32_t)(q.c_idx.size() - begin));
-    }
     std::vector<uint16_t> dist;
-    int rc = hamming_lists(c, q_desc, nq, desc, n, q.q_idx, q.c_begin, q.c_len, q.c_begin, q.c_idx.data(), q.c_idx.size(),
-                           q.c_idx.size(), dist);
+    std::vector<int32_t> lmin((size_t)nq);
+    for (int i = 0; i < nq; ++i) lmin[i] = q_level[i] - 1; // :556
+    int rc = window_candidates(c, true, sigma2, n_levels, 48, q_desc, q_xy, q_radius, lmin.data(), q_level, q_ok, nq, kps,
+                               desc, n, img_w, img_h, q, dist);
     if (rc) return rc;
     int found = 0;
     for (size_t k = 0; k < q.q_idx.size(); ++k) {
@@ -1264,5 +1489,25 @@ extern "C" int orbm_search_fuse(orbm_t *c, const uint8_t *q_desc, const float *q
         if (bestIdx1 != -1) ++found;
     }
     *n_found = found;
+    return ORBX_OK;
+}
+
+// The window lists of one device-resident frame record (orbx_extract_batch_device -> orbf_frame_post_device): the grid
+// is the CSR orbf built, nothing visits the host.  See include/orbm.h.
+extern "C" int orbm_window_lists_device(orbm_t *c, const void *d_kps, const uint8_t *d_desc, const int32_t *d_cell_start,
+                                        const int32_t *d_cell_items, int grid_cols, int grid_rows, const uint8_t *d_q_desc,
+                                        const float *d_q_xy, const float *d_q_radius, const int32_t *d_q_min_level,
+                                        const int32_t *d_q_max_level, const uint8_t *d_q_ok, int nq, int strict,
+                                        const float *d_sigma2, int cap, int32_t *d_counts, uint32_t *d_lists, void *stream)
+{
+    if (!c || !d_kps || !d_desc || !d_cell_start || !d_cell_items || !d_q_desc || !d_q_xy || !d_q_radius || !d_q_min_level ||
+        !d_q_max_level || !d_q_ok || !d_counts || !d_lists || grid_cols < 1 || grid_rows < 1 || cap < 1 || nq < 0)
+        return orbx_set_error(ORBX_E_ARG, "bad argument");
+    if (nq == 0) return ORBX_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipLaunchKernelGGL(k_window_lists, dim3((nq + 3) / 4), dim3(256), 0, s, (const orbx_kp *)d_kps, d_desc, d_cell_start,
+                       d_cell_items, grid_cols, grid_rows, d_q_desc, d_q_xy, d_q_radius, d_q_min_level, d_q_max_level, d_q_ok,
+                       nq, strict ? 1 : 0, d_sigma2, cap, d_counts, d_lists, nullptr, nullptr);
+    M_TRY(hipGetLastError());
     return ORBX_OK;
 }

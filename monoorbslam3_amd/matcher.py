@@ -51,6 +51,7 @@ def _mlib():
             "orbm_search_by_projection_points": (i32, [vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp,
                                                        C.POINTER(i32), vp]),
             "orbm_search_fuse": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp, C.POINTER(i32)]),
+            "orbm_window_lists_device": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]),
             "orbm_distinctive_descriptors": (i32, [vp, vp, vp, i32, vp]),
             "orbm_distinctive_descriptors_device": (i32, [vp, vp, vp, i32, vp, vp]),
             "orbm_three_maxima": (None, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),

@@ -389,3 +389,121 @@ def test_search_fuse(oracle_mod):
     # without candidates / without key points
     e_bi, e_bd, e_n = m.SearchFuse(q_desc[:3], q_xy[:3], q_radius[:3], q_level[:3], np.zeros(3, np.uint8), k1, d1, w, h, sigma2)
     assert e_n == 0 and (e_bi == -1).all()
+
+
+def test_window_lists_on_a_device_resident_frame_record(oracle_mod):
+    """extract -> orbf frame record (undistorted key points + CSR grid) -> orbm_window_lists_device, all on
+    device buffers; every query's list = the oracle's getFeaturesInArea (Frame and KeyFrame variants, level rules, the
+    fuse's chi-square gate) in the same order, with the Hamming distance of every hit."""
+    import ctypes as C
+    import torch
+    from monoorbslam3_amd import _lib
+    from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
+    from monoorbslam3_amd.frame import FramePost
+    from monoorbslam3_amd.matcher import MatcherHandle, _mlib
+    dev = torch.device("cuda", 0)
+    w, h, nf = 752, 480, 1500
+    img = torch.from_numpy(synth.make_frames(1, w, h, seed=77)).to(dev)
+    ex = ORBExtractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    cap = ex.max_keypoints(w, h)
+    d_kp = torch.zeros((1, cap, 28), dtype=torch.uint8, device=dev)
+    d_un = torch.zeros((1, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ex.extract_batch_device(img.data_ptr(), 1, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), st)
+    fp = FramePost(w, h, 458.654, 457.296, 367.215, 248.375, dist=(-0.2834, 0.0739, 1.9e-4, 1.8e-5))
+    d_start = torch.zeros((1, fp.n_cells + 1), dtype=torch.int32, device=dev)
+    d_items = torch.zeros((1, cap), dtype=torch.int32, device=dev)
+    fp.post_device(1, d_kp.data_ptr(), d_n.data_ptr(), cap, d_un.data_ptr(), d_start.data_ptr(), d_items.data_ptr(), st)
+    torch.cuda.synchronize()
+    n = int(d_n[0])
+    kps = np.frombuffer(d_un[0, :n].cpu().numpy().tobytes(), KP_DTYPE)
+    desc = d_desc[0, :n].cpu().numpy()
+    cols, rows = fp.cols, fp.rows
+    rng = np.random.RandomState(3)
+    nq = 700
+    pick = rng.randint(0, n, nq)
+    q_xy = np.stack([kps["x"][pick] + rng.normal(0, 6, nq), kps["y"][pick] + rng.normal(0, 6, nq)], 1).astype(np.float32)
+    q_xy[:8] = [(-30, 50), (w + 20, 100), (100, -70), (100, h + 55), (0, 0), (w - 1, h - 1), (2000, 2000), (-500, -500)]
+    q_r = rng.choice([4.0, 9.5, 17.0, 40.0, 100.0], nq).astype(np.float32)
+    q_r[8] = np.float32(abs(kps["x"][pick[8]] - q_xy[8, 0]))       # a key point exactly on the window edge
+    q_min = rng.randint(-1, 7, nq).astype(np.int32)
+    q_max = np.where(rng.uniform(size=nq) < 0.2, -1, q_min + rng.randint(0, 3, nq)).astype(np.int32)
+    q_ok = (rng.uniform(size=nq) > 0.1).astype(np.uint8)
+    q_ok[:9] = 1
+    q_desc = (desc[pick] ^ np.packbits(rng.uniform(size=(nq, 256)) < 0.05, axis=1, bitorder="little")).astype(np.uint8)
+    sigma2 = ((np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    dq, dxy, dr, dmin, dmax, dok, ds2 = t(q_desc), t(q_xy), t(q_r), t(q_min), t(q_max), t(q_ok), t(sigma2)
+    mh = MatcherHandle(device=0)
+    L = _mlib()
+    LCAP = 2048
+    for strict, gate in ((0, False), (1, False), (1, True)):
+        d_cnt = torch.full((nq,), -9, dtype=torch.int32, device=dev)
+        d_lst = torch.zeros((nq, LCAP), dtype=torch.int32, device=dev)
+        _lib.check(L.orbm_window_lists_device(mh._h, d_un.data_ptr(), d_desc.data_ptr(), d_start.data_ptr(), d_items.data_ptr(),
+                                              cols, rows, dq.data_ptr(), dxy.data_ptr(), dr.data_ptr(), dmin.data_ptr(),
+                                              dmax.data_ptr(), dok.data_ptr(), nq, strict, ds2.data_ptr() if gate else None,
+                                              LCAP, d_cnt.data_ptr(), d_lst.data_ptr(), st))
+        torch.cuda.synchronize()
+        cnt, lst = d_cnt.cpu().numpy(), d_lst.cpu().numpy().view(np.uint32)
+        total = 0
+        for i in range(nq):
+            if not q_ok[i]:
+                assert cnt[i] == -1
+                continue
+            ref = oracle_mod.features_in_area(kps, w, h, float(q_xy[i, 0]), float(q_xy[i, 1]), float(q_r[i]), int(q_min[i]),
+                                              int(q_max[i]))
+            if strict:  # KeyFrame.cpp:204
+                ref = [j for j in ref if abs(kps["x"][j] - q_xy[i, 0]) < q_r[i] and abs(kps["y"][j] - q_xy[i, 1]) < q_r[i]]
+            if gate:    # ORBMatcher.cpp:566-567
+                e2 = [np.float32(np.float32(q_xy[i, 0] - kps["x"][j]) * np.float32(q_xy[i, 0] - kps["x"][j])) +
+                      np.float32(np.float32(q_xy[i, 1] - kps["y"][j]) * np.float32(q_xy[i, 1] - kps["y"][j])) for j in ref]
+                ref = [j for j, e in zip(ref, e2) if not float(np.float32(e)) > 5.991 * float(sigma2[kps["octave"][j]])]
+            got = lst[i, :cnt[i]]
+            assert cnt[i] == len(ref) and (got & 0x3FFFFF).tolist() == [int(j) for j in ref], (strict, gate, i)
+            if len(ref):
+                d = np.unpackbits(desc[np.asarray(ref, int)] ^ q_desc[i], axis=1).sum(1)
+                assert (got >> 22).tolist() == d.tolist()
+            total += len(ref)
+        assert total > (100 if gate else 3000)
+    assert cnt[6] == 0 and cnt[7] == 0
+
+
+def test_window_searches_device_lists_equal_the_host_twin(oracle_mod, monkeypatch):
+    """The four window searches with their candidate lists built on the device (default) and on the host
+    (ORBM_WINDOW=host): identical results, both equal to the oracle's."""
+    from monoorbslam3_amd.matcher import MatcherHandle, ORBMatcher
+    w, h, k1, d1, k2, d2 = _two_views()
+    rng = np.random.RandomState(21)
+    n1, n2 = len(k1), len(k2)
+    dev_h = MatcherHandle()
+    monkeypatch.setenv("ORBM_WINDOW", "host")
+    host_h = MatcherHandle()
+    monkeypatch.delenv("ORBM_WINDOW")
+    q_xy = np.stack([k1["x"] - 6.0 + rng.normal(0, 1.5, n1), k1["y"] - 4.0 + rng.normal(0, 1.5, n1)], axis=1).astype(np.float32)
+    q_ok = (rng.uniform(size=n1) > 0.3).astype(np.uint8)
+    mp0 = np.where(rng.uniform(size=n2) > 0.95, 12345, -1).astype(np.int32)
+    q_level = np.clip(k1["octave"] + rng.randint(0, 2, n1), 0, 7).astype(np.int32)
+    sigma2 = ((np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
+    pre = np.stack([k1["x"], k1["y"]], axis=1)
+    res = []
+    for hd in (dev_h, host_h):
+        m = ORBMatcher(0.9, True, handle=hd)
+        a = m.SearchByProjectionFrame(d1, q_xy, (14.0 * k1["size"]).astype(np.float32), k1["octave"], k1["angle"], q_ok, k2, d2, w, h, mp0)
+        b = m.SearchByProjectionPoints(d1, q_xy, (12.0 * (1.2 ** q_level)).astype(np.float32), q_level, q_ok, k2, d2, w, h, mp0)
+        f = m.SearchFuse(d1, q_xy, (3.0 * (np.float32(1.2) ** q_level)).astype(np.float32), q_level, q_ok, k2, d2, w, h, sigma2)
+        i = m.SearchForInitialization(k1, d1, k2, d2, w, h, pre, 100)
+        res.append((a, b, f, i))
+    for x, y in zip(res[0], res[1]):
+        for u, v in zip(x, y):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+    ref = oracle_mod.search_by_projection_frame(True, d1, q_xy, (14.0 * k1["size"]).astype(np.float32), k1["octave"], k1["angle"], q_ok, k2, d2, w, h, mp0)
+    assert res[0][0][0] == ref[0] and np.array_equal(res[0][0][1], ref[1]) and ref[0] > 100
+    # a window longer than the device list buffer falls back to the host lists and stays exact
+    big = np.full(n1, 400.0, np.float32)
+    m = ORBMatcher(0.9, False, handle=dev_h)
+    got = m.SearchByProjectionFrame(d1[:50], q_xy[:50], big[:50], k1["octave"][:50], k1["angle"][:50], np.ones(50, np.uint8), k2, d2, w, h, mp0)
+    ref = oracle_mod.search_by_projection_frame(False, d1[:50], q_xy[:50], big[:50], k1["octave"][:50], k1["angle"][:50], np.ones(50, np.uint8), k2, d2, w, h, mp0)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
