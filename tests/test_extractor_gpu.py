@@ -48,7 +48,9 @@ def _check_frame(ex, orc, img, kps, desc, frame=0, stages=True):
 # 6000 features: per-level quotas too large for the LDS-resident quadtree -> global-scratch kernel
 @pytest.mark.parametrize("w,h,nf", [(1242, 375, 2000), (752, 480, 1000), (640, 200, 500), (1242, 375, 6000),
                                     (1242, 375, 4000)])
-def test_single_frame_all_stages(oracle_mod, w, h, nf):
+@pytest.mark.parametrize("variant", ["3", "1"])
+def test_single_frame_all_stages(oracle_mod, monkeypatch, w, h, nf, variant):
+    monkeypatch.setenv("ORBX_FAST_VARIANT", variant)  # both FAST kernels: per strip (batches) and per cell (few frames)
     ex, orc = _mk(oracle_mod, nf, w, h)
     img = synth.make_frames(1, w, h, seed=synth.DEFAULT_SEED + w)[0]
     kps, desc = ex(img)
@@ -156,11 +158,13 @@ def test_other_constructor_arguments(oracle_mod, nf, sf, levels, ini, mn):
 
 @pytest.mark.parametrize("ini,mn,kind", [(5, 2, "noise"), (2, 1, "noise"), (2, 1, "scene"), (3, 3, "noise"), (40, 1, "scene"),
                                          (254, 200, "noise")])
-def test_fast_dense_corners_and_tiny_thresholds(oracle_mod, ini, mn, kind):
+@pytest.mark.parametrize("variant", ["3", "1"])  # 3 = one wave per strip of cells (batches), 1 = one wave per cell (few frames)
+def test_fast_dense_corners_and_tiny_thresholds(oracle_mod, monkeypatch, ini, mn, kind, variant):
     """The FAST kernel's rare paths: i.i.d. noise at low thresholds makes nearly every pixel a corner (more corners per
     strip than its LDS list holds -> the NMS sweeps the score map), thresholds 0..2 make the 6-bit arc test pass pixels
     in both polarities, thresholds near 255 pass nothing.  Candidates, key points and descriptors stay the oracle's."""
     w, h, nf = 500, 300, 1500
+    monkeypatch.setenv("ORBX_FAST_VARIANT", variant)  # read when the extractor is created
     ex, orc = _mk(oracle_mod, nf, w, h, ini=ini, mn=mn)
     if kind == "noise":
         img = np.random.RandomState(ini * 31 + mn).randint(0, 256, (h, w)).astype(np.uint8)
