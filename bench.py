@@ -373,6 +373,22 @@ def main():
         match_ms += ev_m0.elapsed_time(ev_m1) / n_prof
     ex.set_stage_timing(False)
     counts = d_n[0].cpu().numpy()
+    # ---- the timed match is checked, not only timed: a sample of frame 0's rows against frame 1 by a numpy popcount scan
+    match_check = None
+    if B > 1 and not args.no_match:
+        n0, n1 = int(counts[0]), int(counts[1])
+        a0 = d_desc[0][0, :n0].cpu().numpy()
+        b1 = d_desc[0][1, :n1].cpu().numpy()
+        rows = np.random.RandomState(7).choice(n0, size=min(48, n0), replace=False)
+        dm = np.unpackbits(a0[rows][:, None, :] ^ b1[None, :, :], axis=2).sum(axis=2)
+        want_idx = dm.argmin(axis=1)
+        part = np.partition(dm, 1, axis=1)
+        got_idx = d_bidx[0][0, :n0].cpu().numpy()[rows]
+        got_bd = d_bd[0][0, :n0].cpu().numpy().view(np.uint16)[rows]
+        got_sd = d_sd[0][0, :n0].cpu().numpy().view(np.uint16)[rows]
+        ok = bool((got_idx == want_idx).all() and (got_bd == part[:, 0]).all() and (got_sd == part[:, 1]).all())
+        match_check = {"rows": int(len(rows)), "equal_to_numpy_popcount_scan": ok}
+        assert ok, "the best/second-best match of the timed step differs from a numpy popcount scan"
     kp_mean = float(counts.mean())
     alg, P = algorithmic_bytes(ex, W, H, int(round(kp_mean)))
     stage_gbs = {k: (alg[k] * B / (acc[k] * 1e-3) / 1e9 if acc[k] > 0 and alg[k] > 0 else None) for k in acc}
@@ -460,6 +476,7 @@ def main():
                     if rec else None),
         "stages_ms": {k: round(v, 4) for k, v in acc.items()},
         "match_ms": round(match_ms, 4),
+        "match_check": match_check,
         "stage_algorithmic_GBps": {k: (round(v, 1) if v else None) for k, v in stage_gbs.items()},
         "stages_ms_note": "HIP events around each stage with every kernel on ONE stream (orbx_set_stage_timing), extra untimed "
                           "steps; the timed steps overlap FAST / blur / match on three streams, so the stages sum to more "
