@@ -1687,75 +1687,112 @@ void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLev
 #define OR_LANES 8                 // lanes per keypoint
 #define OR_KP (256 / OR_LANES)     // keypoints per workgroup
 #define OR_TASKS (64 / OR_LANES)   // (row, half) tasks per lane
+struct OrientLevels { // what k_orient needs of every level, passed by value so that it sits in the kernel-argument segment
+    int kp_off[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS];
+    unsigned long long raw_off[ORBX_MAX_LEVELS];
+};
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, size_t l0_fs, int l0_pitch,
-                                                const OrbxLevels *__restrict__ levels, OrbxBuffers b,
+                                                const OrbxLevels *__restrict__ levels, OrientLevels tab, OrbxBuffers b,
                                                 const int *__restrict__ u_max, int per_frame, int n_frames)
 {
-    __shared__ int s_m[OR_KP][2];
+    // byte masks of the circular patch, one 16-byte row per (row, half) task: they depend on the task only, so they are
+    // built once per workgroup (thread = (task, dword)) instead of per key point
+    __shared__ __align__(16) uint32_t s_mask[64][4];
     int frame, blk;
     if (!xcd_remap(per_frame, n_frames, &frame, &blk)) return;
     const int tid = threadIdx.x, sub = tid & (OR_LANES - 1), grp = tid / OR_LANES;
-    const int L = levels->n_levels;
+    const int L = levels->n_levels, kc = levels->kcap_total;
     const int *cnts = b.sel_count + frame * ORBX_MAX_LEVELS;
     const int slot = blk * OR_KP + grp;
-    bool live = slot < levels->kcap_total;
-    int level = 0;
-    for (int l = 1; l < L; ++l) level += live && slot >= levels->lv[l].kp_off;
-    const OrbxLevel &lv = levels->lv[level];
-    live = live && (slot - lv.kp_off) < cnts[level];
+    // Everything this thread needs before the patch loads is requested at once and without a branch -- the mask-table
+    // entry's u_max, the key-point record (slot clamped), and through the scalar cache the level table and the per-level
+    // counts, from which level, pitch and offset are SELECTED rather than gathered: one memory round trip, not four.
+    const int mt = tid >> 2, mw = tid & 3, mv = min(mt >> 1, 2 * ORBX_HALF_PATCH) - ORBX_HALF_PATCH;
+    const int md_raw = u_max[mv < 0 ? -mv : mv];
+    const uint2 rec = b.sel[(size_t)frame * kc + min(slot, kc - 1)];
+    int level = 0, rpitch = l0_pitch, cnt = cnts[0], kp_off = 0;
+    size_t raw_off = 0;
+#pragma unroll
+    for (int l = 1; l < ORBX_MAX_LEVELS; ++l) { // fixed trip count: the table comes in with the kernel arguments, wide scalar loads
+        const bool ge = l < L && slot >= tab.kp_off[l];
+        level += ge;
+        rpitch = ge ? tab.pitch[l] : rpitch;
+        raw_off = ge ? (size_t)tab.raw_off[l] : raw_off;
+        kp_off = ge ? tab.kp_off[l] : kp_off;
+        cnt = ge ? cnts[l] : cnt;
+    }
+    const bool live = slot < kc && (slot - kp_off) < cnt;
+    {
+        const int d = mt < 2 * (2 * ORBX_HALF_PATCH + 1) ? md_raw : -1;
+        // right half keeps bytes idx <= d (idx = 4w + byte), left half keeps idx >= 16 - d
+        const int n_lo = min(max(d + 1 - 4 * mw, 0), 4);        // kept low bytes (right half)
+        const int n_hi = min(max(4 * mw + 4 - (16 - d), 0), 4); // kept high bytes (left half)
+        const uint32_t m_lo = n_lo >= 4 ? 0xFFFFFFFFu : ((1u << (8 * n_lo)) - 1u);
+        const uint32_t m_hi = n_hi <= 0 ? 0u : (0xFFFFFFFFu << (8 * (4 - n_hi)));
+        s_mask[mt][mw] = (mt & 1) ? m_lo : m_hi;
+    }
+    __syncthreads();
     int m10 = 0, m01 = 0;
     if (live) {
-        const uint2 rec = b.sel[(size_t)frame * levels->kcap_total + slot];
         const int x = rec.x & 0xFFFF, y = rec.x >> 16;
-        const uint8_t *raw = level == 0 ? l0 + (size_t)frame * l0_fs : b.img_arena + (size_t)frame * b.img_frame_stride + lv.raw_off;
-        const int rpitch = level == 0 ? l0_pitch : lv.pitch;
+        const uint8_t *raw = level == 0 ? l0 + (size_t)frame * l0_fs : b.img_arena + (size_t)frame * b.img_frame_stride + raw_off;
         struct __attribute__((packed, aligned(1))) U128 { uint32_t w[4]; };
         U128 q[OR_TASKS];
-        int vv[OR_TASKS], dd[OR_TASKS];
-#pragma unroll
-        for (int k = 0; k < OR_TASKS; ++k) { // task t = sub + OR_LANES*k: row v = t/2 - 15, half = t & 1 (tasks 62, 63 are idle)
-            const int t = sub + OR_LANES * k, v = min(t >> 1, 2 * ORBX_HALF_PATCH) - ORBX_HALF_PATCH;
-            vv[k] = v;
-            dd[k] = t < 2 * (2 * ORBX_HALF_PATCH + 1) ? u_max[v < 0 ? -v : v] : -1;
-            q[k] = *reinterpret_cast<const U128 *>(raw + (size_t)(y + v) * rpitch + x + ((t & 1) ? 0 : -16));
-        }
+        uint4 mk[OR_TASKS];
+        static_assert((OR_LANES & 1) == 0, "a lane's tasks all lie in the same half");
+        const int half = sub & 1; // task t = sub + OR_LANES*k: row v = t/2 - 15, half = t & 1 (tasks 62, 63 are idle: mask 0)
 #pragma unroll
         for (int k = 0; k < OR_TASKS; ++k) {
-            const int half = (sub + OR_LANES * k) & 1, d = dd[k];
-            uint32_t ssum = 0, wsum = 0;
+            const int t = sub + OR_LANES * k, v = min(t >> 1, 2 * ORBX_HALF_PATCH) - ORBX_HALF_PATCH;
+            q[k] = *reinterpret_cast<const U128 *>(raw + (size_t)(y + v) * rpitch + x + (half ? 0 : -16));
+            mk[k] = *reinterpret_cast<const uint4 *>(s_mask[t]);
+        }
+        // u-weights of the 16 bytes: the right half holds u = 0..15, the left half u = -16..-1 (as 16 - idx, negated below)
+        uint32_t wt[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t wr = (uint32_t)(4 * w) | ((uint32_t)(4 * w + 1) << 8) | ((uint32_t)(4 * w + 2) << 16) | ((uint32_t)(4 * w + 3) << 24);
+            const uint32_t wl = (uint32_t)(16 - 4 * w) | ((uint32_t)(15 - 4 * w) << 8) | ((uint32_t)(14 - 4 * w) << 16) | ((uint32_t)(13 - 4 * w) << 24);
+            wt[w] = half ? wr : wl;
+        }
+        uint32_t wsum = 0;
+#pragma unroll
+        for (int k = 0; k < OR_TASKS; ++k) {
+            const int v = min((sub + OR_LANES * k) >> 1, 2 * ORBX_HALF_PATCH) - ORBX_HALF_PATCH;
+            const uint32_t m4[4] = {mk[k].x, mk[k].y, mk[k].z, mk[k].w};
+            uint32_t ssum = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                // right half keeps bytes idx <= d (idx = 4w + byte), left half keeps idx >= 16 - d
-                const int n_lo = min(max(d + 1 - 4 * w, 0), 4);        // kept low bytes (right half)
-                const int n_hi = min(max(4 * w + 4 - (16 - d), 0), 4); // kept high bytes (left half)
-                const uint32_t m_lo = n_lo >= 4 ? 0xFFFFFFFFu : ((1u << (8 * n_lo)) - 1u);
-                const uint32_t m_hi = n_hi <= 0 ? 0u : (0xFFFFFFFFu << (8 * (4 - n_hi)));
-                const uint32_t wd = q[k].w[w] & (half ? m_lo : m_hi);
-                const uint32_t wr = (uint32_t)(4 * w) | ((uint32_t)(4 * w + 1) << 8) | ((uint32_t)(4 * w + 2) << 16) | ((uint32_t)(4 * w + 3) << 24);
-                const uint32_t wl = (uint32_t)(16 - 4 * w) | ((uint32_t)(15 - 4 * w) << 8) | ((uint32_t)(14 - 4 * w) << 16) | ((uint32_t)(13 - 4 * w) << 24);
-                wsum = __builtin_amdgcn_udot4(wd, half ? wr : wl, wsum, false);
+                const uint32_t wd = q[k].w[w] & m4[w];
+                wsum = __builtin_amdgcn_udot4(wd, wt[w], wsum, false);
                 ssum = __builtin_amdgcn_sad_u8(wd, 0u, ssum);
             }
-            m10 += half ? (int)wsum : -(int)wsum;
-            m01 += vv[k] * (int)ssum;
+            m01 += v * (int)ssum;
         }
+        m10 = half ? (int)wsum : -(int)wsum;
     }
 #pragma unroll
     for (int o = OR_LANES / 2; o > 0; o >>= 1) {
         m10 += __shfl_xor(m10, o);
         m01 += __shfl_xor(m01, o);
     }
-    if (sub == 0) { s_m[grp][0] = m10; s_m[grp][1] = m01; }
-    __syncthreads();
-    if (tid < OR_KP) {
-        const int s2 = blk * OR_KP + tid;
-        if (s2 < levels->kcap_total) {
-            const float ang = orb_fast_atan2((float)s_m[tid][1], (float)s_m[tid][0]);
-            float cs, sn;
-            orb_sincos_deg(ang, &cs, &sn);
-            b.kp_ang[(size_t)frame * levels->kcap_total + s2] = make_float4(ang, cs, sn, 0.f);
-        }
-    }
+    // the moments leave as they are; k_angle turns them into (angle, cos, sin) with one thread per key point -- done here
+    // the long double-precision chain ran on one quarter-filled wave per workgroup while the other three waited
+    if (sub == 0 && slot < levels->kcap_total)
+        b.kp_ang[(size_t)frame * levels->kcap_total + slot] = make_float4(__int_as_float(m10), __int_as_float(m01), 0.f, 0.f);
+}
+
+// IC_Angle's last line (reference :41) and the sine / cosine of computeOrbDescriptor (:54), one thread per key-point slot
+__global__ __launch_bounds__(256) void k_angle(const OrbxLevels *__restrict__ levels, OrbxBuffers b, int n_frames)
+{
+    const int kc = levels->kcap_total;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)kc * n_frames) return;
+    const float4 m = b.kp_ang[i];
+    const float ang = orb_fast_atan2((float)__float_as_int(m.y), (float)__float_as_int(m.x));
+    float cs, sn;
+    orb_sincos_deg(ang, &cs, &sn);
+    b.kp_ang[i] = make_float4(ang, cs, sn, 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1899,8 +1936,16 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
                              uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done)
 {
     const int pf_o = (levels.kcap_total + OR_KP - 1) / OR_KP, pf_d = (levels.kcap_total + 4 * DP_K - 1) / (4 * DP_K);
-    hipLaunchKernelGGL(k_orient, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, b,
+    OrientLevels tab;
+    for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
+        tab.kp_off[l] = l < levels.n_levels ? levels.lv[l].kp_off : 0;
+        tab.pitch[l] = l < levels.n_levels ? levels.lv[l].pitch : 0;
+        tab.raw_off[l] = l < levels.n_levels ? (unsigned long long)levels.lv[l].raw_off : 0ull;
+    }
+    hipLaunchKernelGGL(k_orient, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, tab, b,
                        u_max, pf_o, n_frames);
+    hipLaunchKernelGGL(k_angle, dim3((unsigned)(((size_t)levels.kcap_total * n_frames + 255) / 256)), dim3(256), 0, s, d_levels, b,
+                       n_frames);
     if (blur_done) (void)hipStreamWaitEvent(s, blur_done, 0); // the blurred levels come from a side stream
     hipLaunchKernelGGL(k_orient_desc, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, d_levels, b, out_kp,
                        out_desc, cap, out_n, pf_d, n_frames);
