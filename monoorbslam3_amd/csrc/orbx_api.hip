@@ -525,8 +525,8 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     // FAST work units (strips of cells, or single cells for ORBX_FAST_VARIANT=1); both lists are level-major
     // Strips need a few thousand waves in flight to pay (two cells per wave, a long rolling pipeline); a call with a
     // handful of frames is bounded by the longest wave instead, where one short wave per cell finishes sooner
-    // (single 1242x375 frame: 36 us against 50).  Same candidates either way (tests).  ORBX_FAST_VARIANT=1 / 3 force one.
-    const bool strips = c->fast_variant == 3 || (c->fast_variant != 1 && n_frames >= 8);
+    // (single 1242x375 frame: 31 us against 50; 16 frames: 63 against 69; 32 frames: 110 against 97).  Same candidates either way (tests).  ORBX_FAST_VARIANT=1 / 3 force one.
+    const bool strips = c->fast_variant == 3 || (c->fast_variant != 1 && n_frames >= 24);
     const uint16_t *d_units = strips ? c->d_fast_strips : c->d_fast_cells;
     const int n_units = strips ? c->n_fast_strips : c->n_fast_cells;
     const int n_cells0 = strips ? c->n_fast_strips0 : LV.lv[0].n_cols * LV.lv[0].n_rows;
