@@ -376,13 +376,14 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
 //      What passes is a superset of the corners of about 1.15 x their number; those pixels are queued;
 //   4. queued pixels get the exact strength from the raw tile (17 byte gathers, min3/max3 windows), 64 at a time;
 //      corners (S >= T) go to a score map and a list;
-//   5. strict 3x3 NMS from the score map (one empty column between cells, so a neighbour in the next cell reads 0),
-//      ONE returning atomic per strip, keepers to global memory.
+//   5. once the pipeline has drained the score map is written over the tile (one empty column between cells, so a
+//      neighbour in the next cell reads 0), strict 3x3 NMS from it, ONE returning atomic per strip, keepers to global
+//      memory.
 // Stages 2-4 run as a rolling pipeline (a stage fires as soon as 64 entries wait), so their lanes are full whatever
 // the corner density.  A cell left without a keeper is redone at the min threshold (reference :604-607).
 // ---------------------------------------------------------------------------------------------
 #ifndef FS_K
-#define FS_K 2                       // cells per strip (at most)
+#define FS_K 4                       // cells per strip (at most)
 #endif
 #define FS_W (FS_K * ORBX_CELL)      // region columns of a full strip
 #define FS_G ((FS_W + 3) / 4)        // 4-pixel groups of a full strip
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
 #define FS_SP ((FS_W + FS_K + 2 + 3) / 4 * 4) // score-map pitch; score column = region column + cell index + 1
 #define FS_IQ 128                    // item ring (at most 63 left over + 64 new)
 #define FS_CQ 512                    // pixel ring (at most 63 left over + 256 new)
-#define FS_LIST (128 * FS_K)         // scored corners of a pass kept for the NMS sweep; more -> dense sweep
+#define FS_LIST (128 * FS_K)         // corners of a pass (the NMS works from this list); more -> narrow passes
+#define FS_NARROW (FS_LIST / 30 - 2) // columns of a narrow pass: (FS_NARROW + 2) x 30 pixels always fit the list
 struct __attribute__((aligned(8))) FastStrip { // 8-byte aligned: one scalar load per strip
     uint16_t level, cy, cx0, ncells;
 };
@@ -433,7 +435,12 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
                                                    int n_frames)
 {
     __shared__ __align__(16) uint8_t tile[FS_TROWS * FS_TP];
-    __shared__ __align__(16) uint8_t score[32 * FS_SP];
+    // The score map of the NMS lives in the tile's memory: it is built from the pass's corner list once the pipeline has
+    // drained and the pixels are no longer needed (a later pass reloads the tile).  Without a map of its own a wave needs
+    // a third less LDS, which is what lets a strip span more cells at the same occupancy.
+    static_assert(32 * FS_SP <= FS_TROWS * FS_TP, "the score map must fit into the tile");
+    static_assert(FS_NARROW >= 2, "the corner list is too short for a narrow pass");
+    uint8_t *const score = tile;
     __shared__ uint32_t iq[FS_IQ];
     __shared__ uint16_t cq[FS_CQ];
     __shared__ uint32_t list[FS_LIST];
@@ -452,9 +459,8 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
     const int pitch = src.pitch[level];
     const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level] + (size_t)(y0 - 3) * pitch + (x0 - 4);
 
-    for (int i = lane; i < 32 * FS_SP / 16; i += 64) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
     if (lane < FS_K) s_cellkeep[lane] = 0;
-    {
+    auto load_tile = [&]() {
         // tile column tc <-> level x = x0 - 4 + tc; region columns are tc in [4, 4 + Ws); the ring of the last region
         // column ends at tc = Ws + 6.  Lane = (8-byte item tx, row ty mod 4); nine row groups, all requested before the
         // first is stored (row and item clamped instead of branching: surplus lanes repeat the last row / item).  The
@@ -474,7 +480,8 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         for (int k = 0; k < 9; ++k) {
             *reinterpret_cast<unsigned long long *>(&tile[dst[k]]) = v[k];
         }
-    }
+            FS_WAVE_ORDER();
+    };
     __syncthreads();
 
     int iq_head = 0, iq_tail = 0, cq_head = 0, cq_tail = 0, list_n = 0;
@@ -510,12 +517,10 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         const int sc = v - a - 1;
         const bool corner = live && sc >= thr;
         const int c = tc - 4;
-        const int scol = c + ((c * 2185) >> 16) + 1; // c / 30 for c < 150
-        if (corner) score[(r + 1) * FS_SP + scol] = (uint8_t)sc;
         const u64 mk = __ballot(corner);
         const int pos = list_n + wave_rank(mk);
         if (corner && pos < FS_LIST) list[pos] = (uint32_t)r | ((uint32_t)c << 8) | ((uint32_t)sc << 16);
-        list_n += (int)__popcll(mk); // may exceed FS_LIST: the NMS then sweeps the score map instead
+        list_n += (int)__popcll(mk); // may exceed FS_LIST: the pass is then redone in narrow column ranges
     };
     // ---- stage 3: the full 16-point test of `n` queued items on the 6-bit tile, four pixels per operation
     auto stage_arc = [&](int n) {
@@ -572,8 +577,9 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         }
     };
 
-    // One pass = everything up to the keepers of the region columns [col_lo, col_hi) at threshold `thr`.
-    auto run_pass = [&](int col_lo, int col_hi) {
+    // One pass = every corner of the region columns [col_lo, col_hi) at threshold `thr`, and of those with a column in
+    // [out_lo, out_hi) the keepers.  Returns false (nothing written) when the corners do not fit the list.
+    auto run_pass = [&](int col_lo, int col_hi, int out_lo, int out_hi) -> bool {
         const int t6 = min(max((thr + 1) >> 2, 0), 64); // ceil((thr - 2) / 4) for thr >= 0
         Kd = 0x01010101u * (uint32_t)(128 - t6);
         both_possible = t6 == 0;
@@ -618,73 +624,74 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         }
         while (cq_tail > cq_head) { stage_score(min(cq_tail - cq_head, 64)); FS_WAVE_ORDER(); }
 
-        // ---- stage 5: strict 3x3 NMS inside each cell, then the keepers leave
-        auto is_max = [&](int r, int c, int sc) -> bool {
-            const uint8_t *sp = &score[r * FS_SP + c + ((c * 2185) >> 16)]; // (row - 1, column - 1) of the 3 x 3 block
-            return sc > sp[0] && sc > sp[1] && sc > sp[2] && sc > sp[FS_SP] && sc > sp[FS_SP + 2] && sc > sp[2 * FS_SP] &&
-                   sc > sp[2 * FS_SP + 1] && sc > sp[2 * FS_SP + 2];
-        };
-        int n_keep = 0;
-        const bool listed = list_n <= FS_LIST;
-        if (listed) {
-            // keepers are compacted in place: a batch is read before it is written, at positions <= the ones just read
-            for (int i0 = 0; i0 < list_n; i0 += 64) {
-                const int i = min(i0 + lane, list_n - 1);
-                const uint32_t e = list[i];
-                const int r = e & 255, c = (e >> 8) & 255, sc = e >> 16;
-                const bool keep = i0 + lane < list_n && is_max(r, c, sc);
-                if (keep) s_cellkeep[(c * 2185) >> 16] = 1;
-                const u64 mk = __ballot(keep);
-                FS_WAVE_ORDER();
-                if (keep) list[n_keep + wave_rank(mk)] = e;
-                n_keep += (int)__popcll(mk);
-            }
-        } else {
-            // more corners than the list holds (rare): count by sweeping the score map itself
-            const int Wp = col_hi - col_lo, n_scan = ch * Wp;
-            for (int i0 = 0; i0 < n_scan; i0 += 64) {
-                const int i = min(i0 + lane, n_scan - 1), r = i / Wp, c = col_lo + i - r * Wp;
-                const int sc = score[(r + 1) * FS_SP + c + ((c * 2185) >> 16) + 1];
-                const bool keep = i0 + lane < n_scan && sc >= thr && sc > 0 && is_max(r, c, sc);
-                if (keep) s_cellkeep[(c * 2185) >> 16] = 1;
-                n_keep += (int)__popcll(__ballot(keep));
-            }
+        if (list_n > FS_LIST) return false; // more corners than the list holds: the caller redoes the range in narrow pieces
+
+        // ---- stage 5: the score map takes the tile's place (every stage that reads pixels has drained), then the strict
+        // 3x3 NMS inside each cell, and the keepers with a column in [out_lo, out_hi) leave
+        FS_WAVE_ORDER();
+        for (int i = lane; i < 32 * FS_SP / 16; i += 64) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
+        FS_WAVE_ORDER();
+        for (int i = lane; i < list_n; i += 64) {
+            const uint32_t e = list[i];
+            const int r = e & 255, c = (e >> 8) & 255;
+            score[(r + 1) * FS_SP + c + ((c * 2185) >> 16) + 1] = (uint8_t)(e >> 16); // c / 30 = c * 2185 >> 16 for c < 150
         }
-        if (n_keep == 0) return;
+        FS_WAVE_ORDER();
+        int n_keep = 0;
+        // keepers are compacted in place: a batch is read before it is written, at positions <= the ones just read
+        for (int i0 = 0; i0 < list_n; i0 += 64) {
+            const int i = min(i0 + lane, list_n - 1);
+            const uint32_t e = list[i];
+            const int r = e & 255, c = (e >> 8) & 255, sc = e >> 16;
+            const uint8_t *sp = &score[r * FS_SP + c + ((c * 2185) >> 16)]; // (row - 1, column - 1) of the 3 x 3 block
+            const bool keep = i0 + lane < list_n && c >= out_lo && c < out_hi && sc > sp[0] && sc > sp[1] && sc > sp[2] &&
+                              sc > sp[FS_SP] && sc > sp[FS_SP + 2] && sc > sp[2 * FS_SP] && sc > sp[2 * FS_SP + 1] &&
+                              sc > sp[2 * FS_SP + 2];
+            if (keep) s_cellkeep[(c * 2185) >> 16] = 1;
+            const u64 mk = __ballot(keep);
+            FS_WAVE_ORDER();
+            if (keep) list[n_keep + wave_rank(mk)] = e;
+            n_keep += (int)__popcll(mk);
+        }
+        if (n_keep == 0) return true;
         int base = 0;
         if (lane == 0) base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], n_keep);
         base = __builtin_amdgcn_readfirstlane(base);
         u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + base;
         const uint32_t xb = st.cx0 * ORBX_CELL, yb = st.cy * ORBX_CELL;
-        if (listed) {
-            FS_WAVE_ORDER();
-            for (int i = lane; i < n_keep; i += 64) {
-                const uint32_t e = list[i];
-                out[i] = (u64)((xb + ((e >> 8) & 255)) | ((yb + (e & 255)) << 16)) | ((u64)(e >> 16) << 32);
-            }
-        } else {
-            const int Wp = col_hi - col_lo, n_scan = ch * Wp;
-            int w = 0;
-            for (int i0 = 0; i0 < n_scan; i0 += 64) {
-                const int i = min(i0 + lane, n_scan - 1), r = i / Wp, c = col_lo + i - r * Wp;
-                const int sc = score[(r + 1) * FS_SP + c + ((c * 2185) >> 16) + 1];
-                const bool keep = i0 + lane < n_scan && sc >= thr && sc > 0 && is_max(r, c, sc);
-                const u64 mk = __ballot(keep);
-                if (keep) out[w + wave_rank(mk)] = (u64)((xb + c) | ((yb + r) << 16)) | ((u64)(uint32_t)sc << 32);
-                w += (int)__popcll(mk);
-            }
+        FS_WAVE_ORDER();
+        for (int i = lane; i < n_keep; i += 64) {
+            const uint32_t e = list[i];
+            out[i] = (u64)((xb + ((e >> 8) & 255)) | ((yb + (e & 255)) << 16)) | ((u64)(e >> 16) << 32);
         }
+        return true;
     };
-
+    // Work list of the strip, one call site for the pass: the whole strip at the ini threshold; then (reference :604-607)
+    // every cell left without a keeper again at the min threshold.  A pass leaves the score map where the pixels were, so
+    // each one starts by (re)loading the tile.  A range with more corners than the list holds (noise at a low threshold)
+    // is redone in ranges of FS_NARROW columns, each computed with one more column either side so that the 3x3
+    // neighbourhoods of its own columns are complete.
     thr = levels->ini_th;
-    run_pass(0, Ws);
-    __syncthreads();
-    // reference :604-607: a cell without a keeper at the ini threshold is redone at the min threshold
-    thr = levels->min_th;
-    for (int k = 0; k * ORBX_CELL < Ws; ++k) {
-        if (s_cellkeep[k]) continue;
-        run_pass(k * ORBX_CELL, min((k + 1) * ORBX_CELL, Ws));
-        __syncthreads();
+    int lo = 0, hi = Ws, cell = -1, narrow = -1; // narrow >= 0: first column of the next narrow range of [lo, hi)
+    bool retry = false;
+    for (;;) {
+        int clo = lo, chi = hi, olo = lo, ohi = hi;
+        if (narrow >= 0) {
+            olo = narrow; ohi = min(narrow + FS_NARROW, hi);
+            clo = max(olo - 1, 0); chi = min(ohi + 1, Ws);
+        }
+        load_tile();
+        if (!run_pass(clo, chi, olo, ohi)) { narrow = lo; continue; } // cannot happen for a narrow range
+        if (narrow >= 0) {
+            narrow += FS_NARROW;
+            if (narrow < hi) continue;
+            narrow = -1;
+        }
+        FS_WAVE_ORDER();
+        if (!retry) { retry = true; thr = levels->min_th; }
+        do ++cell; while (cell * ORBX_CELL < Ws && __builtin_amdgcn_readfirstlane(s_cellkeep[min(cell, FS_K - 1)]));
+        if (cell * ORBX_CELL >= Ws) break;
+        lo = cell * ORBX_CELL; hi = min(lo + ORBX_CELL, Ws);
     }
 }
 
