@@ -51,6 +51,10 @@ struct orbx_ctx {
     uint16_t *d_fast_strips; int n_fast_strips, n_fast_strips0; // strips of all levels / of level 0
     int fast_variant;                                           // 2 = strips (default), 1 = one wave per cell
     uint16_t *d_blur_tiles; int n_blur_tiles;
+    // the Gaussian on the matrix pipe: strip list, band tables, per-level record; levels [0, blur_mfma_levels)
+    uint16_t *d_blur_strips; uint8_t *d_band_h, *d_band_v;
+    BlurMfmaLevels blur_tab; int blur_strips_before[ORBX_MAX_LEVELS + 1]; int blur_mfma_levels;
+    int blur_mfma;                                              // ORBX_BLUR=valu switches it off
     uint8_t *d_l0_stage; size_t l0_stage_fs;
     orbx_kp *d_out_kp; uint8_t *d_out_desc; int32_t *d_out_n; int out_cap;
     // capacities actually allocated
@@ -318,6 +322,16 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
             HIP_TRY(dev_alloc(&c->d_blur_tiles, tl.size()));
             HIP_TRY(hipMemcpy(c->d_blur_tiles, tl.data(), tl.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             c->n_blur_tiles = nt;
+            std::vector<uint16_t> bs;
+            std::vector<uint8_t> bh, bv;
+            orbx_build_blur_mfma(c->levels, c->taps, bs, bh, bv, c->blur_tab, c->blur_strips_before);
+            c->blur_mfma_levels = orbx_blur_mfma_levels(c->levels);
+            HIP_TRY(dev_alloc(&c->d_blur_strips, std::max(bs.size(), (size_t)2)));
+            HIP_TRY(dev_alloc(&c->d_band_h, std::max(bh.size(), (size_t)16)));
+            HIP_TRY(dev_alloc(&c->d_band_v, std::max(bv.size(), (size_t)16)));
+            if (!bs.empty()) HIP_TRY(hipMemcpy(c->d_blur_strips, bs.data(), bs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            if (!bh.empty()) HIP_TRY(hipMemcpy(c->d_band_h, bh.data(), bh.size(), hipMemcpyHostToDevice));
+            if (!bv.empty()) HIP_TRY(hipMemcpy(c->d_band_v, bv.data(), bv.size(), hipMemcpyHostToDevice));
         }
         std::vector<OrbxTap> taps;
         for (int l = 1; l < c->levels.n_levels; ++l) {
@@ -392,6 +406,8 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
         c->early_fast = f ? atoi(f) : 1;
         const char *fv = getenv("ORBX_FAST_VARIANT");
         c->fast_variant = fv ? atoi(fv) : 2;
+        const char *bl = getenv("ORBX_BLUR");
+        c->blur_mfma = bl ? (strcmp(bl, "valu") == 0 ? 0 : strcmp(bl, "mfma") == 0 ? 2 : 1) : 1;
     }
     {
         const char *e = getenv("ORBX_STREAMS");
@@ -434,7 +450,7 @@ extern "C" void orbx_destroy(orbx_t *c)
     OrbxBuffers &b = c->buf;
     void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.pcode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
                     b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.kp_ang, b.sel_count, c->d_levels, c->d_umax, c->d_taps,
-                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n, c->d_fast_cells, c->d_fast_strips, c->d_blur_tiles};
+                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n, c->d_fast_cells, c->d_fast_strips, c->d_blur_tiles, c->d_blur_strips, c->d_band_h, c->d_band_v};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         if (c->d_xtap[l]) (void)hipFree(c->d_xtap[l]);
@@ -534,6 +550,17 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         if (strips) orbx_launch_fast_strips(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, units, n, n_frames);
         else orbx_launch_fast(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, units, n, n_frames);
     };
+    // 7x7 Gaussian of levels [lb, le): on the matrix pipe for the levels that are large enough when the call is a batch
+    // (ORBX_BLUR=mfma forces it for any batch, =valu switches it off), the VALU kernels for the rest
+    auto launch_blur = [&](hipStream_t st, int lb, int le) {
+        const int lm = (c->blur_mfma == 2 || (c->blur_mfma == 1 && n_frames >= 8)) ? std::min(c->blur_mfma_levels, le) : 0;
+        if (lm > lb)
+            orbx_launch_blur_mfma(st, d_l0, l0_fs, l0_pitch, LV, b, c->blur_tab, c->d_blur_strips, c->blur_strips_before,
+                                  c->d_band_h, c->d_band_v, c->taps, n_frames, lb, lm);
+        if (le > std::max(lb, lm))
+            orbx_launch_blur(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames,
+                             std::max(lb, lm), le);
+    };
     const bool early = side_ok && c->early_fast && L > 1 && n_cells0 > 0 && n_cells0 < n_units;
     if (early) {
         HIP_TRY(hipEventRecord(c->ev_start[slot], s)); // candidate counters are zero from here on
@@ -541,8 +568,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         launch_fast(c->side[slot], d_units, n_cells0);
         HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
         if (c->early_fast > 1) // level 0 needs no pyramid for its blur either
-            orbx_launch_blur(c->side[slot], d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps,
-                             n_frames, 0, 1);
+            launch_blur(c->side[slot], 0, 1);
     }
     for (int l = 1; l < L; ++l) {
         const uint8_t *sp; size_t sfs; int spitch;
@@ -556,8 +582,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     auto fork_blur = [&]() -> int { // the blur only needs the pyramid: side stream, joined before the descriptor kernel
         HIP_TRY(hipEventRecord(c->ev_pyr[slot], s));
         HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_pyr[slot], 0));
-        orbx_launch_blur(c->side[slot], d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps,
-                         n_frames, (early && c->early_fast > 1) ? 1 : 0, L);
+        launch_blur(c->side[slot], (early && c->early_fast > 1) ? 1 : 0, L);
         HIP_TRY(hipEventRecord(c->ev_blur[slot], c->side[slot]));
         return ORBX_OK;
     };
@@ -571,7 +596,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
     if (side && c->side_blur != 1) { int rc = fork_blur(); if (rc) return rc; } // next to the quadtree and orientation
     if (!side)
-        orbx_launch_blur(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames, 0, L);
+        launch_blur(s, 0, L);
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));
     orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes);
     if (t) HIP_TRY(hipEventRecord(c->ev[4], s));

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/orbx.h"
 
 #define ORBX_EDGE 19        // EDGE_THRESHOLD (reference modules/ORB/ORBExtractor.cpp:15)
@@ -76,6 +78,19 @@ void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pit
                       const OrbxLevels &levels, const OrbxBuffers &b, const void *d_tiles, int n_tiles, const int *taps7,
                       int n_frames, int level_begin, int level_end);
 int orbx_build_blur_tiles(const OrbxLevels &levels, uint16_t *out);
+// the Gaussian on the matrix pipe (orbx_kernels.hip, k_blur_mfma): levels 0 .. orbx_blur_mfma_levels() - 1
+struct BlurMfmaLevels { // per-level record of k_blur_mfma, passed by value
+    int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], dst_pitch[ORBX_MAX_LEVELS], n_ty[ORBX_MAX_LEVELS];
+    unsigned long long dst_off[ORBX_MAX_LEVELS];
+    int bh_off[ORBX_MAX_LEVELS], bv_off[ORBX_MAX_LEVELS]; // in uint4, into the band tables
+};
+int orbx_blur_mfma_levels(const OrbxLevels &levels);
+void orbx_build_blur_mfma(const OrbxLevels &levels, const int taps[7], std::vector<uint16_t> &strips, std::vector<uint8_t> &band_h,
+                          std::vector<uint8_t> &band_v, BlurMfmaLevels &out, int strips_before[ORBX_MAX_LEVELS + 1]);
+void orbx_launch_blur_mfma(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels &levels,
+                           const OrbxBuffers &b, const BlurMfmaLevels &tab, const void *d_strips, const int *strips_before,
+                           const void *d_band_h, const void *d_band_v, const int taps[7], int n_frames, int level_begin,
+                           int level_end);
 void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLevels &levels, const OrbxBuffers &b,
                         int n_frames, size_t sort_lds_bytes);
 void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,

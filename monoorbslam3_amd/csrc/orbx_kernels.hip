@@ -6,6 +6,10 @@
 //   k_blur7        cv::GaussianBlur 7x7 s=2    modules/ORB/ORBExtractor.cpp:527-528
 //   k_octree       DistributeOctree            modules/ORB/ORBExtractor.cpp:640-830
 //   k_orient_desc  IC_Angle + rBRIEF + output  modules/ORB/ORBExtractor.cpp:18-97, :507-546, :626-637
+#include <string.h>
+
+#include <vector>
+
 #include "orbx_internal.h"
 #include "orb_math.h"
 #include "orb_pattern.h"
@@ -1000,6 +1004,229 @@ void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pit
     const int tasks = 3 * ((max_h + BE_ROWS - 1) / BE_ROWS);
     hipLaunchKernelGGL(k_blur_edges, dim3((tasks + 63) / 64, n_frames, level_end - level_begin), dim3(64), 0, s, src, d_levels,
                        b.img_arena, b.img_frame_stride, taps7, level_begin);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same 7x7 Gaussian on the MATRIX pipe (levels at least 64 x 8; the VALU kernels above stay the parity twin and
+// serve the small levels).  Both passes are banded matrix products, exact in i8 x i8 -> i32:
+//   H pass   H[y][x] = sum_i k_i src[y][x + i - 3]          = (pixels - 128) (32 rows x 64 columns) x band (64 x 32), + 32768
+//   V pass   V[y][x] = sum_j k_j H[y + j - 3][x],  H = 256 Hhi + Hlo, each byte (minus 128) its own product
+// with BORDER_REFLECT_101 folded into the band matrices of the border tiles (host tables: a tap whose source lies
+// outside the image is added to the coefficient of the pixel it reflects to).  One wave owns a strip of 32 columns and
+// walks down 32 rows at a time.  The H tile comes out with its column on the lane and its rows in the 16 accumulator
+// registers, which is exactly the A-operand layout of a product that sums over those rows (cdna_hip_programming.md,
+// "an accumulator tile as the next MFMA's operand"): byte 1 of every accumulator is the signed high byte of H - 32768,
+// byte 0 ^ 0x80 the signed low byte, so the hand-over is 24 v_perm + 4 v_xor and no LDS.  Using H as the A operand makes the
+// V product come out TRANSPOSED (output row on the lane, four groups of four consecutive columns in the registers), so
+// a lane stores four dwords per tile instead of sixteen bytes.  Per 32 x 32 output tile: 6 MFMA and about 110 VALU
+// (7 lane-operations per pixel against 23 of the VALU kernel).
+// ---------------------------------------------------------------------------------------------
+typedef int bl_v4i __attribute__((ext_vector_type(4)));
+typedef int bl_v16i __attribute__((ext_vector_type(16)));
+#define BM_COLS 128  // output columns of a workgroup: four waves, one 32-column MFMA tile each
+#define BM_SRC_W 160 // source bytes staged per row: 16 either side, in 16-byte chunks
+#define BM_SRC_P 176 // LDS pitch of a staged source row (conflict-free 16-byte operand reads)
+#define BM_OUT_P 132 // LDS pitch of a finished output row (33 dwords: conflict-free dword writes)
+struct __attribute__((aligned(4))) BlurBlock { uint16_t level, bx; };
+struct __attribute__((packed, aligned(1))) UnalignedV4 { bl_v4i v; };
+struct __attribute__((packed, aligned(1))) UnalignedU4 { uint32_t x, y, z, w; };
+
+// The 160 staged source columns of block bx start at blur_origin(); the 64-column window (two K-steps) of tile column tx
+// at blur_window().  `limit` = readable bytes of a row (the width for level 0, the padded pitch for the arena levels).
+// The host tables use the same two rules.
+__host__ __device__ __forceinline__ int blur_origin(int bx, int limit) { return min(max(BM_COLS * bx - 16, 0), limit - BM_SRC_W); }
+__host__ __device__ __forceinline__ int blur_window(int tx, int limit)
+{
+    const int xo = blur_origin(tx >> 2, limit);
+    return min(max(32 * tx - 16, xo), xo + BM_SRC_W - 64);
+}
+
+__global__ __launch_bounds__(256) void k_blur_mfma(FastSrc src, BlurMfmaLevels lv, const BlurBlock *__restrict__ blocks,
+                                                   const uint4 *__restrict__ band_h, const uint4 *__restrict__ band_v,
+                                                   uint8_t *__restrict__ arena, size_t arena_fs, int hbias, uint32_t vbias,
+                                                   int clamp255, int n_blocks, int n_frames)
+{
+    // hbias = 128 K - 32768 and vbias = 128 K * 257 + 2^15 for taps that sum to K (256, or 257 for the plain-rounded set)
+    __shared__ __align__(16) uint8_t s_src[2][32 * BM_SRC_P];
+    __shared__ __align__(16) uint8_t s_out[32 * BM_OUT_P];
+    int frame, bid;
+    if (!xcd_remap(n_blocks, n_frames, &frame, &bid)) return;
+    const BlurBlock bk = blocks[bid];
+    const int level = bk.level, tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = lv.w[level], h = lv.h[level], pitch = src.pitch[level], n_ty = lv.n_ty[level], dpitch = lv.dst_pitch[level];
+    const int limit = level == 0 ? w : pitch;
+    const int xo = blur_origin(bk.bx, limit);
+    const int n_tx = (w + 31) >> 5, tx = min(4 * (int)bk.bx + wave, n_tx - 1); // a wave past the last tile repeats it (not stored)
+    const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level];
+    uint8_t *D = arena + (size_t)frame * arena_fs + lv.dst_off[level];
+    // band of the H pass for this wave's tile column: two K-steps of 32 source columns
+    const uint4 *bh = band_h + lv.bh_off[level] + (size_t)tx * 128;
+    const bl_v4i bh0 = __builtin_bit_cast(bl_v4i, bh[lane]), bh1 = __builtin_bit_cast(bl_v4i, bh[64 + lane]);
+    const int a_off = n * BM_SRC_P + (blur_window(tx, limit) - xo) + 16 * hh; // this lane's 16 operand bytes of K-step 0
+
+    // staging: 32 rows x ten 16-byte chunks per H tile = 320 chunks, thread t takes chunk t and (t < 64) chunk 256 + t.
+    // H tile T = rows 32 T - 3 .. 32 T + 28 (rows outside the image are clamped: their coefficients are zero).
+    const int c0r = tid / 10, c0c = tid - 10 * c0r, c1r = (256 + tid) / 10, c1c = (256 + tid) - 10 * c1r;
+    auto g_load = [&](int T, uint4 *u0, uint4 *u1) {
+        const int r0 = min(max(32 * T - 3 + c0r, 0), h - 1), r1 = min(max(32 * T - 3 + min(c1r, 31), 0), h - 1);
+        const UnalignedU4 a = *reinterpret_cast<const UnalignedU4 *>(S + (size_t)r0 * pitch + xo + 16 * c0c);
+        const UnalignedU4 b2 = *reinterpret_cast<const UnalignedU4 *>(S + (size_t)r1 * pitch + xo + 16 * (tid < 64 ? c1c : 0));
+        *u0 = make_uint4(a.x, a.y, a.z, a.w);
+        *u1 = make_uint4(b2.x, b2.y, b2.z, b2.w);
+    };
+    auto s_store = [&](int buf, const uint4 &u0, const uint4 &u1) {
+        *reinterpret_cast<uint4 *>(&s_src[buf][c0r * BM_SRC_P + 16 * c0c]) = u0;
+        if (tid < 64) *reinterpret_cast<uint4 *>(&s_src[buf][c1r * BM_SRC_P + 16 * c1c]) = u1;
+    };
+    // the H tile staged in `buf`, turned into the two A operands of the V pass
+    auto h_tile = [&](int buf, bl_v4i *hi, bl_v4i *lo) {
+        bl_v4i a0 = reinterpret_cast<const UnalignedV4 *>(&s_src[buf][a_off])->v;
+        bl_v4i a1 = reinterpret_cast<const UnalignedV4 *>(&s_src[buf][a_off + 32])->v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a0[k] ^= (int)0x80808080u; a1[k] ^= (int)0x80808080u; } // pixel - 128 as i8
+        const bl_v16i zero = {};
+        bl_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bh0, zero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bh1, acc, 0, 0, 0);
+        // acc = H - 128 K; with hbias it is H - 32768: byte 1 = (H >> 8) - 128 and byte 0 = H & 255, what the V pass takes
+        if (hbias) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] += hbias;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t p = (uint32_t)acc[4 * k], q = (uint32_t)acc[4 * k + 1], r2 = (uint32_t)acc[4 * k + 2], t = (uint32_t)acc[4 * k + 3];
+            const uint32_t pq1 = __builtin_amdgcn_perm(q, p, 0x0c0c0501u), rt1 = __builtin_amdgcn_perm(t, r2, 0x0c0c0501u);
+            const uint32_t pq0 = __builtin_amdgcn_perm(q, p, 0x0c0c0400u), rt0 = __builtin_amdgcn_perm(t, r2, 0x0c0c0400u);
+            (*hi)[k] = (int)__builtin_amdgcn_perm(rt1, pq1, 0x05040100u);
+            (*lo)[k] = (int)(__builtin_amdgcn_perm(rt0, pq0, 0x05040100u) ^ 0x80808080u);
+        }
+    };
+    uint4 u0, u1;
+    g_load(0, &u0, &u1);
+    s_store(0, u0, u1);
+    g_load(1, &u0, &u1);
+    s_store(1, u0, u1);
+    __syncthreads();
+    bl_v4i hiP, loP, hiN, loN;
+    h_tile(0, &hiP, &loP);
+    const uint4 *bv = band_v + lv.bv_off[level];
+    const int orow = tid >> 3, ocol = 16 * (tid & 7); // this thread's 16 bytes of the finished 32 x 128 tile
+    for (int ty = 0; ty < n_ty; ++ty, bv += 128) {
+        const bl_v4i bv0 = __builtin_bit_cast(bl_v4i, bv[lane]), bv1 = __builtin_bit_cast(bl_v4i, bv[64 + lane]);
+        g_load(ty + 2, &u0, &u1); // source of the trip after the next, in flight under this trip's arithmetic
+        h_tile((ty + 1) & 1, &hiN, &loN);
+        const bl_v16i zero = {};
+        bl_v16i ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(hiP, bv0, zero, 0, 0, 0);
+        ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(hiN, bv1, ah, 0, 0, 0);
+        bl_v16i al = __builtin_amdgcn_mfma_i32_32x32x32_i8(loP, bv0, zero, 0, 0, 0);
+        al = __builtin_amdgcn_mfma_i32_32x32x32_i8(loN, bv1, al, 0, 0, 0);
+        // sum k H = 256 (ah + 128 K) + (al + 128 K) with K = sum of the taps; + 2^15 and >> 16 is byte 2 of the total.
+        // The product is transposed: this lane holds output row n, columns 8 g + 4 hh + (0..3) of its wave's tile.
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = (uint32_t)(ah[4 * g + k] * 256 + al[4 * g + k]) + vbias;
+                if (clamp255) v[k] = min(v[k], 0x00FFFFFFu);
+            }
+            const uint32_t a = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), b2 = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);
+            *reinterpret_cast<uint32_t *>(&s_out[n * BM_OUT_P + 32 * wave + 8 * g + 4 * hh]) = __builtin_amdgcn_perm(b2, a, 0x05040100u);
+        }
+        __syncthreads(); // the tile is complete in s_out, and nobody reads s_src[ty & 1] any more
+        {
+            const int y = 32 * ty + orow, x = BM_COLS * (int)bk.bx + ocol;
+            if (y < h && x < dpitch) { // columns between the width and the padded pitch take whatever the last tile holds
+                const uint32_t *o = reinterpret_cast<const uint32_t *>(&s_out[orow * BM_OUT_P + ocol]);
+                *reinterpret_cast<uint4 *>(D + (size_t)y * dpitch + x) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        s_store(ty & 1, u0, u1);
+        __syncthreads(); // s_src[ty & 1] holds tile ty + 2, s_out may be overwritten
+        hiP = hiN; loP = loN;
+    }
+}
+
+static int reflect101_host(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+// Levels 0 .. (return value - 1) are large enough for k_blur_mfma (160 staged source bytes inside every row).
+int orbx_blur_mfma_levels(const OrbxLevels &levels)
+{
+    int n = 0;
+    while (n < levels.n_levels && levels.lv[n].w >= BM_SRC_W && levels.lv[n].h >= 8) ++n;
+    return n;
+}
+// Block list (2 x uint16 per workgroup, level-major), the two band tables (16 bytes per lane and K-step) and the per-level
+// record of k_blur_mfma.  blocks_before[l] = workgroups of the levels below l.  l0_width_is_limit: level 0 is the caller's
+// buffer, nothing beyond a row's width may be read there; the arena levels may be read up to their padded pitch.
+void orbx_build_blur_mfma(const OrbxLevels &levels, const int taps[7], std::vector<uint16_t> &blocks, std::vector<uint8_t> &band_h,
+                          std::vector<uint8_t> &band_v, BlurMfmaLevels &out, int blocks_before[ORBX_MAX_LEVELS + 1])
+{
+    blocks.clear(); band_h.clear(); band_v.clear();
+    memset(&out, 0, sizeof out);
+    const int n_lv = orbx_blur_mfma_levels(levels);
+    for (int l = 0; l <= ORBX_MAX_LEVELS; ++l) blocks_before[l] = 0;
+    for (int l = 0; l < n_lv; ++l) {
+        const OrbxLevel &v = levels.lv[l];
+        const int w = v.w, h = v.h, n_tx = (w + 31) / 32, n_ty = (h + 31) / 32, limit = l == 0 ? w : v.pitch;
+        out.w[l] = w; out.h[l] = h; out.dst_pitch[l] = v.pitch; out.n_ty[l] = n_ty; out.dst_off[l] = v.blur_off;
+        out.bh_off[l] = (int)(band_h.size() / 16); out.bv_off[l] = (int)(band_v.size() / 16);
+        blocks_before[l] = (int)(blocks.size() / 2);
+        for (int bx = 0; bx < (w + BM_COLS - 1) / BM_COLS; ++bx) { blocks.push_back((uint16_t)l); blocks.push_back((uint16_t)bx); }
+        for (int tx = 0; tx < n_tx; ++tx) {
+            // H pass: coefficient of source column cw + kk (64-column window, two K-steps) for output column 32 tx + n
+            int B[64][32] = {};
+            const int x0 = 32 * tx, cw = blur_window(tx, limit);
+            for (int n = 0; n < 32 && x0 + n < w; ++n)
+                for (int i = 0; i < 7; ++i) B[reflect101_host(x0 + n + i - 3, w) - cw][n] += taps[i];
+            for (int s = 0; s < 2; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 16; ++j) band_h.push_back((uint8_t)(int8_t)B[32 * s + 16 * (lane >> 5) + j][lane & 31]);
+        }
+        for (int ty = 0; ty < n_ty; ++ty) {
+            // V pass: coefficient of H-tile row rho (tile ty + step, rows 32 (ty + step) - 3 ...) for output row 32 ty + n
+            int C[2][32][32] = {};
+            for (int n = 0; n < 32 && 32 * ty + n < h; ++n)
+                for (int i = 0; i < 7; ++i) {
+                    const int r = reflect101_host(32 * ty + n + i - 3, h);
+                    const int step = r >= 32 * (ty + 1) - 3 ? 1 : 0;
+                    C[step][r - (32 * (ty + step) - 3)][n] += taps[i];
+                }
+            for (int step = 0; step < 2; ++step)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 16; ++j) {
+                        const int rho = (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5); // accumulator row of register j (C/D layout)
+                        band_v.push_back((uint8_t)(int8_t)C[step][rho][lane & 31]);
+                    }
+        }
+    }
+    for (int l = n_lv; l <= ORBX_MAX_LEVELS; ++l) blocks_before[l] = (int)(blocks.size() / 2);
+}
+
+void orbx_launch_blur_mfma(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels &levels,
+                           const OrbxBuffers &b, const BlurMfmaLevels &tab, const void *d_blocks, const int *blocks_before,
+                           const void *d_band_h, const void *d_band_v, const int taps[7], int n_frames, int level_begin,
+                           int level_end)
+{
+    const int first = blocks_before[level_begin], count = blocks_before[level_end] - first;
+    if (count <= 0) return;
+    FastSrc src;
+    for (int l = 0; l < levels.n_levels; ++l) {
+        src.base[l] = l == 0 ? l0 : b.img_arena + levels.lv[l].raw_off;
+        src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
+        src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
+    }
+    int K = 0;
+    for (int i = 0; i < 7; ++i) K += taps[i];
+    hipLaunchKernelGGL(k_blur_mfma, dim3(orbx_xcd_grid(count, n_frames)), dim3(256), 0, s, src, tab,
+                       reinterpret_cast<const BlurBlock *>(d_blocks) + first, reinterpret_cast<const uint4 *>(d_band_h),
+                       reinterpret_cast<const uint4 *>(d_band_v), b.img_arena, b.img_frame_stride, 128 * K - 32768,
+                       (uint32_t)(128 * K * 257 + 32768), K != 256 ? 1 : 0, count, n_frames);
 }
 
 int orbx_build_blur_tiles(const OrbxLevels &levels, uint16_t *out /* 4 per tile, or NULL to count */)
