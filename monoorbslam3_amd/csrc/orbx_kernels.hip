@@ -1041,14 +1041,16 @@ __host__ __device__ __forceinline__ int blur_window(int tx, int limit)
     return min(max(32 * tx - 16, xo), xo + BM_SRC_W - 64);
 }
 
+template <int K_SUM> // the taps sum to 256 (default set), or to 257 (the plain-rounded set: two more operations per pixel)
 __global__ __launch_bounds__(256) void k_blur_mfma(FastSrc src, BlurMfmaLevels lv, const BlurBlock *__restrict__ blocks,
                                                    const uint4 *__restrict__ band_h, const uint4 *__restrict__ band_v,
-                                                   uint8_t *__restrict__ arena, size_t arena_fs, int hbias, uint32_t vbias,
-                                                   int clamp255, int n_blocks, int n_frames)
+                                                   uint8_t *__restrict__ arena, size_t arena_fs, int n_blocks, int n_frames)
 {
-    // hbias = 128 K - 32768 and vbias = 128 K * 257 + 2^15 for taps that sum to K (256, or 257 for the plain-rounded set)
+    constexpr int hbias = 128 * K_SUM - 32768;                 // H - 128 K  ->  H - 32768
+    constexpr uint32_t vbias = 128u * K_SUM * 257u + 32768u;   // the two 128 K of the byte products, and the rounding 2^15
+    constexpr bool clamp255 = K_SUM != 256;
     __shared__ __align__(16) uint8_t s_src[2][32 * BM_SRC_P];
-    __shared__ __align__(16) uint8_t s_out[32 * BM_OUT_P];
+    __shared__ __align__(16) uint8_t s_out[2][32 * BM_OUT_P];
     int frame, bid;
     if (!xcd_remap(n_blocks, n_frames, &frame, &bid)) return;
     const BlurBlock bk = blocks[bid];
@@ -1107,14 +1109,20 @@ __global__ __launch_bounds__(256) void k_blur_mfma(FastSrc src, BlurMfmaLevels l
     s_store(0, u0, u1);
     g_load(1, &u0, &u1);
     s_store(1, u0, u1);
+    g_load(2, &u0, &u1);
     __syncthreads();
     bl_v4i hiP, loP, hiN, loN;
     h_tile(0, &hiP, &loP);
+    __syncthreads(); // buffer 0 is free for tile 2
     const uint4 *bv = band_v + lv.bv_off[level];
     const int orow = tid >> 3, ocol = 16 * (tid & 7); // this thread's 16 bytes of the finished 32 x 128 tile
+    // One barrier per trip: trip ty reads source buffer (ty + 1) & 1, so buffer ty & 1 (last read in trip ty - 1) takes
+    // tile ty + 2 at the top of the trip, from registers loaded during the trip before; the finished tiles alternate
+    // between two output buffers.
     for (int ty = 0; ty < n_ty; ++ty, bv += 128) {
         const bl_v4i bv0 = __builtin_bit_cast(bl_v4i, bv[lane]), bv1 = __builtin_bit_cast(bl_v4i, bv[64 + lane]);
-        g_load(ty + 2, &u0, &u1); // source of the trip after the next, in flight under this trip's arithmetic
+        s_store(ty & 1, u0, u1);
+        g_load(ty + 3, &u0, &u1); // in flight under this trip's arithmetic (rows clamped past the image)
         h_tile((ty + 1) & 1, &hiN, &loN);
         const bl_v16i zero = {};
         bl_v16i ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(hiP, bv0, zero, 0, 0, 0);
@@ -1123,6 +1131,7 @@ __global__ __launch_bounds__(256) void k_blur_mfma(FastSrc src, BlurMfmaLevels l
         al = __builtin_amdgcn_mfma_i32_32x32x32_i8(loN, bv1, al, 0, 0, 0);
         // sum k H = 256 (ah + 128 K) + (al + 128 K) with K = sum of the taps; + 2^15 and >> 16 is byte 2 of the total.
         // The product is transposed: this lane holds output row n, columns 8 g + 4 hh + (0..3) of its wave's tile.
+        uint8_t *so = s_out[ty & 1];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint32_t v[4];
@@ -1132,18 +1141,16 @@ __global__ __launch_bounds__(256) void k_blur_mfma(FastSrc src, BlurMfmaLevels l
                 if (clamp255) v[k] = min(v[k], 0x00FFFFFFu);
             }
             const uint32_t a = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), b2 = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);
-            *reinterpret_cast<uint32_t *>(&s_out[n * BM_OUT_P + 32 * wave + 8 * g + 4 * hh]) = __builtin_amdgcn_perm(b2, a, 0x05040100u);
+            *reinterpret_cast<uint32_t *>(&so[n * BM_OUT_P + 32 * wave + 8 * g + 4 * hh]) = __builtin_amdgcn_perm(b2, a, 0x05040100u);
         }
-        __syncthreads(); // the tile is complete in s_out, and nobody reads s_src[ty & 1] any more
+        __syncthreads(); // the finished tile and the source of the next trip are complete
         {
             const int y = 32 * ty + orow, x = BM_COLS * (int)bk.bx + ocol;
             if (y < h && x < dpitch) { // columns between the width and the padded pitch take whatever the last tile holds
-                const uint32_t *o = reinterpret_cast<const uint32_t *>(&s_out[orow * BM_OUT_P + ocol]);
+                const uint32_t *o = reinterpret_cast<const uint32_t *>(&so[orow * BM_OUT_P + ocol]);
                 *reinterpret_cast<uint4 *>(D + (size_t)y * dpitch + x) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         }
-        s_store(ty & 1, u0, u1);
-        __syncthreads(); // s_src[ty & 1] holds tile ty + 2, s_out may be overwritten
         hiP = hiN; loP = loN;
     }
 }
@@ -1223,10 +1230,14 @@ void orbx_launch_blur_mfma(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l
     }
     int K = 0;
     for (int i = 0; i < 7; ++i) K += taps[i];
-    hipLaunchKernelGGL(k_blur_mfma, dim3(orbx_xcd_grid(count, n_frames)), dim3(256), 0, s, src, tab,
-                       reinterpret_cast<const BlurBlock *>(d_blocks) + first, reinterpret_cast<const uint4 *>(d_band_h),
-                       reinterpret_cast<const uint4 *>(d_band_v), b.img_arena, b.img_frame_stride, 128 * K - 32768,
-                       (uint32_t)(128 * K * 257 + 32768), K != 256 ? 1 : 0, count, n_frames);
+    if (K == 256)
+        hipLaunchKernelGGL(k_blur_mfma<256>, dim3(orbx_xcd_grid(count, n_frames)), dim3(256), 0, s, src, tab,
+                           reinterpret_cast<const BlurBlock *>(d_blocks) + first, reinterpret_cast<const uint4 *>(d_band_h),
+                           reinterpret_cast<const uint4 *>(d_band_v), b.img_arena, b.img_frame_stride, count, n_frames);
+    else // K == 257 (orbx_blur_mfma_levels() returns 0 for any other tap set)
+        hipLaunchKernelGGL(k_blur_mfma<257>, dim3(orbx_xcd_grid(count, n_frames)), dim3(256), 0, s, src, tab,
+                           reinterpret_cast<const BlurBlock *>(d_blocks) + first, reinterpret_cast<const uint4 *>(d_band_h),
+                           reinterpret_cast<const uint4 *>(d_band_v), b.img_arena, b.img_frame_stride, count, n_frames);
 }
 
 int orbx_build_blur_tiles(const OrbxLevels &levels, uint16_t *out /* 4 per tile, or NULL to count */)
