@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/orbm.h"
@@ -634,6 +635,7 @@ struct orbm_ctx {
     DevBuf w_in, w_out, w_grid; // window searches: staged inputs, lists, CSR grid + scratch
     PinBuf h_in, h_out;
     int window_on_device = 1;   // ORBM_WINDOW=host keeps the host grid (the parity twin of the device lists)
+    size_t window_last_total = 0; // candidates the previous window search returned (sizes the first copy-out)
 };
 
 extern "C" int orbm_create(int device, orbm_t **out)
@@ -1188,21 +1190,38 @@ struct FrameGrid {
     }
 };
 struct WindowQueries {
-    std::vector<int32_t> q_idx, c_begin, c_len, c_idx;
+    std::vector<int32_t> q_idx, c_begin, c_len;
+    const uint32_t *e = nullptr;      // packed entries: distance << 22 | candidate index
+    std::vector<uint32_t> own;        // the entries when they were made on the host
+    std::vector<int32_t> c_idx;       // host path scratch
+    int idx(size_t k, int t) const { return (int)(e[c_begin[k] + t] & 0x3FFFFFu); }
+    int dist(size_t k, int t) const { return (int)(e[c_begin[k] + t] >> 22); }
 };
 } // namespace
 
-// The candidate lists of a window search, either way: q.q_idx = queries with a non-empty window, their lists in
-// q.c_idx[q.c_begin[k] .. + q.c_len[k]) in the reference's getFeaturesInArea order, dist[] aligned with q.c_idx.
+// The candidate lists of a window search, either way: q.q_idx = queries with a non-empty window, their lists
+// q.e[q.c_begin[k] .. + q.c_len[k]) (distance << 22 | index) in the reference's getFeaturesInArea order.  On the device
+// path q.e is the pinned copy-out buffer of the context, read in place (valid until the context's next call).
 //   device path (default): ONE pinned staging copy in, grid build + one wave per query on the device, ONE copy out;
 //   host path (ORBM_WINDOW=host, or a window longer than `cap`): FrameGrid::area on the host + k_hamming_lists.
+struct PhaseTrace { // ORBM_TRACE=1: host time stamps of the phases of a window search on stderr
+    bool on; std::chrono::steady_clock::time_point t0;
+    PhaseTrace() : on(getenv("ORBM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[orbm] %-24s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - t0).count());
+        t0 = t;
+    }
+};
+
 static int window_candidates(orbm_ctx *c, bool strict, const float *sigma2, int n_sigma, int cap, const uint8_t *q_desc,
                              const float *q_xy, const float *q_radius, const int32_t *q_min, const int32_t *q_max,
                              const uint8_t *q_ok, int nq, const orbx_kp *kps2, const uint8_t *desc2, int n2, int img_w,
-                             int img_h, WindowQueries &q, std::vector<uint16_t> &dist)
+                             int img_h, WindowQueries &q)
 {
-    q.q_idx.clear(); q.c_begin.clear(); q.c_len.clear(); q.c_idx.clear();
-    dist.clear();
+    q.q_idx.clear(); q.c_begin.clear(); q.c_len.clear(); q.c_idx.clear(); q.own.clear();
+    q.e = nullptr;
     if (nq <= 0 || n2 <= 0) return ORBX_OK;
     const int G = ORBM_GRID;
     const int cols = img_w % G == 0 ? img_w / G : img_w / G + 1, rows = img_h % G == 0 ? img_h / G : img_h / G + 1;
@@ -1222,6 +1241,7 @@ static int window_candidates(orbm_ctx *c, bool strict, const float *sigma2, int 
         const size_t o_max = o; o = al(o + (size_t)nq * 4);
         const size_t o_ok = o; o = al(o + (size_t)nq);
         const size_t o_s2 = o; o = al(o + (size_t)std::max(n_sigma, 1) * 4);
+        PhaseTrace tr;
         M_TRY(c->h_in.need(o));
         M_TRY(c->w_in.need(o));
         uint8_t *hp = (uint8_t *)c->h_in.p;
@@ -1234,6 +1254,7 @@ static int window_candidates(orbm_ctx *c, bool strict, const float *sigma2, int 
         memcpy(hp + o_max, q_max, (size_t)nq * 4);
         memcpy(hp + o_ok, q_ok, (size_t)nq);
         if (sigma2) memcpy(hp + o_s2, sigma2, (size_t)n_sigma * 4);
+        tr.mark("stage inputs");
         M_TRY(hipMemcpyAsync(c->w_in.p, hp, o, hipMemcpyHostToDevice, s));
         const uint8_t *dp = (const uint8_t *)c->w_in.p;
         const size_t g_bytes = ((size_t)nc + 1 + 3 * (size_t)n2) * 4;
@@ -1241,7 +1262,8 @@ static int window_candidates(orbm_ctx *c, bool strict, const float *sigma2, int 
         int32_t *cell_start = (int32_t *)c->w_grid.p, *cell_items = cell_start + nc + 1, *cell_of = cell_items + n2, *tmp = cell_of + n2;
         // device output: [total, pad x3][counts nq][offs nq][pool]; the lists are packed, `cap` entries per query on average
         const size_t pool_cap = (size_t)nq * cap, head = 16 + (size_t)nq * 8;
-        const size_t first = std::min(pool_cap, (size_t)nq * 12 + 256); // what one copy brings back; the rest only if needed
+        // what one copy brings back (the rest only if needed): the previous call's total is the best guess for this one
+        const size_t first = std::min(pool_cap, std::max((size_t)nq * 12 + 256, c->window_last_total + c->window_last_total / 8 + 64));
         M_TRY(c->w_out.need(head + pool_cap * 4));
         M_TRY(c->h_out.need(head + pool_cap * 4));
         int32_t *d_total = (int32_t *)c->w_out.p, *d_counts = d_total + 4, *d_offs = d_counts + nq;
@@ -1255,24 +1277,28 @@ static int window_candidates(orbm_ctx *c, bool strict, const float *sigma2, int 
                            d_pool, d_total, d_offs);
         M_TRY(hipGetLastError());
         M_TRY(hipMemcpyAsync(c->h_out.p, c->w_out.p, head + first * 4, hipMemcpyDeviceToHost, s));
+        tr.mark("enqueue");
         M_TRY(hipStreamSynchronize(s));
+        tr.mark("device + first copy");
         const int32_t *h_total = (const int32_t *)c->h_out.p, *counts = h_total + 4, *offs = counts + nq;
         const uint32_t *pool = (const uint32_t *)(offs + nq);
         const size_t total = (size_t)std::max(h_total[0], 0);
+        c->window_last_total = total;
         if (total > pool_cap) on_device = false; // windows longer than the pool: redo on the host
         else if (total > first) {
             M_TRY(hipMemcpyAsync((uint8_t *)c->h_out.p + head + first * 4, (uint8_t *)c->w_out.p + head + first * 4,
                                  (total - first) * 4, hipMemcpyDeviceToHost, s));
             M_TRY(hipStreamSynchronize(s));
         }
+        tr.mark("second copy");
         if (on_device) {
-            q.c_idx.reserve(total); dist.reserve(total);
+            q.e = pool;
             for (int i = 0; i < nq; ++i) {
                 if (counts[i] <= 0) continue;
-                q.q_idx.push_back(i); q.c_begin.push_back((int32_t)q.c_idx.size()); q.c_len.push_back(counts[i]);
-                const uint32_t *e = pool + offs[i];
-                for (int t = 0; t < counts[i]; ++t) { q.c_idx.push_back((int32_t)(e[t] & 0x3FFFFFu)); dist.push_back((uint16_t)(e[t] >> 22)); }
+                q.q_idx.push_back(i); q.c_begin.push_back(offs[i]); q.c_len.push_back(counts[i]);
             }
+            if (tr.on) fprintf(stderr, "[orbm] %zu queries, %zu candidates\n", q.q_idx.size(), total);
+            tr.mark("unpack");
             return ORBX_OK;
         }
         q.q_idx.clear(); q.c_begin.clear(); q.c_len.clear(); q.c_idx.clear();
@@ -1296,8 +1322,14 @@ static int window_candidates(orbm_ctx *c, bool strict, const float *sigma2, int 
         if (q.c_idx.size() == begin) continue;
         q.q_idx.push_back(i); q.c_begin.push_back((int32_t)begin); q.c_len.push_back((int32_t)(q.c_idx.size() - begin));
     }
-    return hamming_lists(c, q_desc, nq, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.c_begin, q.c_idx.data(), q.c_idx.size(),
-                         q.c_idx.size(), dist);
+    std::vector<uint16_t> dist;
+    int rc = hamming_lists(c, q_desc, nq, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.c_begin, q.c_idx.data(), q.c_idx.size(),
+                           q.c_idx.size(), dist);
+    if (rc) return rc;
+    q.own.resize(q.c_idx.size());
+    for (size_t t = 0; t < q.c_idx.size(); ++t) q.own[t] = (uint32_t)dist[t] << 22 | (uint32_t)q.c_idx[t];
+    q.e = q.own.data();
+    return ORBX_OK;
 }
 
 extern "C" int orbm_search_for_initialization(orbm_t *c, float nn_ratio, int check_orientation, const void *kps1v,
@@ -1318,10 +1350,9 @@ extern "C" int orbm_search_for_initialization(orbm_t *c, float nn_ratio, int che
     std::vector<float> rad((size_t)n1, (float)window_size);
     for (int idx1 = 0; idx1 < n1; ++idx1) { lv[idx1] = kps1[idx1].octave; q_ok[idx1] = kps1[idx1].octave <= 0; } // :48 `if (level1 > 0) continue`
     WindowQueries wq;
-    std::vector<uint16_t> dist;
     int rc = window_candidates(c, false, nullptr, 0, 768, desc1, pre, rad.data(), lv.data(), lv.data(), q_ok.data(), n1, kps2, desc2,
-                               n2, img_w, img_h, wq, dist);
-    const std::vector<int32_t> &q_idx = wq.q_idx, &c_begin = wq.c_begin, &c_len = wq.c_len, &c_idx = wq.c_idx, &out_begin = wq.c_begin;
+                               n2, img_w, img_h, wq);
+    const std::vector<int32_t> &q_idx = wq.q_idx, &c_len = wq.c_len;
     if (rc) return rc;
     std::vector<int> matches21(n2, -1), matchedDist(n2, INT_MAX);
     RotHist rh;
@@ -1330,8 +1361,8 @@ extern "C" int orbm_search_for_initialization(orbm_t *c, float nn_ratio, int che
         const int idx1 = q_idx[k];
         int bestDist = INT_MAX - 1, bestDist2 = INT_MAX, bestIdx2 = -1;
         for (int t = 0; t < c_len[k]; ++t) {
-            const int idx2 = c_idx[c_begin[k] + t];
-            const int d = dist[out_begin[k] + t];
+            const int idx2 = wq.idx(k, t);
+            const int d = wq.dist(k, t);
             if (matchedDist[idx2] <= d) continue; // :63
             if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = idx2; }
             else if (d < bestDist2) bestDist2 = d;
@@ -1373,11 +1404,10 @@ extern "C" int orbm_search_by_projection_frame(orbm_t *c, int check_orientation,
     if (nq <= 0 || n2 <= 0) return ORBX_OK;
     const orbx_kp *kps2 = (const orbx_kp *)kps2v;
     WindowQueries q;
-    std::vector<uint16_t> dist;
     std::vector<int32_t> lmin((size_t)nq), lmax((size_t)nq);
     for (int i = 0; i < nq; ++i) { lmin[i] = q_octave[i] - 1; lmax[i] = q_octave[i] + 1; } // :226-229
     int rc = window_candidates(c, false, nullptr, 0, 48, q_desc, q_xy, q_radius, lmin.data(), lmax.data(), q_ok, nq, kps2, desc2,
-                               n2, img_w, img_h, q, dist);
+                               n2, img_w, img_h, q);
     if (rc) return rc;
     RotHist rh;
     int num = 0;
@@ -1385,9 +1415,9 @@ extern "C" int orbm_search_by_projection_frame(orbm_t *c, int check_orientation,
         const int i = q.q_idx[k];
         int bestDist = ORBM_TH_HIGH + 1, bestIdx2 = -1;
         for (int t = 0; t < q.c_len[k]; ++t) {
-            const int idx2 = q.c_idx[q.c_begin[k] + t];
+            const int idx2 = q.idx(k, t);
             if (frame_mp[idx2] != -1) continue; // :235 -- includes points matched earlier in this call
-            const int d = dist[q.c_begin[k] + t];
+            const int d = q.dist(k, t);
             if (d < bestDist) { bestDist = d; bestIdx2 = idx2; }
         }
         if (bestDist <= ORBM_TH_HIGH) { // :244
@@ -1421,23 +1451,22 @@ extern "C" int orbm_search_by_projection_points(orbm_t *c, float nn_ratio, const
     if (nq <= 0) return ORBX_OK;
     const orbx_kp *kps2 = (const orbx_kp *)kps2v;
     WindowQueries q;
-    std::vector<uint16_t> dist;
     std::vector<int32_t> lmin((size_t)nq);
     for (int i = 0; i < nq; ++i) {
         if (!q_ok[i]) ++n_out; // :355-358
         lmin[i] = q_level[i] - 1;  // :367-369
     }
     int rc = window_candidates(c, false, nullptr, 0, 48, q_desc, q_xy, q_radius, lmin.data(), q_level, q_ok, nq, kps2, desc2,
-                               std::max(n2, 0), img_w, img_h, q, dist);
+                               std::max(n2, 0), img_w, img_h, q);
     if (rc) return rc;
     int num = 0;
     for (size_t k = 0; k < q.q_idx.size(); ++k) {
         const int i = q.q_idx[k];
         int bestDist = 256, bestLevel = -1, secondDist = 257, secondLevel = -1, bestIdx = -1;
         for (int t = 0; t < q.c_len[k]; ++t) {
-            const int idx = q.c_idx[q.c_begin[k] + t];
+            const int idx = q.idx(k, t);
             if (frame_mp[idx] != -1) continue; // :383 -- a slot holding a good MapPoint (also one assigned in this call)
-            const int d = dist[q.c_begin[k] + t];
+            const int d = q.dist(k, t);
             if (d < bestDist) { secondDist = bestDist; bestDist = d; secondLevel = bestLevel; bestLevel = kps2[idx].octave; bestIdx = idx; }
             else if (d < secondDist) { secondDist = d; secondLevel = kps2[idx].octave; }
         }
@@ -1472,18 +1501,17 @@ extern "C" int orbm_search_fuse(orbm_t *c, const uint8_t *q_desc, const float *q
     for (int j = 0; j < n; ++j)
         if (kps[j].octave < 0 || kps[j].octave >= n_levels) return orbx_set_error(ORBX_E_ARG, "key-point octave outside the sigma2 table");
     WindowQueries q;
-    std::vector<uint16_t> dist;
     std::vector<int32_t> lmin((size_t)nq);
     for (int i = 0; i < nq; ++i) lmin[i] = q_level[i] - 1; // :556
     int rc = window_candidates(c, true, sigma2, n_levels, 48, q_desc, q_xy, q_radius, lmin.data(), q_level, q_ok, nq, kps,
-                               desc, n, img_w, img_h, q, dist);
+                               desc, n, img_w, img_h, q);
     if (rc) return rc;
     int found = 0;
     for (size_t k = 0; k < q.q_idx.size(); ++k) {
         int bestDist = ORBM_TH_LOW + 1, bestIdx1 = -1;
         for (int t = 0; t < q.c_len[k]; ++t) {
-            const int d = dist[q.c_begin[k] + t];
-            if (d < bestDist) { bestDist = d; bestIdx1 = q.c_idx[q.c_begin[k] + t]; }
+            const int d = q.dist(k, t);
+            if (d < bestDist) { bestDist = d; bestIdx1 = q.idx(k, t); }
         }
         best_idx[q.q_idx[k]] = bestIdx1; best_dist[q.q_idx[k]] = bestDist;
         if (bestIdx1 != -1) ++found;
