@@ -186,6 +186,29 @@ def test_blur_tap_variant_and_handle_reuse(oracle_mod):
         _check_frame(ex, orc, img, kps, desc, stages=True)
 
 
+@pytest.mark.parametrize("w,h", [(1242, 375), (752, 480), (1920, 1080), (331, 77), (161, 40), (640, 9 * 4)])
+@pytest.mark.parametrize("blur_variant", [0, 1])
+def test_gaussian_on_the_matrix_pipe(oracle_mod, monkeypatch, w, h, blur_variant):
+    """k_blur_mfma (the batch path's 7x7 Gaussian: banded i8 matrix products) forced for a single frame: every blurred
+    level byte-identical to the oracle, for both tap sets (sum 256 and the plain-rounded sum 257 with its clamp), widths
+    that are not multiples of the 128-column block or the 32-column tile, and levels too small for it (VALU kernels)."""
+    from monoorbslam3_amd.extractor import ORBExtractor
+    monkeypatch.setenv("ORBX_BLUR", "mfma")  # read when the extractor is created
+    ex = ORBExtractor(800, 1.2, 8, 20, 7, blur_variant=blur_variant)
+    orc = oracle_mod.Oracle(800, 1.2, 8, 20, 7, blur_variant=blur_variant)
+    img = synth.make_frames(1, w, h, seed=7 * w + h)[0]
+    if blur_variant == 1:
+        img[: h // 3, : w // 2] = 255  # saturated area: the sum-257 taps overshoot 255 here and must clamp
+    kps, desc = ex(img)
+    pyr = orc.pyramid(img)
+    for l in range(orc.n_levels):
+        if min(pyr[l].shape) < 1:
+            continue
+        assert np.array_equal(ex.tap_level(0, l, w, h, blurred=True), orc.blur(pyr[l])), "blurred level %d differs" % l
+    okps, odesc, _ = orc.extract(img)
+    assert len(kps) == len(okps) and np.array_equal(desc, odesc)
+
+
 def test_batch_device_pointers_and_determinism(oracle_mod):
     """HBM-resident batch API (the bench path): two runs give identical bytes, and they match the oracle"""
     import torch

@@ -8,7 +8,7 @@ import csv, glob, collections
 f = glob.glob('/tmp/tr/**/*kernel_trace.csv', recursive=True)[0]
 acc = collections.defaultdict(list)
 for row in csv.DictReader(open(f)):
-    k = row['Kernel_Name'].split('(')[0]
+    k = row['Kernel_Name'].split('(')[0].replace('void ', '')
     if k.startswith('k_'):
         acc[(k, row['Grid_Size_X'] if 'Grid_Size_X' in row else row.get('Grid_Size'))].append(int(row['End_Timestamp']) - int(row['Start_Timestamp']))
 for (k, g), v in sorted(acc.items()):

@@ -12,7 +12,7 @@ import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('/tmp/ldsb/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row['Kernel_Name'].split('(')[0]
+        k = row['Kernel_Name'].split('(')[0].replace('void ', '')
         if k.startswith('k_'):
             acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
 print("%-20s %10s %12s %12s %12s %14s %14s %10s" % ("kernel", "waves", "VALU/wave", "LDS/wave", "SALU/wave", "LDSact/LDSinst", "conflict/inst", "launches"))

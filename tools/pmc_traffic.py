@@ -15,9 +15,14 @@ from collections import defaultdict
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from monoorbslam3_amd._lib import kernels_sha16  # noqa: E402  (hash of the kernel sources the counters belong to)
 
-STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_fast_strip": "fast", "k_blur_cols": "blur", "k_octree_lds": "octree",
+STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_fast_strip": "fast", "k_blur_cols": "blur", "k_blur_edges": "blur", "k_blur_mfma": "blur", "k_angle": "orient_desc", "k_octree_lds": "octree",
          "k_orient": "orient_desc", "k_orient_desc": "orient_desc", "k_best2": "match_best2", "k_best2_mfma": "match_best2"}
 # per-step totals = sum over all dispatches of a kernel / number of steps in the run; a step has exactly one quadtree launch
+def kname(full):
+    """'void k_blur_mfma<256>(FastSrc, ...)' -> 'k_blur_mfma'"""
+    return full.split("(")[0].replace("void ", "").split("<")[0].strip()
+
+
 STEP_MARKER = "k_octree_lds"
 
 
@@ -25,7 +30,7 @@ def per_kernel(root):
     acc = defaultdict(list)
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+            acc[kname(row["Kernel_Name"])].append(float(row["Counter_Value"]))
     return acc
 
 

@@ -11,9 +11,14 @@ from collections import defaultdict
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from monoorbslam3_amd._lib import kernels_sha16  # noqa: E402  (hash of the kernel sources the counters belong to)
 
-STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_fast_strip": "fast", "k_blur_cols": "blur", "k_blur_edges": "blur",
+STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_fast_strip": "fast", "k_blur_cols": "blur", "k_blur_edges": "blur", "k_blur_mfma": "blur", "k_angle": "orient_desc",
          "k_octree_lds": "octree", "k_octree": "octree", "k_orient": "orient_desc", "k_orient_desc": "orient_desc",
          "k_best2": "match_best2", "k_best2_mfma": "match_best2"}
+def kname(full):
+    """'void k_blur_mfma<256>(FastSrc, ...)' -> 'k_blur_mfma'"""
+    return full.split("(")[0].replace("void ", "").split("<")[0].strip()
+
+
 STEP_MARKER = "k_octree_lds"  # exactly one launch per step: per-step totals = sum over all dispatches / its count
 
 
@@ -23,7 +28,7 @@ def main():
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == "SQ_INSTS_VALU":
-                acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+                acc[kname(row["Kernel_Name"])].append(float(row["Counter_Value"]))
     res, detail = defaultdict(float), {}
     n_steps = max(len(acc.get(STEP_MARKER, [])), 1)
     for k, v in acc.items():

@@ -12,7 +12,7 @@ import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('/tmp/sqb/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row['Kernel_Name'].split('(')[0]
+        k = row['Kernel_Name'].split('(')[0].replace('void ', '')
         if k.startswith('k_'):
             acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
 print("%-20s %10s | %% of wave cycles: %8s %10s %8s | %% of wave cycles issuing: %6s %6s %6s %6s" %
