@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "orb_math.h"
@@ -56,6 +57,9 @@ struct orbx_ctx {
     BlurMfmaLevels blur_tab; int blur_strips_before[ORBX_MAX_LEVELS + 1]; int blur_mfma_levels;
     int blur_mfma;                                              // ORBX_BLUR=valu switches it off
     uint8_t *d_l0_stage; size_t l0_stage_fs;
+    // host-API output staging, one device block: [counts, 256 B aligned][key points][descriptors]; `h_out_block` is its
+    // pinned mirror while the block is small (a few frames): the records then come back in one copy and one wait
+    uint8_t *d_out_block; uint8_t *h_out_block; size_t out_block_bytes, out_kp_off, out_desc_off;
     orbx_kp *d_out_kp; uint8_t *d_out_desc; int32_t *d_out_n; int out_cap;
     // capacities actually allocated
     int alloc_batch;
@@ -72,7 +76,7 @@ struct orbx_ctx {
     // The blur only needs the pyramid, FAST -> quadtree -> orientation only the raw levels: inside a frame range the
     // blur runs on a side stream next to that chain and joins before the descriptor kernel.  Slot 8 serves the
     // unsplit (small batch) case.
-    int side_blur;
+    int side_blur, split_level0;
     hipStream_t side[9];
     hipEvent_t ev_pyr[9], ev_blur[9];
     // FAST on level 0 needs no pyramid: its cells start on the side stream at once, next to the (latency-bound) resize
@@ -286,9 +290,16 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
     if (out_cap > 0 && (out_cap > c->alloc_out_cap || grow)) {
         HIP_TRY(hipDeviceSynchronize());
         const int cap = std::max(out_cap, c->alloc_out_cap);
-        HIP_TRY(dev_alloc(&c->d_out_kp, (size_t)cap * c->alloc_batch));
-        HIP_TRY(dev_alloc(&c->d_out_desc, (size_t)cap * 32 * c->alloc_batch));
-        HIP_TRY(dev_alloc(&c->d_out_n, (size_t)c->alloc_batch));
+        const size_t B = (size_t)c->alloc_batch;
+        c->out_kp_off = align_up(B * sizeof(int32_t), 256);
+        c->out_desc_off = align_up(c->out_kp_off + B * cap * sizeof(orbx_kp), 256);
+        c->out_block_bytes = c->out_desc_off + B * cap * 32;
+        HIP_TRY(dev_alloc(&c->d_out_block, c->out_block_bytes));
+        c->d_out_n = reinterpret_cast<int32_t *>(c->d_out_block);
+        c->d_out_kp = reinterpret_cast<orbx_kp *>(c->d_out_block + c->out_kp_off);
+        c->d_out_desc = c->d_out_block + c->out_desc_off;
+        if (c->h_out_block) { (void)hipHostFree(c->h_out_block); c->h_out_block = nullptr; }
+        if (c->out_block_bytes <= (size_t)4 << 20) HIP_TRY(hipHostMalloc((void **)&c->h_out_block, c->out_block_bytes, hipHostMallocDefault));
         c->alloc_out_cap = cap;
     }
     if (!same) {
@@ -404,6 +415,8 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
         c->side_blur = e ? atoi(e) : 1;
         const char *f = getenv("ORBX_EARLY_FAST");
         c->early_fast = f ? atoi(f) : 1;
+        const char *sp = getenv("ORBX_SPLIT_LEVEL0");
+        c->split_level0 = sp ? atoi(sp) : 1;
         const char *fv = getenv("ORBX_FAST_VARIANT");
         c->fast_variant = fv ? atoi(fv) : 2;
         const char *bl = getenv("ORBX_BLUR");
@@ -450,8 +463,9 @@ extern "C" void orbx_destroy(orbx_t *c)
     OrbxBuffers &b = c->buf;
     void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.pcode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
                     b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.kp_ang, b.sel_count, c->d_levels, c->d_umax, c->d_taps,
-                    c->d_l0_stage, c->d_out_kp, c->d_out_desc, c->d_out_n, c->d_fast_cells, c->d_fast_strips, c->d_blur_tiles, c->d_blur_strips, c->d_band_h, c->d_band_v};
+                    c->d_l0_stage, c->d_out_block, c->d_fast_cells, c->d_fast_strips, c->d_blur_tiles, c->d_blur_strips, c->d_band_h, c->d_band_v};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->h_out_block) (void)hipHostFree(c->h_out_block);
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         if (c->d_xtap[l]) (void)hipFree(c->d_xtap[l]);
         if (c->d_ytap[l]) (void)hipFree(c->d_ytap[l]);
@@ -508,6 +522,17 @@ extern "C" int orbx_max_keypoints(const orbx_t *c, int w0, int h0)
 // ------------------------------------------------------------------------------------------------
 // the pipeline
 // ------------------------------------------------------------------------------------------------
+struct PhaseTrace { // ORBX_TRACE=1: host time stamps of the phases of orbx_extract_batch on stderr
+    bool on; std::chrono::steady_clock::time_point t0;
+    PhaseTrace() : on(getenv("ORBX_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[orbx] %-24s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - t0).count());
+        t0 = t;
+    }
+};
+
 // the same arenas, seen from frame f0 on
 static OrbxBuffers offset_buffers(const OrbxBuffers &a, int f0, int kcap_total)
 {
@@ -562,13 +587,21 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
                              std::max(lb, lm), le);
     };
     const bool early = side_ok && c->early_fast && L > 1 && n_cells0 > 0 && n_cells0 < n_units;
+    // A call with a few frames is a chain of latency-bound kernels: level 0 (a third of the pixels, the longest quadtree)
+    // then runs FAST -> quadtree on the side stream next to resize -> FAST -> quadtree of the other levels, and the blur
+    // takes a stream of its own (slot 7 is free whenever the whole batch is on slot 8).
+    const bool split = early && slot == 8 && !strips && c->split_level0;
+    const int bslot = split ? 7 : slot;
     if (early) {
         HIP_TRY(hipEventRecord(c->ev_start[slot], s)); // candidate counters are zero from here on
         HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_start[slot], 0));
         launch_fast(c->side[slot], d_units, n_cells0);
+        if (split) orbx_launch_octree(c->side[slot], c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, 1);
         HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
-        if (c->early_fast > 1) // level 0 needs no pyramid for its blur either
-            launch_blur(c->side[slot], 0, 1);
+        if (c->early_fast > 1) { // level 0 needs no pyramid for its blur either
+            if (split) HIP_TRY(hipStreamWaitEvent(c->side[bslot], c->ev_start[slot], 0));
+            launch_blur(c->side[bslot], 0, 1);
+        }
     }
     for (int l = 1; l < L; ++l) {
         const uint8_t *sp; size_t sfs; int spitch;
@@ -580,16 +613,16 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     if (t) HIP_TRY(hipEventRecord(c->ev[1], s));
     const bool side = !t && c->side_blur && slot >= 0;
     auto fork_blur = [&]() -> int { // the blur only needs the pyramid: side stream, joined before the descriptor kernel
-        HIP_TRY(hipEventRecord(c->ev_pyr[slot], s));
-        HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_pyr[slot], 0));
-        launch_blur(c->side[slot], (early && c->early_fast > 1) ? 1 : 0, L);
-        HIP_TRY(hipEventRecord(c->ev_blur[slot], c->side[slot]));
+        HIP_TRY(hipEventRecord(c->ev_pyr[bslot], s));
+        HIP_TRY(hipStreamWaitEvent(c->side[bslot], c->ev_pyr[bslot], 0));
+        launch_blur(c->side[bslot], (early && c->early_fast > 1) ? 1 : 0, L);
+        HIP_TRY(hipEventRecord(c->ev_blur[bslot], c->side[bslot]));
         return ORBX_OK;
     };
     if (side && c->side_blur == 1) { int rc = fork_blur(); if (rc) return rc; } // next to FAST
     if (early) {
         launch_fast(s, d_units + 4 * n_cells0, n_units - n_cells0);
-        HIP_TRY(hipStreamWaitEvent(s, c->ev_fast0[slot], 0));
+        if (!split) HIP_TRY(hipStreamWaitEvent(s, c->ev_fast0[slot], 0));
     } else {
         launch_fast(s, d_units, n_units);
     }
@@ -598,10 +631,11 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     if (!side)
         launch_blur(s, 0, L);
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));
-    orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes);
+    orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, split ? 1 : 0, L);
+    if (split) HIP_TRY(hipStreamWaitEvent(s, c->ev_fast0[slot], 0));
     if (t) HIP_TRY(hipEventRecord(c->ev[4], s));
     orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames,
-                            side ? c->ev_blur[slot] : nullptr);
+                            side ? c->ev_blur[bslot] : nullptr);
     if (t) { HIP_TRY(hipEventRecord(c->ev[5], s)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
     return ORBX_OK;
@@ -662,6 +696,7 @@ extern "C" int orbx_extract_batch(orbx_t *c, const uint8_t *imgs, int n_frames, 
     if (rc) return rc;
     const int scap = c->alloc_out_cap;
     hipStream_t s = c->stream;
+    PhaseTrace tr;
     // Level 0 goes to HBM as it is laid out on the host: dense rows (stride == width, the cv::Mat::clone() case of
     // Frame.cpp:17) are ONE linear copy (a pitched 2-D copy from pageable memory costs milliseconds); the kernels
     // accept any level-0 pitch.  Only a genuinely strided input takes the 2-D copy.
@@ -681,23 +716,59 @@ extern "C" int orbx_extract_batch(orbx_t *c, const uint8_t *imgs, int n_frames, 
             HIP_TRY(hipMemcpy2DAsync(c->d_l0_stage + (size_t)f * l0_fs, l0_pitch, imgs + (size_t)f * frame_stride, stride,
                                      width, height, hipMemcpyHostToDevice, s));
     }
+    tr.mark("copy-in call");
+    auto copy_records = [&]() -> int {
+        // few frames: the whole fixed-capacity block comes back in one piece (three when the call uses fewer frames than
+        // the block was laid out for), one wait, and the live records go to the caller's buffers from pinned memory
+        const size_t nb = (size_t)n_frames;
+        if (n_frames == c->alloc_batch) {
+            HIP_TRY(hipMemcpyAsync(c->h_out_block, c->d_out_block, c->out_block_bytes, hipMemcpyDeviceToHost, s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(c->h_out_block, c->d_out_block, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(c->h_out_block + c->out_kp_off, c->d_out_block + c->out_kp_off, nb * scap * sizeof(orbx_kp),
+                                   hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(c->h_out_block + c->out_desc_off, c->d_out_block + c->out_desc_off, nb * scap * 32,
+                                   hipMemcpyDeviceToHost, s));
+        }
+        return ORBX_OK;
+    };
+    // (Replaying the call as one captured hipGraph -- kernels on three streams plus the record copy -- was measured and is
+    // not used: 295 us per 1242x375 frame against 218 us for the eager launches, ROCm 7.2.)
     rc = enqueue_batch(c, s, c->d_l0_stage, l0_fs, l0_pitch, n_frames, c->d_out_kp, c->d_out_desc, scap, c->d_out_n);
     if (rc) return rc;
-    std::vector<int32_t> counts(n_frames);
-    HIP_TRY(hipMemcpyAsync(counts.data(), c->d_out_n, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (c->h_out_block) { rc = copy_records(); if (rc) return rc; }
+    tr.mark("kernel launches");
     int status = ORBX_OK;
-    for (int f = 0; f < n_frames; ++f) {
-        const int n = counts[f];
-        n_out[f] = n;
-        if (n == 0) continue; // reference :512 -- outputs untouched
-        if (n > cap) { status = ORBX_E_CAPACITY; continue; }
-        HIP_TRY(hipMemcpyAsync(out_kp + (size_t)f * cap, c->d_out_kp + (size_t)f * scap, sizeof(orbx_kp) * n,
-                               hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out_desc + (size_t)f * cap * 32, c->d_out_desc + (size_t)f * scap * 32, (size_t)n * 32,
-                               hipMemcpyDeviceToHost, s));
+    if (c->h_out_block) {
+        HIP_TRY(hipStreamSynchronize(s));
+        tr.mark("device + records");
+        const int32_t *counts = reinterpret_cast<const int32_t *>(c->h_out_block);
+        for (int f = 0; f < n_frames; ++f) {
+            const int n = counts[f];
+            n_out[f] = n;
+            if (n == 0) continue; // reference :512 -- outputs untouched
+            if (n > cap) { status = ORBX_E_CAPACITY; continue; }
+            memcpy(out_kp + (size_t)f * cap, c->h_out_block + c->out_kp_off + (size_t)f * scap * sizeof(orbx_kp), sizeof(orbx_kp) * n);
+            memcpy(out_desc + (size_t)f * cap * 32, c->h_out_block + c->out_desc_off + (size_t)f * scap * 32, (size_t)n * 32);
+        }
+    } else {
+        std::vector<int32_t> counts(n_frames);
+        HIP_TRY(hipMemcpyAsync(counts.data(), c->d_out_n, sizeof(int32_t) * n_frames, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        tr.mark("device + counts");
+        for (int f = 0; f < n_frames; ++f) {
+            const int n = counts[f];
+            n_out[f] = n;
+            if (n == 0) continue; // reference :512 -- outputs untouched
+            if (n > cap) { status = ORBX_E_CAPACITY; continue; }
+            HIP_TRY(hipMemcpyAsync(out_kp + (size_t)f * cap, c->d_out_kp + (size_t)f * scap, sizeof(orbx_kp) * n,
+                                   hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(out_desc + (size_t)f * cap * 32, c->d_out_desc + (size_t)f * scap * 32, (size_t)n * 32,
+                                   hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
     }
-    HIP_TRY(hipStreamSynchronize(s));
+    tr.mark("records out");
     if (status == ORBX_E_CAPACITY) return fail(status, "output capacity too small");
     return ORBX_OK;
 }
@@ -786,3 +857,15 @@ extern "C" int orbx_stage_times_ms(orbx_t *c, float *ms)
 
 extern "C" const char *orbx_last_error(void) { return g_err.c_str(); }
 extern "C" const char *orbx_version(void) { return "orbx 0.1 (gfx950)"; }
+
+#ifdef OCT_PROF
+// development build only (make prof): the quadtree kernel's phase time stamps of frame 0 (tools/octree_phases.py)
+extern "C" int orbx_dev_octree_phases(orbx_t *c, unsigned long long *out, int n_levels)
+{
+    if (!c || !out) return fail(ORBX_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->buf.best, sizeof(unsigned long long) * 64 * n_levels, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+#endif

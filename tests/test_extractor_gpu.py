@@ -209,6 +209,21 @@ def test_gaussian_on_the_matrix_pipe(oracle_mod, monkeypatch, w, h, blur_variant
     assert len(kps) == len(okps) and np.array_equal(desc, odesc)
 
 
+@pytest.mark.parametrize("w,h,nf,n_patches,side", [(1242, 375, 2000, 12, 40), (752, 480, 1000, 6, 30), (640, 200, 3000, 5, 48)])
+def test_quadtree_on_crowded_corners(oracle_mod, w, h, nf, n_patches, side):
+    """Every corner of the frame sits in a few small noise patches: the quadtree has to divide seven to nine times before
+    the quota is reached (a scene takes three or four), which is where the kernel extends its descent codes."""
+    ex, orc = _mk(oracle_mod, nf, w, h, ini=5, mn=2)  # at these thresholds nearly every noise pixel is a corner
+    rng = np.random.RandomState(w + nf)
+    img = np.full((h, w), 128, np.uint8)
+    for _ in range(n_patches):
+        x0, y0 = rng.randint(20, w - 20 - side), rng.randint(20, h - 20 - side)
+        img[y0:y0 + side, x0:x0 + side] = rng.randint(0, 256, (side, side))
+    kps, desc = ex(img)
+    assert len(kps) > nf * 0.9  # the quota is reached: the tree went as deep as the patches are dense
+    _check_frame(ex, orc, img, kps, desc, stages=True)
+
+
 def test_batch_device_pointers_and_determinism(oracle_mod):
     """HBM-resident batch API (the bench path): two runs give identical bytes, and they match the oracle"""
     import torch
