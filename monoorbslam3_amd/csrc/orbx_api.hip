@@ -513,6 +513,7 @@ extern "C" int orbx_level_size(const orbx_t *c, int w0, int h0, int level, int *
 extern "C" int orbx_max_keypoints(const orbx_t *c, int w0, int h0)
 {
     if (!c) return fail(ORBX_E_ARG, "null handle");
+    if (w0 == c->cur_w && h0 == c->cur_h) return c->levels.kcap_total;
     Geometry g;
     int rc = compute_geometry(c, w0, h0, &g);
     if (rc) return rc;
@@ -557,7 +558,6 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     d_l0 += (size_t)f0 * l0_fs;
     d_kp += (size_t)f0 * cap; d_desc += (size_t)f0 * cap * 32; d_n += f0;
     if (t) HIP_TRY(hipEventRecord(c->ev[0], s));
-    HIP_TRY(hipMemsetAsync(b.cand_count, 0, sizeof(int) * ORBX_MAX_LEVELS * n_frames, s));
     auto raw = [&](int l, const uint8_t **p, size_t *fs, int *pitch) {
         if (l == 0) { *p = d_l0; *fs = l0_fs; *pitch = l0_pitch; }
         else { *p = b.img_arena + LV.lv[l].raw_off; *fs = b.img_frame_stride; *pitch = LV.lv[l].pitch; }
@@ -592,16 +592,42 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     // takes a stream of its own (slot 7 is free whenever the whole batch is on slot 8).
     const bool split = early && slot == 8 && !strips && c->split_level0;
     const int bslot = split ? 7 : slot;
+    if (!split) HIP_TRY(hipMemsetAsync(b.cand_count, 0, sizeof(int) * ORBX_MAX_LEVELS * n_frames, s));
+    if (split) {
+        // The host needs 2-3 us per launch, about what a small resize takes on the device: the chain the call waits for
+        // (resize x7 -> FAST -> quadtree of levels 1..) is issued first and back to back, the two side chains (level 0;
+        // the blur) afterwards -- they have started long before the main chain needs them.
+        for (int l = 1; l < L; ++l) {
+            const uint8_t *sp; size_t sfs; int spitch;
+            raw(l - 1, &sp, &sfs, &spitch);
+            orbx_launch_resize(s, sp, sfs, spitch, LV.lv[l - 1].w, LV.lv[l - 1].h, b.img_arena + LV.lv[l].raw_off,
+                               b.img_frame_stride, LV.lv[l].pitch, LV.lv[l].w, LV.lv[l].h, c->d_xtap[l], c->d_ytap[l],
+                               n_frames, l == 1 ? b.cand_count : nullptr); // the first one clears the candidate counters
+            if (l == 1) HIP_TRY(hipEventRecord(c->ev_start[slot], s));    // ... which are zero from here on
+        }
+        HIP_TRY(hipEventRecord(c->ev_pyr[bslot], s));
+        launch_fast(s, d_units + 4 * n_cells0, n_units - n_cells0);
+        orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 1, L);
+        HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_start[slot], 0));
+        launch_fast(c->side[slot], d_units, n_cells0);
+        orbx_launch_octree(c->side[slot], c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, 1);
+        HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
+        HIP_TRY(hipStreamWaitEvent(c->side[bslot], c->ev_pyr[bslot], 0));
+        launch_blur(c->side[bslot], 0, L);
+        HIP_TRY(hipEventRecord(c->ev_blur[bslot], c->side[bslot]));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_fast0[slot], 0));
+        orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames,
+                                c->ev_blur[bslot]);
+        HIP_TRY(hipGetLastError());
+        return ORBX_OK;
+    }
     if (early) {
         HIP_TRY(hipEventRecord(c->ev_start[slot], s)); // candidate counters are zero from here on
         HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_start[slot], 0));
         launch_fast(c->side[slot], d_units, n_cells0);
-        if (split) orbx_launch_octree(c->side[slot], c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, 1);
         HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
-        if (c->early_fast > 1) { // level 0 needs no pyramid for its blur either
-            if (split) HIP_TRY(hipStreamWaitEvent(c->side[bslot], c->ev_start[slot], 0));
-            launch_blur(c->side[bslot], 0, 1);
-        }
+        if (c->early_fast > 1) // level 0 needs no pyramid for its blur either
+            launch_blur(c->side[slot], 0, 1);
     }
     for (int l = 1; l < L; ++l) {
         const uint8_t *sp; size_t sfs; int spitch;
@@ -622,7 +648,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     if (side && c->side_blur == 1) { int rc = fork_blur(); if (rc) return rc; } // next to FAST
     if (early) {
         launch_fast(s, d_units + 4 * n_cells0, n_units - n_cells0);
-        if (!split) HIP_TRY(hipStreamWaitEvent(s, c->ev_fast0[slot], 0));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_fast0[slot], 0));
     } else {
         launch_fast(s, d_units, n_units);
     }
@@ -631,8 +657,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     if (!side)
         launch_blur(s, 0, L);
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));
-    orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, split ? 1 : 0, L);
-    if (split) HIP_TRY(hipStreamWaitEvent(s, c->ev_fast0[slot], 0));
+    orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, L);
     if (t) HIP_TRY(hipEventRecord(c->ev[4], s));
     orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames,
                             side ? c->ev_blur[bslot] : nullptr);
@@ -688,10 +713,15 @@ extern "C" int orbx_extract_batch(orbx_t *c, const uint8_t *imgs, int n_frames, 
     for (int f = 0; f < n_frames; ++f) n_out[f] = 0;
     if (!imgs || width <= 0 || height <= 0) return ORBX_OK; // reference :497 -- empty image: silent no-op
     if (n_frames < 1 || stride < width || cap < 1 || !out_kp || !out_desc) return fail(ORBX_E_ARG, "bad argument");
-    Geometry g;
-    int rc = compute_geometry(c, width, height, &g);
-    if (rc) return rc;
-    const int dcap = g.levels.kcap_total; // device-side staging holds every possible keypoint
+    int rc, dcap; // device-side staging holds every possible keypoint
+    if (width == c->cur_w && height == c->cur_h) {
+        dcap = c->levels.kcap_total;
+    } else {
+        Geometry g;
+        rc = compute_geometry(c, width, height, &g);
+        if (rc) return rc;
+        dcap = g.levels.kcap_total;
+    }
     rc = ensure_geometry(c, width, height, n_frames, dcap);
     if (rc) return rc;
     const int scap = c->alloc_out_cap;

@@ -66,7 +66,7 @@ struct OrbxBuffers {
 
 void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh,
                         uint8_t *dst, size_t dst_fs, int dst_pitch, int dw, int dh,
-                        const OrbxTap *xtap, const OrbxTap *ytap, int n_frames);
+                        const OrbxTap *xtap, const OrbxTap *ytap, int n_frames, int *zero_counts = nullptr);
 void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                       const OrbxLevels &levels, const OrbxBuffers &b, const void *d_cells, int n_cells, int n_frames);
 int orbx_build_fast_cells(const OrbxLevels &levels, uint16_t *out);

@@ -45,11 +45,14 @@ struct __attribute__((packed, aligned(1))) UnalignedU64 { unsigned long long v; 
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, size_t src_fs, int src_pitch, int sw,
                                                 int sh, uint8_t *__restrict__ dst, size_t dst_fs, int dst_pitch,
                                                 int dw, int dh, const OrbxTap *__restrict__ xtap,
-                                                const OrbxTap *__restrict__ ytap, int gx, int gy, int n_frames)
+                                                const OrbxTap *__restrict__ ytap, int gx, int gy, int n_frames,
+                                                int *__restrict__ zero_counts)
 {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     int frame, blk; // a frame's blocks share one XCD: source rows used by two block rows are fetched once
     if (!xcd_remap(gx * gy, n_frames, &frame, &blk)) return;
+    // a call with a few frames saves the memset launch: the first resize clears the frame's FAST candidate counters
+    if (zero_counts && blk == 0 && threadIdx.y == 0 && threadIdx.x < ORBX_MAX_LEVELS) zero_counts[frame * ORBX_MAX_LEVELS + threadIdx.x] = 0;
     const int by = blk / gx, bx = blk - by * gx;
     const int dx0 = (bx * 64 + threadIdx.x) * 4;
     // a wave is one row of the 64 x 4 block, so its output rows and their row taps are wave-uniform: scalar loads
@@ -110,11 +113,11 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
 
 void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh,
                         uint8_t *dst, size_t dst_fs, int dst_pitch, int dw, int dh, const OrbxTap *xtap,
-                        const OrbxTap *ytap, int n_frames)
+                        const OrbxTap *ytap, int n_frames, int *zero_counts)
 {
     const int gx = (dw + 255) / 256, gy = (dh + 4 * RS_ROWS - 1) / (4 * RS_ROWS);
     hipLaunchKernelGGL(k_resize, dim3(orbx_xcd_grid(gx * gy, n_frames)), dim3(64, 4), 0, s, src, src_fs, src_pitch, sw, sh, dst,
-                       dst_fs, dst_pitch, dw, dh, xtap, ytap, gx, gy, n_frames);
+                       dst_fs, dst_pitch, dw, dh, xtap, ytap, gx, gy, n_frames, zero_counts);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2095,6 +2098,7 @@ struct OrientLevels { // what k_orient needs of every level, passed by value so 
     int kp_off[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS];
     unsigned long long raw_off[ORBX_MAX_LEVELS];
 };
+template <bool WITH_ANGLE> // true (calls with a few frames): the lane that holds the moments also does k_angle's work -- one launch less
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, size_t l0_fs, int l0_pitch,
                                                 const OrbxLevels *__restrict__ levels, OrientLevels tab, OrbxBuffers b,
                                                 const int *__restrict__ u_max, int per_frame, int n_frames)
@@ -2182,8 +2186,14 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, 
     }
     // the moments leave as they are; k_angle turns them into (angle, cos, sin) with one thread per key point -- done here
     // the long double-precision chain ran on one quarter-filled wave per workgroup while the other three waited
-    if (sub == 0 && slot < levels->kcap_total)
-        b.kp_ang[(size_t)frame * levels->kcap_total + slot] = make_float4(__int_as_float(m10), __int_as_float(m01), 0.f, 0.f);
+    if (sub == 0 && slot < levels->kcap_total) {
+        float4 o = make_float4(__int_as_float(m10), __int_as_float(m01), 0.f, 0.f);
+        if (WITH_ANGLE) {
+            o.x = orb_fast_atan2((float)m01, (float)m10);
+            orb_sincos_deg(o.x, &o.y, &o.z);
+        }
+        b.kp_ang[(size_t)frame * levels->kcap_total + slot] = o;
+    }
 }
 
 // IC_Angle's last line (reference :41) and the sine / cosine of computeOrbDescriptor (:54), one thread per key-point slot
@@ -2346,10 +2356,15 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
         tab.pitch[l] = l < levels.n_levels ? levels.lv[l].pitch : 0;
         tab.raw_off[l] = l < levels.n_levels ? (unsigned long long)levels.lv[l].raw_off : 0ull;
     }
-    hipLaunchKernelGGL(k_orient, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, tab, b,
-                       u_max, pf_o, n_frames);
-    hipLaunchKernelGGL(k_angle, dim3((unsigned)(((size_t)levels.kcap_total * n_frames + 255) / 256)), dim3(256), 0, s, d_levels, b,
-                       n_frames);
+    if (n_frames < 24) { // latency-bound: one launch
+        hipLaunchKernelGGL(k_orient<true>, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, tab,
+                           b, u_max, pf_o, n_frames);
+    } else {
+        hipLaunchKernelGGL(k_orient<false>, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, tab,
+                           b, u_max, pf_o, n_frames);
+        hipLaunchKernelGGL(k_angle, dim3((unsigned)(((size_t)levels.kcap_total * n_frames + 255) / 256)), dim3(256), 0, s, d_levels,
+                           b, n_frames);
+    }
     if (blur_done) (void)hipStreamWaitEvent(s, blur_done, 0); // the blurred levels come from a side stream
     hipLaunchKernelGGL(k_orient_desc, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, d_levels, b, out_kp,
                        out_desc, cap, out_n, pf_d, n_frames);
