@@ -550,7 +550,7 @@ static OrbxBuffers offset_buffers(const OrbxBuffers &a, int f0, int kcap_total)
 }
 
 static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs, int l0_pitch, int f0, int n_frames,
-                   orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n, bool t, int slot)
+                   orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n, bool t, int slot, bool latency)
 {
     const OrbxLevels &LV = c->levels;
     const int L = LV.n_levels;
@@ -590,7 +590,9 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     // A call with a few frames is a chain of latency-bound kernels: level 0 (a third of the pixels, the longest quadtree)
     // then runs FAST -> quadtree on the side stream next to resize -> FAST -> quadtree of the other levels, and the blur
     // takes a stream of its own (slot 7 is free whenever the whole batch is on slot 8).
-    const bool split = early && slot == 8 && !strips && c->split_level0;
+    // (only for the synchronous host entry points: on the asynchronous device entry point, where calls pipeline, the extra
+    // cross-stream waits cost throughput -- 4.5 k against 7.0 k single-frame steps per second)
+    const bool split = latency && early && slot == 8 && !strips && c->split_level0;
     const int bslot = split ? 7 : slot;
     if (!split) HIP_TRY(hipMemsetAsync(b.cand_count, 0, sizeof(int) * ORBX_MAX_LEVELS * n_frames, s));
     if (split) {
@@ -669,16 +671,16 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
 // whole batch on one stream, or split into frame ranges on the handle's sub-streams (forked from and joined
 // back into `s` with events, so the caller still sees one in-order stream)
 static int enqueue_batch(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs, int l0_pitch, int n_frames,
-                         orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n)
+                         orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n, bool latency)
 {
     c->last_l0 = d_l0; c->last_l0_fs = l0_fs; c->last_l0_pitch = l0_pitch; c->last_frames = n_frames;
     const int ns = c->timing ? 1 : std::min(c->n_sub, n_frames / 8);
-    if (ns <= 1) return enqueue(c, s, d_l0, l0_fs, l0_pitch, 0, n_frames, d_kp, d_desc, cap, d_n, c->timing != 0, 8);
+    if (ns <= 1) return enqueue(c, s, d_l0, l0_fs, l0_pitch, 0, n_frames, d_kp, d_desc, cap, d_n, c->timing != 0, 8, latency);
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     for (int i = 0; i < ns; ++i) {
         const int f0 = (int)((long long)n_frames * i / ns), f1 = (int)((long long)n_frames * (i + 1) / ns);
         HIP_TRY(hipStreamWaitEvent(c->sub[i], c->ev_fork, 0));
-        int rc = enqueue(c, c->sub[i], d_l0, l0_fs, l0_pitch, f0, f1 - f0, d_kp, d_desc, cap, d_n, false, i);
+        int rc = enqueue(c, c->sub[i], d_l0, l0_fs, l0_pitch, f0, f1 - f0, d_kp, d_desc, cap, d_n, false, i, false);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(c->ev_join[i], c->sub[i]));
         HIP_TRY(hipStreamWaitEvent(s, c->ev_join[i], 0));
@@ -695,7 +697,7 @@ extern "C" int orbx_extract_batch_device(orbx_t *c, const uint8_t *d_imgs, int n
     int rc = ensure_geometry(c, width, height, n_frames, 0);
     if (rc) return rc;
     return enqueue_batch(c, stream ? (hipStream_t)stream : c->stream, d_imgs, frame_stride, stride, n_frames, d_kp,
-                         d_desc, cap, d_n);
+                         d_desc, cap, d_n, false);
 }
 
 extern "C" int orbx_synchronize(orbx_t *c)
@@ -764,7 +766,7 @@ extern "C" int orbx_extract_batch(orbx_t *c, const uint8_t *imgs, int n_frames, 
     };
     // (Replaying the call as one captured hipGraph -- kernels on three streams plus the record copy -- was measured and is
     // not used: 295 us per 1242x375 frame against 218 us for the eager launches, ROCm 7.2.)
-    rc = enqueue_batch(c, s, c->d_l0_stage, l0_fs, l0_pitch, n_frames, c->d_out_kp, c->d_out_desc, scap, c->d_out_n);
+    rc = enqueue_batch(c, s, c->d_l0_stage, l0_fs, l0_pitch, n_frames, c->d_out_kp, c->d_out_desc, scap, c->d_out_n, true);
     if (rc) return rc;
     if (c->h_out_block) { rc = copy_records(); if (rc) return rc; }
     tr.mark("kernel launches");

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one GPU-box call: PMC passes + kernel stats (profile_round.sh), the bench line
+# with those PMC files in place, per-kernel breakdowns, the batch sweep and the latency tools.  Output under gpurun_out/round/.
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$ROOT/gpurun_out/round
+mkdir -p $O
+cd $ROOT
+bash tools/profile_round.sh > $O/profile_round.log 2>&1 || { tail -5 $O/profile_round.log; exit 1; }
+cp gpurun_out/prof/pmc_traffic.json gpurun_out/prof/pmc_valu.json profiles/   # the bench line below replays them
+echo "pmc done"
+python3 bench.py > $O/final_bench.json 2> $O/final_bench.err || { tail -5 $O/final_bench.err; exit 1; }
+echo "bench done: $(cut -c1-160 $O/final_bench.json)"
+bash tools/kernel_stats.sh > $O/kernel_stats_overlapped.txt 2>&1; echo "kernel stats done"
+bash tools/sq_breakdown.sh > $O/sq.log 2>&1; cp gpurun_out/sq_breakdown.txt $O/; echo "sq done"
+bash tools/lds_breakdown.sh > $O/lds.log 2>&1; cp gpurun_out/lds_breakdown.txt $O/; echo "lds done"
+bash tools/batch_sweep.sh > $O/batch_sweep.txt 2> $O/batch_sweep.err; echo "sweep done"
+{ python3 tools/latency.py 1242 375 2000; python3 tools/latency.py 752 480 1000; python3 tools/latency.py 1920 1080 2000; bash tools/latency_c.sh; } 2>&1 | grep -v amdgpu.ids > $O/single_frame_latency.txt; echo "latency done"
+python3 tools/match_latency.py 2>&1 | grep -v amdgpu.ids > $O/match_latency.txt; echo "match latency done"
+python3 tools/octree_phases.py 1 2>&1 | grep -v amdgpu.ids > $O/octree_phases.txt || true
+cp gpurun_out/prof/*_counter_collection.csv gpurun_out/prof/kernel_stats.csv gpurun_out/prof/bench_under_rocprof.json $O/
+ls $O
