@@ -762,6 +762,17 @@ extern "C" int orbm_best2(orbm_t *c, const uint8_t *a, int na, const uint8_t *b,
 
 // distances for per-query candidate lists; the lists may alias each other (queries of one BoW
 // node share the node's candidate list), outputs are disjoint
+struct PhaseTrace { // ORBM_TRACE=1: host time stamps of the phases of a window search on stderr
+    bool on; std::chrono::steady_clock::time_point t0;
+    PhaseTrace() : on(getenv("ORBM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[orbm] %-24s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - t0).count());
+        t0 = t;
+    }
+};
+
 static int hamming_lists(orbm_ctx *c, const uint8_t *a, int na, const uint8_t *b, int nb,
                          const std::vector<int32_t> &q_idx, const std::vector<int32_t> &c_begin,
                          const std::vector<int32_t> &c_len, const std::vector<int32_t> &out_begin,
@@ -997,10 +1008,12 @@ extern "C" int orbm_search_by_bow(orbm_t *c, float nn_ratio, int check_orientati
         return orbx_set_error(ORBX_E_ARG, "null argument");
     *n_matches = 0;
     if (n1 <= 0 || n2 <= 0) return ORBX_OK;
+    PhaseTrace tr;
     std::vector<NodePair> nodes;
     shared_nodes(fv1, fv2, nodes);
     NodeQueries q;
     build_node_queries(fv1, fv2, nodes, kf_mp_ok, nullptr, q);
+    tr.mark("bow: node queries");
     // The device returns, per key-frame feature, the TOPK closest candidates of its node among the frame features
     // that are free when the call starts.  The reference's sequential loop only ever needs the two closest
     // candidates that are STILL free (:150-161); they are the first two unmatched entries of that sorted list.
@@ -1019,8 +1032,9 @@ extern "C" int orbm_search_by_bow(orbm_t *c, float nn_ratio, int check_orientati
         rc = hamming_lists(c, desc1, n1, desc2, n2, q.q_idx, q.c_begin, q.c_len, q.out_begin,
                            reinterpret_cast<const int32_t *>(fv2->indices), (size_t)fv2->offsets[fv2->n_nodes], q.n_out, dist);
     if (rc) return rc;
+    tr.mark("bow: device top-k");
     RotHist rh;
-    int num = 0;
+    int num = 0, n_rescans = 0;
     for (size_t k = 0; k < q.q_idx.size(); ++k) {
         const int idx1 = q.q_idx[k];
         const uint32_t *cand = fv2->indices + q.c_begin[k];
@@ -1029,19 +1043,28 @@ extern "C" int orbm_search_by_bow(orbm_t *c, float nn_ratio, int check_orientati
         if (!long_list) {
             int found = 0;
             bool exhausted = false; // saw the end-of-list sentinel: no further free candidate exists
+            int last_dd = 0; // distance of the last list entry looked at: no free candidate outside the list is closer
             for (int r = 0; r < TOPK && found < 2; ++r) {
                 const uint32_t key = topk[k * TOPK + r];
                 if (key == 0xFFFFFFFFu) { exhausted = true; break; }
                 const int idx2 = (int)cand[key & 0xFFFF], dd = (int)(key >> 16);
+                last_dd = dd;
                 if (frame_mp[idx2] != -1) continue; // taken by an earlier match of this call (:150)
                 if (found == 0) { if (dd < 256) { bestDist = dd; bestIdx2 = idx2; } }
                 else secondDist = std::min(dd, 256);
                 ++found;
             }
-            // decided if both were seen, if the list ended, or if the best already fails the threshold (:164)
+            // decided if both were seen, if the list ended, if the best already fails the threshold (:164) -- or if the best
+            // passes the ratio test even against the smallest value the unseen second best can have (the list is sorted, so
+            // that is the distance of its last entry; the second distance is used for nothing but this test)
             resolved = found == 2 || exhausted || (found == 1 && bestDist > ORBM_TH_LOW);
+            if (!resolved && found == 1 && (float)bestDist < nn_ratio * (float)std::min(last_dd, 256)) {
+                secondDist = std::min(last_dd, 256);
+                resolved = true;
+            }
         }
         if (!resolved) {
+            ++n_rescans;
             bestDist = 256; secondDist = 256; bestIdx2 = -1;
             for (int t = 0; t < q.c_len[k]; ++t) {
                 const int idx2 = (int)cand[t];
@@ -1058,6 +1081,8 @@ extern "C" int orbm_search_by_bow(orbm_t *c, float nn_ratio, int check_orientati
             if (check_orientation) rh.add(angle1[idx1], angle2[bestIdx2], bestIdx2);
         }
     }
+    if (tr.on) fprintf(stderr, "[orbm] bow: %zu queries, TOPK %d, %d rows rescanned on the host\n", q.q_idx.size(), TOPK, n_rescans);
+    tr.mark("bow: greedy replay");
     if (check_orientation) {
         int i1, i2, i3;
         rh.keep3(&i1, &i2, &i3);
@@ -1109,15 +1134,19 @@ extern "C" int orbm_search_for_triangulation(orbm_t *c, int check_orientation, c
         int bestDist = ORBM_TH_LOW, bestIdx2 = -1;
         bool resolved = false;
         if (!long_list) {
+            int last_dd = 0;
             for (int r = 0; r < TOPK; ++r) {
                 const uint32_t key = topk[k * TOPK + r];
                 if (key == 0xFFFFFFFFu) { resolved = true; break; }
                 const int idx2 = (int)cand[key & 0xFFFF], dd = (int)(key >> 16);
+                last_dd = dd;
                 if (matched2[idx2]) continue; // :466 -- matched earlier in this call
                 if (dd < bestDist) { bestIdx2 = idx2; bestDist = dd; }
                 resolved = true;
                 break;
             }
+            // the whole list is taken, but it is sorted: nothing outside it is closer than its last entry
+            if (!resolved && last_dd >= ORBM_TH_LOW) resolved = true;
         }
         if (!resolved) {
             for (int t = 0; t < q.c_len[k]; ++t) {
@@ -1204,16 +1233,6 @@ struct WindowQueries {
 // path q.e is the pinned copy-out buffer of the context, read in place (valid until the context's next call).
 //   device path (default): ONE pinned staging copy in, grid build + one wave per query on the device, ONE copy out;
 //   host path (ORBM_WINDOW=host, or a window longer than `cap`): FrameGrid::area on the host + k_hamming_lists.
-struct PhaseTrace { // ORBM_TRACE=1: host time stamps of the phases of a window search on stderr
-    bool on; std::chrono::steady_clock::time_point t0;
-    PhaseTrace() : on(getenv("ORBM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
-    void mark(const char *what) {
-        if (!on) return;
-        const auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[orbm] %-24s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - t0).count());
-        t0 = t;
-    }
-};
 
 static int window_candidates(orbm_ctx *c, bool strict, const float *sigma2, int n_sigma, int cap, const uint8_t *q_desc,
                              const float *q_xy, const float *q_radius, const int32_t *q_min, const int32_t *q_max,
