@@ -222,6 +222,7 @@ typedef int bm_v16i __attribute__((ext_vector_type(16)));
 #ifndef BM_TC
 #define BM_TC 128  // candidates per stage (four 32-row MFMA tiles)
 #endif
+#define BM_MAX_CAND 8160 // 255 tiles of 32: (16 tile + register) must stay below 4096 in the key
 #define BM_ROWB 272 // bytes per unpacked candidate in LDS: 256 + 16 so that the 32 rows of a tile fall in different banks
 // a * m + c with 24-bit signed factors; c is wave-uniform (a VOP3 instruction of gfx9 reads at most one SGPR)
 __device__ __forceinline__ uint32_t bm_mad24(int a, int m, uint32_t c)
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(BM_WAVES * 64) void k_best2_mfma(const uint8_t *__r
     const uint8_t *A = a + (size_t)p * a_stride * 32;
     const uint8_t *B = b + (size_t)p * b_stride * 32;
 
-    // ---- this lane's query as the B operand of the 8 steps: +1 / -1 bytes, and -popcount as the accumulator seed
+    // ---- this lane's query as the B operand of the 8 steps: +64 / -64 bytes (the candidates are 0 / 64, so the MFMA leaves
+    // 4096 x (popcount(query) - hamming) and the low 12 bits are free for the candidate's place)
     bm_v4i bq[8];
     int pcq = 0;
     {
@@ -259,14 +261,20 @@ __global__ __launch_bounds__(BM_WAVES * 64) void k_best2_mfma(const uint8_t *__r
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t d = (w >> (j + 4 * h)) & 0x01010101u;
-                bq[t][j] = (int)(((d ^ 0x01010101u) * 0xFFu) | d);
+                bq[t][j] = (int)(0xC0C0C0C0u - (d << 7)); // bit set: +64, clear: -64
             }
         }
     }
-    // hamming = popcount(query) - acc, and the popcount is the same for everything a lane sees: the running state orders
-    // candidates by key = (256 - acc) << 22 | (tile * 16 + register) and the popcount comes in at the very end
-    const uint32_t SENT = 0xFFFFFFFFu;
-    uint32_t k1 = SENT, k2 = SENT; // the two smallest keys seen so far
+    // Keys: key = BIAS + 4096 acc + 15 - r   (acc = popcount(query) - hamming, r = accumulator register) is ONE plain
+    // addition of a literal per register (a multiply-add in the slow VOP3 class before).  The larger key is the closer
+    // candidate, ties go to the lower register.  Tiles are told apart by keeping the running state (the two LARGEST keys
+    // seen) in the frame of the tile being processed: true key = key - 16 tile, so the state moves up by 16 when the wave
+    // moves to the next tile (two additions per tile).  16 tile + r stays below 4096: at most 255 tiles = 8160 candidates
+    // per problem.  (Seeding the accumulators with BIAS + 15 - r instead makes the keys free, but its 16 extra registers
+    // cost the second workgroup per CU: 0.57 ms against 0.49.)
+    const uint32_t BIAS = 1u << 30, NONE = 1u << 29; // keys are above 2^30 - 2^21; a state below NONE holds no candidate
+    uint32_t k1 = 0, k2 = 0; // the two largest keys, in the frame of tile `frame`
+    int frame = 0;
 
     // ---- staging: thread = (candidate tid / 8 (+ multiples of the workgroup's 8 per wave) of the stage, descriptor dword
     // tid % 8) -> 32 unpacked bytes each
@@ -280,15 +288,15 @@ __global__ __launch_bounds__(BM_WAVES * 64) void k_best2_mfma(const uint8_t *__r
         }
 #pragma unroll
         for (int q = 0; q < BM_TC / (BM_WAVES * 8); ++q) {
+            const uint32_t M = 0x40404040u;
             uint4 lo, hi;
-            lo.x = w[q] & 0x01010101u;        lo.y = (w[q] >> 1) & 0x01010101u; lo.z = (w[q] >> 2) & 0x01010101u; lo.w = (w[q] >> 3) & 0x01010101u;
-            hi.x = (w[q] >> 4) & 0x01010101u; hi.y = (w[q] >> 5) & 0x01010101u; hi.z = (w[q] >> 6) & 0x01010101u; hi.w = (w[q] >> 7) & 0x01010101u;
+            lo.x = (w[q] << 6) & M; lo.y = (w[q] << 5) & M; lo.z = (w[q] << 4) & M; lo.w = (w[q] << 3) & M;
+            hi.x = (w[q] << 2) & M; hi.y = (w[q] << 1) & M; hi.z = w[q] & M;        hi.w = (w[q] >> 1) & M;
             uint4 *dst = reinterpret_cast<uint4 *>(&sb[buf][((BM_WAVES * 8) * q + sr) * BM_ROWB + st * 32]);
             dst[0] = lo; dst[1] = hi;
         }
     };
     const int n_steps = (nb + BM_TC - 1) / BM_TC;
-    const int mult = -(1 << 22);
     if (n_steps > 0) stage(0, 0);
     __syncthreads();
     for (int s = 0; s < n_steps; ++s) {
@@ -309,44 +317,55 @@ __global__ __launch_bounds__(BM_WAVES * 64) void k_best2_mfma(const uint8_t *__r
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const int tile = (BM_TC / 32) * s + 2 * pair + sub, nvalid = nb - tile * 32; // candidates of this tile that exist
-                const uint32_t kbase = (256u << 22) + (uint32_t)tile * 16u;
+                if (nvalid <= 0) continue;
+                const uint32_t adv = 16u * (uint32_t)(tile - frame); // into this tile's frame
+                k1 += adv; k2 += adv;
+                frame = tile;
                 if (nvalid >= 32) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const uint32_t k = bm_mad24(acc[sub][r], mult, kbase + r);
+                        const uint32_t k = (uint32_t)acc[sub][r] + (BIAS + 15u - (uint32_t)r);
                         k2 = med3_u32(k, k1, k2);
-                        k1 = min(k, k1);
+                        k1 = max(k, k1);
                     }
-                } else if (nvalid > 0) {
+                } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        uint32_t k = bm_mad24(acc[sub][r], mult, kbase + r);
-                        if ((r & 3) + 8 * (r >> 2) + 4 * h >= nvalid) k = SENT; // accumulator row of register r (C/D layout)
+                        uint32_t k = (uint32_t)acc[sub][r] + (BIAS + 15u - (uint32_t)r);
+                        if ((r & 3) + 8 * (r >> 2) + 4 * h >= nvalid) k = 0; // accumulator row of register r (C/D layout)
                         k2 = med3_u32(k, k1, k2);
-                        k1 = min(k, k1);
+                        k1 = max(k, k1);
                     }
                 }
             }
         }
         __syncthreads();
     }
-    // ---- the lane pair (n, n + 32) holds one query's two halves: turn (tile, register) into the candidate index, merge
+    // ---- decode (distance, candidate) of both states, make them comparable across the lane pair (n, n + 32) that holds
+    // one query's two halves -- final key = (acc + 256) << 13 | (8191 - candidate), 0 = none -- and merge
+    auto final_key = [&](uint32_t sk) -> uint32_t {
+        if (sk < NONE) return 0u;
+        const int t2 = (int)(sk - 16u * (uint32_t)frame - BIAS) - 15;       // 4096 acc - (16 tile + r)
+        const int acc = (t2 + 4095) >> 12;                                  // ceil: 0 <= 16 tile + r < 4096
+        const uint32_t i16 = (uint32_t)(4096 * acc - t2), r = i16 & 15u, tile = i16 >> 4;
+        const uint32_t cand = tile * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
+        return ((uint32_t)(acc + 256) << 13) | (8191u - cand);
+    };
+    uint32_t f1 = final_key(k1), f2 = final_key(k2);
     {
-        const uint32_t r = k1 & 15u, tile = (k1 & 0x3FFFFFu) >> 4;
-        if (k1 != SENT) k1 = (k1 & ~0x3FFFFFu) | (tile * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h);
-        const uint32_t o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32);
-        k2 = min(min(k2, o2), max(k1, o1));
-        k1 = min(k1, o1);
+        const uint32_t o1 = __shfl_xor(f1, 32), o2 = __shfl_xor(f2, 32);
+        f2 = max(max(f2, o2), min(f1, o1));
+        f1 = max(f1, o1);
     }
     const int row = row0 + n;
     if (h == 0 && row < na_max) {
         const size_t orow = (size_t)p * a_stride + row;
         const bool live = row < na && (!row_ok || row_ok[orow]);
-        // key >> 22 = 256 - acc = 256 - popcount(query) + hamming
-        const uint32_t d1 = k1 == SENT ? 256u : (k1 >> 22) + (uint32_t)pcq - 256u;
-        const uint32_t ss = k2 == SENT ? 256u : (k2 >> 22) + (uint32_t)pcq - 256u;
+        // hamming = popcount(query) - acc
+        const uint32_t d1 = f1 == 0 ? 256u : (uint32_t)(pcq - ((int)(f1 >> 13) - 256));
+        const uint32_t ss = f2 == 0 ? 256u : (uint32_t)(pcq - ((int)(f2 >> 13) - 256));
         // a 256-distance candidate never beats the initial 256 of the reference loop
-        best_idx[orow] = (live && d1 < 256) ? (int32_t)(k1 & 0x3FFFFFu) : -1;
+        best_idx[orow] = (live && d1 < 256) ? (int32_t)(8191u - (f1 & 8191u)) : -1;
         best[orow] = live ? (uint16_t)min(d1, 256u) : (uint16_t)256;
         second[orow] = live ? (uint16_t)min(ss, 256u) : (uint16_t)256;
     }
@@ -717,7 +736,7 @@ extern "C" int orbm_best2_device(orbm_t *c, int n_pairs, const uint8_t *d_a, siz
     // the matrix-pipe kernel takes every problem without a candidate mask and fewer than 2^19 * 32 candidates;
     // ORBM_BEST2=valu keeps everything on the VALU kernel (its parity twin)
     static const bool use_mfma = [] { const char *e = getenv("ORBM_BEST2"); return !(e && strcmp(e, "valu") == 0); }();
-    if (use_mfma && !d_col_ok && nb_max < (1 << 22)) {
+    if (use_mfma && !d_col_ok && nb_max <= BM_MAX_CAND) {
         dim3 grid((na_max + BM_WAVES * 32 - 1) / (BM_WAVES * 32), n_pairs);
         hipLaunchKernelGGL(k_best2_mfma, grid, dim3(BM_WAVES * 64), 0, s, d_a, a_stride, d_na, na_max, d_b, b_stride, d_nb,
                            nb_max, d_row_ok, d_best_idx, d_best, d_second);
