@@ -1,0 +1,18 @@
+#!/bin/bash
+# Copy what tools/collect_round.sh left under gpurun_out/round/ into profiles/ under this round's names.  usage: publish_round.sh r02
+set -e
+T=${1:?round tag, e.g. r02}
+R=gpurun_out/round
+cp $R/final_bench.json profiles/${T}_final_bench.json
+cp $R/bench_under_rocprof.json profiles/${T}_final_bench_under_rocprof.json
+cp $R/kernel_stats.csv profiles/${T}_final_kernel_stats.csv
+cp $R/kernel_stats_overlapped.txt profiles/${T}_kernel_stats_overlapped.txt
+cp $R/sq_breakdown.txt profiles/${T}_sq_breakdown.txt
+cp $R/lds_breakdown.txt profiles/${T}_lds_breakdown.txt
+cp $R/batch_sweep.txt profiles/${T}_batch_sweep.txt
+cp $R/single_frame_latency.txt profiles/${T}_single_frame_latency.txt
+cp $R/match_latency.txt profiles/${T}_match_latency.txt
+cp $R/octree_phases.txt profiles/${T}_octree_phases.txt
+mkdir -p profiles/${T}_pmc
+cp $R/*_counter_collection.csv profiles/${T}_pmc/
+cp gpurun_out/prof/pmc_traffic.json gpurun_out/prof/pmc_valu.json profiles/
