@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
             const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1h, w1l, sel[i])), cv, 0u, false);
             const int v = (((int)__umul24((uint32_t)b0[r], (uint32_t)(r0 >> 4)) >> 16) +
                            ((int)__umul24((uint32_t)b1[r], (uint32_t)(r1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 255) << (8 * i);
+            packed |= (uint32_t)v << (8 * i); // v <= 255: the taps of each pass sum to 2048
         }
         // rows of the arena are 64-byte aligned and padded, so the dword store is always in bounds
         *reinterpret_cast<uint32_t *>(D + (size_t)(dy0 + r) * dst_pitch + dx0) = packed;
