@@ -156,6 +156,19 @@ def test_other_constructor_arguments(oracle_mod, nf, sf, levels, ini, mn):
     _check_frame(ex, orc, img, kps, desc, stages=True)
 
 
+@pytest.mark.parametrize("nf,sf,levels,ini,mn,w,h", [(800, 1.5, 4, 30, 10, 640, 360), (1200, 1.1, 12, 12, 5, 640, 360),
+                                                     (2000, 1.2, 8, 20, 7, 1242, 375), (1000, 1.3, 6, 15, 15, 1000, 163)])
+def test_batch_path_with_other_arguments(oracle_mod, nf, sf, levels, ini, mn, w, h):
+    """The throughput path (a host batch of 26 frames: FAST per strip, Gaussian on the matrix pipe, two-launch orientation)
+    with pyramid depths / scales / thresholds / widths other than the benchmark's; every stage of three of the frames."""
+    B = 26
+    ex, orc = _mk(oracle_mod, nf, w, h, ini=ini, mn=mn, n_levels=levels, sf=sf, batch=B)
+    imgs = synth.make_frames(B, w, h, seed=levels * 101 + w)
+    res = ex.extract_batch(imgs)
+    for f in (0, 11, B - 1):
+        _check_frame(ex, orc, imgs[f], res[f][0], res[f][1], frame=f, stages=True)
+
+
 @pytest.mark.parametrize("ini,mn,kind", [(5, 2, "noise"), (2, 1, "noise"), (2, 1, "scene"), (3, 3, "noise"), (40, 1, "scene"),
                                          (254, 200, "noise")])
 @pytest.mark.parametrize("variant", ["3", "1"])  # 3 = one wave per strip of cells (batches), 1 = one wave per cell (few frames)
