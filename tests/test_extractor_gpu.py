@@ -65,6 +65,12 @@ def test_batch_host(oracle_mod):
     res = ex.extract_batch(imgs)
     for f in range(4):
         _check_frame(ex, orc, imgs[f], res[f][0], res[f][1], frame=f, stages=(f in (0, 3)))
+    # fewer frames than the handle was laid out for (the records then come back in three pieces instead of one), then one
+    res2 = ex.extract_batch(imgs[1:3])
+    for f in range(2):
+        _check_frame(ex, orc, imgs[1 + f], res2[f][0], res2[f][1], frame=f, stages=False)
+    kps, desc = ex(imgs[3])
+    _check_frame(ex, orc, imgs[3], kps, desc, stages=True)
 
 
 def test_requota_initial_extractor(oracle_mod):
