@@ -416,7 +416,7 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
         const char *f = getenv("ORBX_EARLY_FAST");
         c->early_fast = f ? atoi(f) : 1;
         const char *sp = getenv("ORBX_SPLIT_LEVEL0");
-        c->split_level0 = sp ? atoi(sp) : 1;
+        c->split_level0 = sp ? atoi(sp) : 4;
         const char *fv = getenv("ORBX_FAST_VARIANT");
         c->fast_variant = fv ? atoi(fv) : 2;
         const char *bl = getenv("ORBX_BLUR");
@@ -599,20 +599,28 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         // The host needs 2-3 us per launch, about what a small resize takes on the device: the chain the call waits for
         // (resize x7 -> FAST -> quadtree of levels 1..) is issued first and back to back, the two side chains (level 0;
         // the blur) afterwards -- they have started long before the main chain needs them.
+        // Levels 0 .. G-1 (most of the pixels) do not wait for the end of the resize chain: their FAST and quadtree run on the
+        // side stream as soon as level G-1 exists, beside the resizes -- and then the FAST and quadtree -- of the small
+        // levels.  (A stream of its own for levels 1 .. G-1 was measured: with a fourth stream the call takes 200 us, not
+        // 160 -- the runtime maps streams onto four hardware queues.)
+        const int G = std::min(std::max(c->split_level0, 1), L - 1); // first level of the main chain's FAST / quadtree (ORBX_SPLIT_LEVEL0, default 4)
+        int cells_before[ORBX_MAX_LEVELS + 1];
+        cells_before[0] = 0;
+        for (int l = 0; l < L; ++l) cells_before[l + 1] = cells_before[l] + LV.lv[l].n_cols * LV.lv[l].n_rows;
         for (int l = 1; l < L; ++l) {
             const uint8_t *sp; size_t sfs; int spitch;
             raw(l - 1, &sp, &sfs, &spitch);
             orbx_launch_resize(s, sp, sfs, spitch, LV.lv[l - 1].w, LV.lv[l - 1].h, b.img_arena + LV.lv[l].raw_off,
                                b.img_frame_stride, LV.lv[l].pitch, LV.lv[l].w, LV.lv[l].h, c->d_xtap[l], c->d_ytap[l],
                                n_frames, l == 1 ? b.cand_count : nullptr); // the first one clears the candidate counters
-            if (l == 1) HIP_TRY(hipEventRecord(c->ev_start[slot], s));    // ... which are zero from here on
+            if (l == std::max(G - 1, 1)) HIP_TRY(hipEventRecord(c->ev_start[slot], s)); // counters are zero, levels < G exist
         }
         HIP_TRY(hipEventRecord(c->ev_pyr[bslot], s));
-        launch_fast(s, d_units + 4 * n_cells0, n_units - n_cells0);
-        orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 1, L);
+        if (cells_before[L] > cells_before[G]) launch_fast(s, d_units + 4 * cells_before[G], cells_before[L] - cells_before[G]);
+        orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, G, L);
         HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_start[slot], 0));
-        launch_fast(c->side[slot], d_units, n_cells0);
-        orbx_launch_octree(c->side[slot], c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, 1);
+        launch_fast(c->side[slot], d_units, cells_before[G]);
+        orbx_launch_octree(c->side[slot], c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, G);
         HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
         HIP_TRY(hipStreamWaitEvent(c->side[bslot], c->ev_pyr[bslot], 0));
         launch_blur(c->side[bslot], 0, L);
