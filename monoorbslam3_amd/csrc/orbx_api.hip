@@ -59,7 +59,7 @@ struct orbx_ctx {
     uint8_t *d_l0_stage; size_t l0_stage_fs;
     // host-API output staging, one device block: [counts, 256 B aligned][key points][descriptors]; `h_out_block` is its
     // pinned mirror while the block is small (a few frames): the records then come back in one copy and one wait
-    uint8_t *d_out_block; uint8_t *h_out_block; size_t out_block_bytes, out_kp_off, out_desc_off;
+    uint8_t *d_out_block; uint8_t *h_out_block; uint8_t *h_out_dev; size_t out_block_bytes, out_kp_off, out_desc_off;
     orbx_kp *d_out_kp; uint8_t *d_out_desc; int32_t *d_out_n; int out_cap;
     // capacities actually allocated
     int alloc_batch;
@@ -299,7 +299,14 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
         c->d_out_kp = reinterpret_cast<orbx_kp *>(c->d_out_block + c->out_kp_off);
         c->d_out_desc = c->d_out_block + c->out_desc_off;
         if (c->h_out_block) { (void)hipHostFree(c->h_out_block); c->h_out_block = nullptr; }
-        if (c->out_block_bytes <= (size_t)4 << 20) HIP_TRY(hipHostMalloc((void **)&c->h_out_block, c->out_block_bytes, hipHostMallocDefault));
+        c->h_out_dev = nullptr;
+        if (c->out_block_bytes <= (size_t)4 << 20) {
+            HIP_TRY(hipHostMalloc((void **)&c->h_out_block, c->out_block_bytes, hipHostMallocMapped));
+            // the descriptor kernel writes a small call's records straight into this block (no copy back); ORBX_ZERO_COPY=0
+            // keeps them in HBM and copies
+            const char *z = getenv("ORBX_ZERO_COPY");
+            if (!(z && atoi(z) == 0)) HIP_TRY(hipHostGetDevicePointer((void **)&c->h_out_dev, c->h_out_block, 0));
+        }
         c->alloc_out_cap = cap;
     }
     if (!same) {
@@ -416,7 +423,7 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
         const char *f = getenv("ORBX_EARLY_FAST");
         c->early_fast = f ? atoi(f) : 1;
         const char *sp = getenv("ORBX_SPLIT_LEVEL0");
-        c->split_level0 = sp ? atoi(sp) : 4;
+        c->split_level0 = sp ? atoi(sp) : 1;
         const char *fv = getenv("ORBX_FAST_VARIANT");
         c->fast_variant = fv ? atoi(fv) : 2;
         const char *bl = getenv("ORBX_BLUR");
@@ -603,7 +610,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         // side stream as soon as level G-1 exists, beside the resizes -- and then the FAST and quadtree -- of the small
         // levels.  (A stream of its own for levels 1 .. G-1 was measured: with a fourth stream the call takes 200 us, not
         // 160 -- the runtime maps streams onto four hardware queues.)
-        const int G = std::min(std::max(c->split_level0, 1), L - 1); // first level of the main chain's FAST / quadtree (ORBX_SPLIT_LEVEL0, default 4)
+        const int G = std::min(std::max(c->split_level0, 1), L - 1); // first level of the main chain's FAST / quadtree (ORBX_SPLIT_LEVEL0, default 1: level 0 alone; 4 is 3 us better at 1242x375 and 17 us worse at 1920x1080)
         int cells_before[ORBX_MAX_LEVELS + 1];
         cells_before[0] = 0;
         for (int l = 0; l < L; ++l) cells_before[l + 1] = cells_before[l] + LV.lv[l].n_cols * LV.lv[l].n_rows;
@@ -774,9 +781,15 @@ extern "C" int orbx_extract_batch(orbx_t *c, const uint8_t *imgs, int n_frames, 
     };
     // (Replaying the call as one captured hipGraph -- kernels on three streams plus the record copy -- was measured and is
     // not used: 295 us per 1242x375 frame against 218 us for the eager launches, ROCm 7.2.)
-    rc = enqueue_batch(c, s, c->d_l0_stage, l0_fs, l0_pitch, n_frames, c->d_out_kp, c->d_out_desc, scap, c->d_out_n, true);
-    if (rc) return rc;
-    if (c->h_out_block) { rc = copy_records(); if (rc) return rc; }
+    if (c->h_out_dev) { // the last kernel writes the records into the pinned block itself
+        rc = enqueue_batch(c, s, c->d_l0_stage, l0_fs, l0_pitch, n_frames, reinterpret_cast<orbx_kp *>(c->h_out_dev + c->out_kp_off),
+                           c->h_out_dev + c->out_desc_off, scap, reinterpret_cast<int32_t *>(c->h_out_dev), true);
+        if (rc) return rc;
+    } else {
+        rc = enqueue_batch(c, s, c->d_l0_stage, l0_fs, l0_pitch, n_frames, c->d_out_kp, c->d_out_desc, scap, c->d_out_n, true);
+        if (rc) return rc;
+        if (c->h_out_block) { rc = copy_records(); if (rc) return rc; }
+    }
     tr.mark("kernel launches");
     int status = ORBX_OK;
     if (c->h_out_block) {
