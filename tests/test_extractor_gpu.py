@@ -341,3 +341,44 @@ def test_stream_layout_variants_give_identical_results(tmp_path):
         results[name] = subprocess.check_output([sys.executable, str(script)], env=e, text=True).strip().splitlines()[-1]
     assert len(set(results.values())) == 1, results
     assert int(results["default"].split()[0]) > 24 * 500
+
+
+def test_full_bench_batch_sampled_parity_and_checksum(oracle_mod):
+    """The benchmark's own shape: 512 resident 1242x375 frames, 2000 features, through the device entry point.  Two runs
+    give the same bytes (checksum over all counts, key points and descriptors), and sampled frames -- the first, the last,
+    two in the middle, one of them a noise-perturbed repeat as bench.py makes them -- equal the oracle's output."""
+    import hashlib
+    import torch
+    from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
+    w, h, nf, B, n_distinct = 1242, 375, 2000, 512, 16
+    base = synth.make_frames(n_distinct, w, h, seed=synth.DEFAULT_SEED + 5)
+    rng = np.random.RandomState(7)
+    imgs = np.repeat(base[None], B // n_distinct, axis=0).reshape(B, h, w).astype(np.int16)
+    imgs[n_distinct:] += rng.randint(-2, 3, imgs[n_distinct:].shape).astype(np.int16)
+    imgs = np.clip(imgs, 0, 255).astype(np.uint8)
+    ex = ORBExtractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    cap = ex.max_keypoints(w, h)
+    d_img = torch.from_numpy(imgs).cuda()
+    sums = []
+    for _ in range(2):
+        d_kp = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+        ex.synchronize()
+        n, kp, desc = d_n.cpu().numpy(), d_kp.cpu().numpy(), d_desc.cpu().numpy()
+        hsh = hashlib.sha256()
+        hsh.update(n.tobytes())
+        for f in range(B):
+            hsh.update(kp[f, :n[f]].tobytes())
+            hsh.update(desc[f, :n[f]].tobytes())
+        sums.append(hsh.hexdigest())
+    assert sums[0] == sums[1]
+    orc = oracle_mod.Oracle(nf, 1.2, 8, 20, 7)
+    for f in (0, 200, 301, B - 1):
+        ok, od, _ = orc.extract(imgs[f])
+        assert n[f] == len(ok)
+        got = kp[f, :n[f]].copy().view(KP_DTYPE).reshape(-1)
+        for fld in ("x", "y", "size", "angle", "response", "octave"):
+            assert np.array_equal(got[fld], ok[fld]), (f, fld)
+        assert np.array_equal(desc[f, :n[f]], od), f
