@@ -57,6 +57,7 @@ struct orbx_ctx {
     BlurMfmaLevels blur_tab; int blur_strips_before[ORBX_MAX_LEVELS + 1]; int blur_mfma_levels;
     int blur_mfma;                                              // ORBX_BLUR=valu switches it off
     uint8_t *d_l0_stage; size_t l0_stage_fs;
+    int *d_slot_level;                                          // level of every key-point slot of the current geometry
     // host-API output staging, one device block: [counts, 256 B aligned][key points][descriptors]; `h_out_block` is its
     // pinned mirror while the block is small (a few frames): the records then come back in one copy and one wait
     uint8_t *d_out_block; uint8_t *h_out_block; uint8_t *h_out_dev; size_t out_block_bytes, out_kp_off, out_desc_off;
@@ -282,6 +283,7 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
         HIP_TRY(dev_alloc(&b.sel, (size_t)kcap * B));
         HIP_TRY(dev_alloc(&b.kp_ang, (size_t)kcap * B));
         HIP_TRY(dev_alloc(&b.sel_count, (size_t)ORBX_MAX_LEVELS * B));
+        HIP_TRY(dev_alloc(&b.sel_prefix, (size_t)ORBX_MAX_LEVELS * B));
         HIP_TRY(dev_alloc(&c->d_l0_stage, l0_fs * B));
         c->alloc_batch = B; c->alloc_img_fs = img_fs; c->alloc_cand_fs = cand_fs; c->alloc_node_fs = node_fs;
         c->alloc_l0_fs = l0_fs; c->alloc_kcap_total = kcap;
@@ -316,6 +318,15 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
         c->l0_stage_pitch = g.l0_pitch;
         c->sort_lds_bytes = g.sort_lds;
         HIP_TRY(hipMemcpy(c->d_levels, &c->levels, sizeof(OrbxLevels), hipMemcpyHostToDevice));
+        {
+            std::vector<int> sl((size_t)std::max(c->levels.kcap_total, 1), 0);
+            for (int l = 0; l < c->levels.n_levels; ++l)
+                for (int k = c->levels.lv[l].kp_off; k < c->levels.lv[l].kp_off + c->levels.lv[l].kcap && k < c->levels.kcap_total; ++k)
+                    sl[k] = l;
+            HIP_TRY(dev_alloc(&c->d_slot_level, sl.size()));
+            HIP_TRY(hipMemcpy(c->d_slot_level, sl.data(), sl.size() * sizeof(int), hipMemcpyHostToDevice));
+            c->buf.slot_level = c->d_slot_level;
+        }
         {
             const int nc = orbx_build_fast_cells(c->levels, nullptr);
             std::vector<uint16_t> cells((size_t)std::max(nc, 1) * 4);
@@ -469,7 +480,7 @@ extern "C" void orbx_destroy(orbx_t *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     OrbxBuffers &b = c->buf;
     void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.pcode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
-                    b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.kp_ang, b.sel_count, c->d_levels, c->d_umax, c->d_taps,
+                    b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.kp_ang, b.sel_count, b.sel_prefix, c->d_slot_level, c->d_levels, c->d_umax, c->d_taps,
                     c->d_l0_stage, c->d_out_block, c->d_fast_cells, c->d_fast_strips, c->d_blur_tiles, c->d_blur_strips, c->d_band_h, c->d_band_v};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_out_block) (void)hipHostFree(c->h_out_block);
@@ -548,7 +559,7 @@ static OrbxBuffers offset_buffers(const OrbxBuffers &a, int f0, int kcap_total)
     const size_t f = (size_t)f0;
     b.img_arena += f * a.img_frame_stride;
     b.cand += f * a.cand_frame_stride; b.pnode += f * a.cand_frame_stride; b.pcode += f * a.cand_frame_stride;
-    b.cand_count += f * ORBX_MAX_LEVELS; b.sel_count += f * ORBX_MAX_LEVELS;
+    b.cand_count += f * ORBX_MAX_LEVELS; b.sel_count += f * ORBX_MAX_LEVELS; b.sel_prefix += f * ORBX_MAX_LEVELS;
     const size_t n = f * a.node_frame_stride;
     b.bnd0 += n; b.bnd1 += n; b.cnt0 += n; b.cnt1 += n; b.rank += n; b.node_of_rank += n; b.newpos += n; b.best += n;
     b.childcnt += 4 * n; b.childpos += 4 * n;

@@ -61,6 +61,8 @@ struct OrbxBuffers {
     unsigned long long *best;
     uint2 *sel;                                           // [frame][kcap_total] selected keypoints (x | y<<16, response)
     int *sel_count;                                       // [frame][level]
+    int *sel_prefix;                                      // [frame][level] key points of the levels before (written by k_orient)
+    const int *slot_level;                                // [kcap_total] level of a key-point slot (per geometry, not per frame)
     float4 *kp_ang;                                       // [frame][kcap_total] (angle, cos, sin, -) per selected keypoint
 };
 

@@ -2111,6 +2111,10 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, 
     const int tid = threadIdx.x, sub = tid & (OR_LANES - 1), grp = tid / OR_LANES;
     const int L = levels->n_levels, kc = levels->kcap_total;
     const int *cnts = b.sel_count + frame * ORBX_MAX_LEVELS;
+    if (blk == 0 && tid == 0) { // key points of the levels before each level: the descriptor kernel's output index starts there
+        int before = 0;
+        for (int l = 0; l < L; ++l) { b.sel_prefix[frame * ORBX_MAX_LEVELS + l] = before; before += cnts[l]; }
+    }
     const int slot = blk * OR_KP + grp;
     // Everything this thread needs before the patch loads is requested at once and without a branch -- the mask-table
     // entry's u_max, the key-point record (slot clamped), and through the scalar cache the level table and the per-level
@@ -2217,7 +2221,14 @@ __global__ __launch_bounds__(256) void k_angle(const OrbxLevels *__restrict__ le
 #define DP_W 64 // patch pitch: four ALIGNED 16-byte loads per row starting at floor16(x-19)
 #define DP_H 37
 #define DP_K 2  // keypoints per wave: their record / patch loads are all issued before the first use
-__global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restrict__ levels, OrbxBuffers b,
+struct DescLv { // what k_orient_desc needs of one level: 32 bytes = ONE scalar load from the kernel-argument segment
+    int kp_off, pitch;
+    float scale;
+    int pad;
+    unsigned long long blur_off, pad2;
+};
+struct DescTab { int n_levels, kcap_total, pad[2]; DescLv lv[ORBX_MAX_LEVELS]; };
+__global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
                                                      orbx_kp *__restrict__ out_kp, uint8_t *__restrict__ out_desc,
                                                      int cap, int32_t *__restrict__ out_n, int per_frame, int n_frames)
 {
@@ -2227,7 +2238,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
     int frame, blk;
     if (!xcd_remap(per_frame, n_frames, &frame, &blk)) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int L = levels->n_levels;
+    const int L = tab.n_levels;
     const int *cnts = b.sel_count + frame * ORBX_MAX_LEVELS;
     if (blk == 0 && threadIdx.x == 0) {
         int tot = 0;
@@ -2252,25 +2263,25 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
 #pragma unroll
     for (int k = 0; k < DP_K; ++k) {
         const int slot = slot0 + k;
-        live[k] = slot < levels->kcap_total;
-        int lvl = 0;
-        for (int l = 1; l < L; ++l) lvl += live[k] && slot >= levels->lv[l].kp_off;
+        live[k] = slot < tab.kcap_total;
+        // level of the slot from a per-geometry table, key points of the levels before from k_orient's prefix: a handful of
+        // scalar loads where two loops over the levels ran on the scalar unit (which this kernel kept as busy as the VALU)
+        const int lvl = live[k] ? b.slot_level[slot] : 0;
         level[k] = lvl;
-        const int i = slot - levels->lv[lvl].kp_off;
+        const DescLv lv = tab.lv[lvl]; // (an empty slot has level 0: the corner of blurred level 0 is what it stages)
+        const int i = slot - lv.kp_off;
         live[k] = live[k] && i < cnts[lvl];
-        int oi = i;
-        for (int l = 0; l < lvl; ++l) oi += cnts[l];
+        const int oi = i + b.sel_prefix[frame * ORBX_MAX_LEVELS + lvl];
         out_idx[k] = oi;
         live[k] = live[k] && oi < cap;
         rec[k] = make_uint2(0, 0);
         ang[k] = make_float4(0.f, 1.f, 0.f, 0.f);
         // a slot without a keypoint stages the top-left corner of the blurred level 0 (valid memory, never sampled), so
         // that the loads below need no branch
-        const OrbxLevel &lv = levels->lv[live[k] ? lvl : 0];
         int x = 19, y = 18;
         if (live[k]) {
-            rec[k] = b.sel[(size_t)frame * levels->kcap_total + slot];
-            ang[k] = b.kp_ang[(size_t)frame * levels->kcap_total + slot];
+            rec[k] = b.sel[(size_t)frame * tab.kcap_total + slot];
+            ang[k] = b.kp_ang[(size_t)frame * tab.kcap_total + slot];
             x = rec[k].x & 0xFFFF;
             y = rec[k].x >> 16;
         }
@@ -2307,7 +2318,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
 #pragma unroll
     for (int k = 0; k < DP_K; ++k) {
         if (!live[k]) continue;
-        const OrbxLevel &lv = levels->lv[level[k]];
+        const float lscale = tab.lv[level[k]].scale;
         const float a = ang[k].y, bb = ang[k].z;
         // cvRound (ties to even) without v_rndne + v_cvt: adding 1.5 * 2^23 makes the float add itself round to the nearest
         // integer (|value| <= 19 here), the integer is then the low mantissa bits.  The constant's bit pattern M is not
@@ -2337,8 +2348,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const OrbxLevels *__restric
             const int x = rec[k].x & 0xFFFF, y = rec[k].x >> 16;
             orbx_kp kp;
             float fx = (float)x, fy = (float)y;
-            if (level[k] != 0) { fx = ORB_FMUL(fx, lv.scale); fy = ORB_FMUL(fy, lv.scale); }
-            kp.x = fx; kp.y = fy; kp.size = lv.scale; kp.angle = ang[k].x; kp.response = (float)rec[k].y;
+            if (level[k] != 0) { fx = ORB_FMUL(fx, lscale); fy = ORB_FMUL(fy, lscale); }
+            kp.x = fx; kp.y = fy; kp.size = lscale; kp.angle = ang[k].x; kp.response = (float)rec[k].y;
             kp.octave = level[k]; kp.class_id = -1;
             out_kp[(size_t)frame * cap + out_idx[k]] = kp;
         }
@@ -2366,6 +2377,16 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
                            b, n_frames);
     }
     if (blur_done) (void)hipStreamWaitEvent(s, blur_done, 0); // the blurred levels come from a side stream
-    hipLaunchKernelGGL(k_orient_desc, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, d_levels, b, out_kp,
+    DescTab dt;
+    dt.n_levels = levels.n_levels; dt.kcap_total = levels.kcap_total; dt.pad[0] = dt.pad[1] = 0;
+    for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
+        const bool in = l < levels.n_levels;
+        dt.lv[l].kp_off = in ? levels.lv[l].kp_off : 0;
+        dt.lv[l].pitch = in ? levels.lv[l].pitch : 0;
+        dt.lv[l].scale = in ? levels.lv[l].scale : 1.f;
+        dt.lv[l].pad = 0; dt.lv[l].pad2 = 0;
+        dt.lv[l].blur_off = in ? (unsigned long long)levels.lv[l].blur_off : 0ull;
+    }
+    hipLaunchKernelGGL(k_orient_desc, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, dt, b, out_kp,
                        out_desc, cap, out_n, pf_d, n_frames);
 }
