@@ -382,3 +382,30 @@ def test_full_bench_batch_sampled_parity_and_checksum(oracle_mod):
         for fld in ("x", "y", "size", "angle", "response", "octave"):
             assert np.array_equal(got[fld], ok[fld]), (f, fld)
         assert np.array_equal(desc[f, :n[f]], od), f
+
+
+def _random_cases():
+    rng = np.random.RandomState(20261004)
+    cases = []
+    for i in range(14):
+        w = int(rng.randint(96, 900))
+        h = int(rng.randint(64, 500))
+        cases.append((i, w, h, int(rng.choice([300, 800, 1500, 2500])), float(rng.choice([1.1, 1.2, 1.25, 1.44])),
+                      int(rng.randint(2, 11)), int(rng.randint(5, 40)), int(rng.randint(2, 20)), int(rng.choice([1, 9, 25]))))
+    return cases
+
+
+@pytest.mark.parametrize("i,w,h,nf,sf,levels,ini,mn,B", _random_cases())
+def test_random_shapes_and_arguments(oracle_mod, i, w, h, nf, sf, levels, ini, mn, B):
+    """Seeded random frame sizes (odd widths, heights down to 64), feature counts, scale factors, pyramid depths and
+    thresholds, as a single call (latency path), 9 frames (per-cell FAST + matrix-pipe Gaussian) or 25 frames (throughput
+    path): every stage of the first frame and the records of the last against the oracle."""
+    ex, orc = _mk(oracle_mod, nf, w, h, ini=ini, mn=mn, n_levels=levels, sf=sf, batch=B)
+    imgs = synth.make_frames(B, w, h, seed=1000 + i)
+    if B == 1:
+        kps, desc = ex(imgs[0])
+        _check_frame(ex, orc, imgs[0], kps, desc, stages=True)
+        return
+    res = ex.extract_batch(imgs)
+    _check_frame(ex, orc, imgs[0], res[0][0], res[0][1], frame=0, stages=True)
+    _check_frame(ex, orc, imgs[B - 1], res[B - 1][0], res[B - 1][1], frame=B - 1, stages=False)
