@@ -44,9 +44,14 @@ int orbd_world(const orbd_t *c);
  * k-th frame.  Pure host arithmetic. */
 int orbd_shard_count(int n_frames, int rank, int world);
 int orbd_shard_global_index(int k, int rank, int world);
+/* ceil(n_frames / world): the size of the largest shard.  When n_frames % world != 0 the shards are uneven, but the
+ * exchanges below move equal blocks: every rank passes n_frames = orbd_shard_capacity(...) records and sets the count of
+ * the frames it does not own (k >= orbd_shard_count) to 0 -- d_n[k] = 0 is all the padding a record needs. */
+int orbd_shard_capacity(int n_frames, int world);
 
 /* Gather to `root`.  Every rank passes its own records (device pointers: d_n [n_frames], d_kp [n_frames][cap],
- * d_desc [n_frames][cap][32], the same n_frames and cap everywhere).  On the root the three *_all buffers
+ * d_desc [n_frames][cap][32]; n_frames and cap MUST be the same on every rank -- pass orbd_shard_capacity, not
+ * orbd_shard_count, when the batch does not divide evenly: mismatched sizes would hang the exchange).  On the root the three *_all buffers
  * (device, world x the local sizes, rank-major) receive them; other ranks may pass NULL.  Enqueued on `stream`
  * (hipStream_t, NULL = the default stream); no host synchronisation. */
 int orbd_gather_records(orbd_t *c, int root, int n_frames, int cap, const int32_t *d_n, const orbx_kp *d_kp,

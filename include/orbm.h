@@ -57,7 +57,10 @@ int orbm_hamming_matrix_device(orbm_t *h, const uint8_t *d_a, int na, const uint
  * both distances start at 256, best index -1 when no candidate.  row_ok / col_ok
  * (may be NULL) are byte masks: skipped queries return (-1,256,256); masked candidates
  * are not considered.  `n_pairs` independent (A,B) problems are processed in one launch:
- * problem p uses a + p*a_stride ... (strides in descriptors/elements).  Device pointers. */
+ * problem p uses a + p*a_stride ... (strides in descriptors/elements).  Device pointers.
+ * Which kernel runs: problems without a candidate mask (d_col_ok == NULL) and nb_max <= 8160 take the matrix-pipe
+ * kernel (k_best2_mfma); a candidate mask, more candidates, or ORBM_BEST2=valu in the environment take the VALU
+ * kernel (k_best2).  Both give the same outputs; only the speed differs. */
 int orbm_best2_device(orbm_t *h, int n_pairs, const uint8_t *d_a, size_t a_stride, const int32_t *d_na, int na_max,
                       const uint8_t *d_b, size_t b_stride, const int32_t *d_nb, int nb_max,
                       const uint8_t *d_row_ok, const uint8_t *d_col_ok, int32_t *d_best_idx, uint16_t *d_best,

@@ -116,6 +116,10 @@ int orbx_tap_candidates(orbx_t *h, int frame, int level, uint16_t *xs, uint16_t 
 /* per-level keypoint counts after the quadtree */
 int orbx_tap_level_counts(orbx_t *h, int frame, int32_t *counts);
 
+/* the device's evaluation of `cos(angle)`, `sin(angle)` of computeOrbDescriptor (modules/ORB/ORBExtractor.cpp:53-54,
+ * i.e. glibc cosf / sinf of angle_deg * (float)(CV_PI / 180.f)) on n host angles; cos_sin receives n (cos, sin) pairs */
+int orbx_tap_sincos(orbx_t *h, const float *angles_deg, int n, float *cos_sin);
+
 /* ---- per-kernel timing (HIP events on the handle's stream) ---- */
 #define ORBX_STAGE_RESIZE 0
 #define ORBX_STAGE_FAST 1

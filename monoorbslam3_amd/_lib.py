@@ -57,6 +57,7 @@ def lib():
         "orbx_tap_level": (i32, [vp, i32, i32, i32, vp, sz]),
         "orbx_tap_candidates": (i32, [vp, i32, i32, vp, vp, vp, i32, C.POINTER(i32)]),
         "orbx_tap_level_counts": (i32, [vp, i32, vp]),
+        "orbx_tap_sincos": (i32, [vp, vp, i32, vp]),
         "orbx_set_stage_timing": (i32, [vp, i32]),
         "orbx_stage_times_ms": (i32, [vp, vp]),
         "orbx_last_error": (C.c_char_p, []),

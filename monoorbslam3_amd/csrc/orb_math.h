@@ -81,47 +81,66 @@ ORB_HD float orb_fast_atan2(float y, float x)
     return a;
 }
 
-// (cosf, sinf) of angle_deg * (float)(CV_PI/180.f): double-precision Cody-Waite
-// reduction + degree-13/12 kernel polynomials, rounded once to float.
+// glibc's sincosf on [0, 2*pi] -- what `cos(angle)`, `sin(angle)` on a float resolve to at
+// modules/ORB/ORBExtractor.cpp:53-54 (`using namespace std` at :11 -> std::cos(float) -> cosf).
+// glibc >= 2.28 (sysdeps/ieee754/flt-32/s_sincosf.h, s_sinf.c, s_cosf.c; not vendored by the
+// reference, pinned here by the container's glibc 2.35): |y| < pi/4 takes the degree-7 / degree-8
+// polynomials directly; otherwise n = round(y * 2/pi) by a 2^24-scaled double -> int32 conversion
+// (the !TOINT_INTRINSICS branch x86-64 builds), x = y - n*(pi/2) in double, polynomial picked by the
+// quadrant, rounded once to float.  tests/test_oracle_kat.py compares the oracle's copy of this with
+// the host libm's sinf / cosf / sincosf on every float in [0, 2*pi] (0 mismatches; the x86-64
+// FMA and SSE2 ifunc variants agree on that whole range, so the separate multiply-add form is used).
+ORB_HD float orb_sincosf_poly(double x, double x2, double sg, int odd)
+{
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
+                 C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    if (!odd) {
+        const double x3 = ORB_DMUL(x, x2);
+        const double s1 = ORB_DADD(S2, ORB_DMUL(x2, S3));
+        const double x7 = ORB_DMUL(x3, x2);
+        const double s = ORB_DADD(x, ORB_DMUL(x3, S1));
+        return (float)ORB_DADD(s, ORB_DMUL(x7, s1));
+    }
+    // __sincosf_table[1] holds the cosine coefficients negated (exact), selected when n & 2
+    const double x4 = ORB_DMUL(x2, x2);
+    const double c2 = ORB_DADD(sg * C3, ORB_DMUL(x2, sg * C4));
+    const double c1 = ORB_DADD(sg * C0, ORB_DMUL(x2, sg * C1));
+    const double x6 = ORB_DMUL(x4, x2);
+    const double c = ORB_DADD(c1, ORB_DMUL(x4, sg * C2));
+    return (float)ORB_DADD(c, ORB_DMUL(x6, c2));
+}
+ORB_HD void orb_sincosf(float y, float *sn, float *cs)
+{
+    union { float f; uint32_t u; } bits;
+    bits.f = y;
+    const uint32_t top = (bits.u >> 20) & 0x7ff;
+    const double x = (double)y;
+    if (top < 0x3f4) {                      // abstop12(y) < abstop12(0x1.921FB6p-1f)
+        if (top < 0x398) {                  // < abstop12(0x1p-12f)
+            *sn = y;
+            *cs = 1.0f;
+            return;
+        }
+        const double x2 = ORB_DMUL(x, x);
+        *sn = orb_sincosf_poly(x, x2, 1.0, 0);
+        *cs = orb_sincosf_poly(x, x2, 1.0, 1);
+        return;
+    }
+    // reduce_fast; valid below 120.0f, and the callers stay within [0, 2*pi]
+    const double r = ORB_DMUL(x, 0x1.45F306DC9C883p+23);
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    const double xr = ORB_DSUB(x, ORB_DMUL((double)n, 0x1.921FB54442D18p0));
+    const double sign = ((n + 1) & 2) ? -1.0 : 1.0;     // sign[n & 3] = {1, -1, -1, 1}
+    const double sg = (n & 2) ? -1.0 : 1.0;
+    const double xs = ORB_DMUL(xr, sign), x2 = ORB_DMUL(xr, xr);
+    *sn = orb_sincosf_poly(xs, x2, sg, n & 1);
+    *cs = orb_sincosf_poly(xs, x2, sg, (n ^ 1) & 1);
+}
+
+// (cosf, sinf) of angle_deg * (float)(CV_PI/180.f)  (modules/ORB/ORBExtractor.cpp:16,53-54)
 ORB_HD void orb_sincos_deg(float angle_deg, float *cs, float *sn)
 {
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    const float a = ORB_FMUL(angle_deg, factorPI);
-    const double x = (double)a;
-    const double two_over_pi = 6.36619772367581382433e-01;
-    const double pio2_hi = 1.57079632673412561417e+00;
-    const double pio2_lo = 6.07710050650619224932e-11;
-    const double kd = floor(ORB_DADD(ORB_DMUL(x, two_over_pi), 0.5));
-    const int k = (int)kd;
-    const double r = ORB_DSUB(ORB_DSUB(x, ORB_DMUL(kd, pio2_hi)), ORB_DMUL(kd, pio2_lo));
-    const double z = ORB_DMUL(r, r);
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double ps = S6;
-    ps = ORB_DADD(ORB_DMUL(ps, z), S5);
-    ps = ORB_DADD(ORB_DMUL(ps, z), S4);
-    ps = ORB_DADD(ORB_DMUL(ps, z), S3);
-    ps = ORB_DADD(ORB_DMUL(ps, z), S2);
-    ps = ORB_DADD(ORB_DMUL(ps, z), S1);
-    const double s = ORB_DADD(r, ORB_DMUL(r, ORB_DMUL(z, ps)));
-    double pc = C6;
-    pc = ORB_DADD(ORB_DMUL(pc, z), C5);
-    pc = ORB_DADD(ORB_DMUL(pc, z), C4);
-    pc = ORB_DADD(ORB_DMUL(pc, z), C3);
-    pc = ORB_DADD(ORB_DMUL(pc, z), C2);
-    pc = ORB_DADD(ORB_DMUL(pc, z), C1);
-    const double c = ORB_DSUB(1.0, ORB_DSUB(ORB_DMUL(0.5, z), ORB_DMUL(z, ORB_DMUL(z, pc))));
-    double cv, sv;
-    switch (k & 3) {
-    case 0: cv = c; sv = s; break;
-    case 1: cv = -s; sv = c; break;
-    case 2: cv = -c; sv = -s; break;
-    default: cv = s; sv = -c; break;
-    }
-    *cs = (float)cv;
-    *sn = (float)sv;
+    orb_sincosf(ORB_FMUL(angle_deg, factorPI), sn, cs);
 }

@@ -114,6 +114,11 @@ extern "C" int orbd_shard_count(int n_frames, int rank, int world)
     return (n_frames - rank + world - 1) / world; // frames rank, rank + world, ... below n_frames
 }
 extern "C" int orbd_shard_global_index(int k, int rank, int world) { return rank + k * world; }
+extern "C" int orbd_shard_capacity(int n_frames, int world)
+{
+    if (n_frames < 0 || world < 1) return 0;
+    return (n_frames + world - 1) / world; // = orbd_shard_count of rank 0, the largest shard
+}
 
 extern "C" int orbd_gather_records(orbd_t *c, int root, int n_frames, int cap, const int32_t *d_n, const orbx_kp *d_kp,
                                    const uint8_t *d_desc, int32_t *d_n_all, orbx_kp *d_kp_all, uint8_t *d_desc_all,
@@ -132,21 +137,28 @@ extern "C" int orbd_gather_records(orbd_t *c, int root, int n_frames, int cap, c
         if (bk) D_HIP(hipMemcpyAsync((uint8_t *)d_kp_all + (size_t)root * bk, d_kp, bk, hipMemcpyDeviceToDevice, s));
         if (bd) D_HIP(hipMemcpyAsync(d_desc_all + (size_t)root * bd, d_desc, bd, hipMemcpyDeviceToDevice, s));
         if (c->world > 1) {
+            // inside a group every call is made even after a failure and the group is always closed: an early return
+            // between ncclGroupStart and ncclGroupEnd would leave the communicator with an open group
             D_NCCL(g_rccl.GroupStart(), "ncclGroupStart");
-            for (int r = 0; r < c->world; ++r) {
+            int bad = 0;
+            for (int r = 0; r < c->world && !bad; ++r) {
                 if (r == root) continue;
-                D_NCCL(g_rccl.Recv((uint8_t *)d_n_all + (size_t)r * bn, bn, NCCL_UINT8, r, c->comm, s), "ncclRecv");
-                if (bk) D_NCCL(g_rccl.Recv((uint8_t *)d_kp_all + (size_t)r * bk, bk, NCCL_UINT8, r, c->comm, s), "ncclRecv");
-                if (bd) D_NCCL(g_rccl.Recv(d_desc_all + (size_t)r * bd, bd, NCCL_UINT8, r, c->comm, s), "ncclRecv");
+                bad |= g_rccl.Recv((uint8_t *)d_n_all + (size_t)r * bn, bn, NCCL_UINT8, r, c->comm, s);
+                if (bk && !bad) bad |= g_rccl.Recv((uint8_t *)d_kp_all + (size_t)r * bk, bk, NCCL_UINT8, r, c->comm, s);
+                if (bd && !bad) bad |= g_rccl.Recv(d_desc_all + (size_t)r * bd, bd, NCCL_UINT8, r, c->comm, s);
             }
-            D_NCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
+            const int end = g_rccl.GroupEnd();
+            if (bad) return rccl_fail("ncclRecv", bad);
+            D_NCCL(end, "ncclGroupEnd");
         }
     } else {
         D_NCCL(g_rccl.GroupStart(), "ncclGroupStart");
-        D_NCCL(g_rccl.Send(d_n, bn, NCCL_UINT8, root, c->comm, s), "ncclSend");
-        if (bk) D_NCCL(g_rccl.Send(d_kp, bk, NCCL_UINT8, root, c->comm, s), "ncclSend");
-        if (bd) D_NCCL(g_rccl.Send(d_desc, bd, NCCL_UINT8, root, c->comm, s), "ncclSend");
-        D_NCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
+        int bad = g_rccl.Send(d_n, bn, NCCL_UINT8, root, c->comm, s);
+        if (bk && !bad) bad |= g_rccl.Send(d_kp, bk, NCCL_UINT8, root, c->comm, s);
+        if (bd && !bad) bad |= g_rccl.Send(d_desc, bd, NCCL_UINT8, root, c->comm, s);
+        const int end = g_rccl.GroupEnd();
+        if (bad) return rccl_fail("ncclSend", bad);
+        D_NCCL(end, "ncclGroupEnd");
     }
     return ORBX_OK;
 }
@@ -162,9 +174,11 @@ extern "C" int orbd_allgather_records(orbd_t *c, int n_frames, int cap, const in
     hipStream_t s = (hipStream_t)stream;
     const size_t bn = (size_t)n_frames * sizeof(int32_t), bk = (size_t)n_frames * cap * sizeof(orbx_kp), bd = (size_t)n_frames * cap * 32;
     D_NCCL(g_rccl.GroupStart(), "ncclGroupStart");
-    D_NCCL(g_rccl.AllGather(d_n, d_n_all, bn, NCCL_UINT8, c->comm, s), "ncclAllGather");
-    if (bk) D_NCCL(g_rccl.AllGather(d_kp, d_kp_all, bk, NCCL_UINT8, c->comm, s), "ncclAllGather");
-    if (bd) D_NCCL(g_rccl.AllGather(d_desc, d_desc_all, bd, NCCL_UINT8, c->comm, s), "ncclAllGather");
-    D_NCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
+    int bad = g_rccl.AllGather(d_n, d_n_all, bn, NCCL_UINT8, c->comm, s);
+    if (bk && !bad) bad |= g_rccl.AllGather(d_kp, d_kp_all, bk, NCCL_UINT8, c->comm, s);
+    if (bd && !bad) bad |= g_rccl.AllGather(d_desc, d_desc_all, bd, NCCL_UINT8, c->comm, s);
+    const int end = g_rccl.GroupEnd();
+    if (bad) return rccl_fail("ncclAllGather", bad);
+    D_NCCL(end, "ncclGroupEnd");
     return ORBX_OK;
 }

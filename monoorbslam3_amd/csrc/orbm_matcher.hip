@@ -733,7 +733,8 @@ extern "C" int orbm_best2_device(orbm_t *c, int n_pairs, const uint8_t *d_a, siz
     if (nb_max >= (1 << 23)) return orbx_set_error(ORBX_E_UNSUPPORTED, "more than 2^23 candidates per problem");
     if (na_max == 0) return ORBX_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    // the matrix-pipe kernel takes every problem without a candidate mask and fewer than 2^19 * 32 candidates;
+    // the matrix-pipe kernel takes every problem without a candidate mask and at most BM_MAX_CAND (8160) candidates --
+    // 16 * tile + register must stay below the 4096 free low bits of its keys; anything else runs k_best2;
     // ORBM_BEST2=valu keeps everything on the VALU kernel (its parity twin)
     static const bool use_mfma = [] { const char *e = getenv("ORBM_BEST2"); return !(e && strcmp(e, "valu") == 0); }();
     if (use_mfma && !d_col_ok && nb_max <= BM_MAX_CAND) {

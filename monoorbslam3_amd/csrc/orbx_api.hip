@@ -901,6 +901,29 @@ extern "C" int orbx_tap_level_counts(orbx_t *c, int frame, int32_t *counts)
     return ORBX_OK;
 }
 
+void launch_tap_sincos(const float *d_ang, int n, float2 *d_out, hipStream_t st);
+extern "C" int orbx_tap_sincos(orbx_t *c, const float *angles_deg, int n, float *cos_sin)
+{
+    if (!c || !angles_deg || !cos_sin || n < 0) return fail(ORBX_E_ARG, "bad argument");
+    if (n == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    float *d_in = nullptr;
+    float2 *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, sizeof(float) * (size_t)n));
+    hipError_t e = hipMalloc(&d_out, sizeof(float2) * (size_t)n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, angles_deg, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_tap_sincos(d_in, n, d_out, c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(cos_sin, d_out, sizeof(float2) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    HIP_TRY(e);
+    return ORBX_OK;
+}
+
 extern "C" int orbx_set_stage_timing(orbx_t *c, int enable)
 {
     if (!c) return fail(ORBX_E_ARG, "null handle");

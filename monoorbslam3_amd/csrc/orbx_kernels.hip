@@ -2213,6 +2213,20 @@ __global__ __launch_bounds__(256) void k_angle(const OrbxLevels *__restrict__ le
     b.kp_ang[i] = make_float4(ang, cs, sn, 0.f);
 }
 
+// parity tap: the device's (cos, sin) of the descriptor rotation on caller-supplied angles (orbx_tap_sincos)
+__global__ __launch_bounds__(256) void k_tap_sincos(const float *__restrict__ ang, int n, float2 *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float cs, sn;
+    orb_sincos_deg(ang[i], &cs, &sn);
+    out[i] = make_float2(cs, sn);
+}
+void launch_tap_sincos(const float *d_ang, int n, float2 *d_out, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_tap_sincos, dim3((n + 255) / 256), dim3(256), 0, st, d_ang, n, d_out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Steered BRIEF on the blurred level (:50-97) + output record (:507-546, :626-632).  One wave64 per
 // keypoint, four keypoints per workgroup; lane l owns descriptor bits l, l+64, l+128, l+192 and four
@@ -2268,7 +2282,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
         // scalar loads where two loops over the levels ran on the scalar unit (which this kernel kept as busy as the VALU)
         const int lvl = live[k] ? b.slot_level[slot] : 0;
         level[k] = lvl;
-        const DescLv lv = tab.lv[lvl]; // (an empty slot has level 0: the corner of blurred level 0 is what it stages)
+        const DescLv lv = tab.lv[lvl]; // (a slot past the last one is given level 0; an empty slot of a level stages the corner of its own blurred level)
         const int i = slot - lv.kp_off;
         live[k] = live[k] && i < cnts[lvl];
         const int oi = i + b.sel_prefix[frame * ORBX_MAX_LEVELS + lvl];
@@ -2276,7 +2290,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
         live[k] = live[k] && oi < cap;
         rec[k] = make_uint2(0, 0);
         ang[k] = make_float4(0.f, 1.f, 0.f, 0.f);
-        // a slot without a keypoint stages the top-left corner of the blurred level 0 (valid memory, never sampled), so
+        // a slot without a keypoint stages the top-left corner of its blurred level (valid memory, never sampled), so
         // that the loads below need no branch
         int x = 19, y = 18;
         if (live[k]) {

@@ -147,6 +147,16 @@ class RecordExchange:
             getattr(L, name).restype, getattr(L, name).argtypes = C.c_int, [C.c_int, C.c_int, C.c_int]
         return [L.orbd_shard_global_index(k, rank, world) for k in range(L.orbd_shard_count(n_frames, rank, world))]
 
+    @staticmethod
+    def capacity(n_frames, world):
+        """Frames every rank passes to gather / allgather (orbd_shard_capacity = ceil(n_frames / world)): the exchanges
+        move equal blocks, so a rank whose shard is shorter pads with frames of count 0."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        L.orbd_shard_capacity.restype, L.orbd_shard_capacity.argtypes = C.c_int, [C.c_int, C.c_int]
+        return L.orbd_shard_capacity(n_frames, world)
+
     def gather(self, counts, kps, desc, root=0, stream=None, out=None):
         """counts int32 [b], kps uint8 [b, cap, 28], desc uint8 [b, cap, 32] device tensors -> on the root
         (counts [world, b], kps [world, b, cap, 28], desc [world, b, cap, 32]), None elsewhere.  `out` (root only): a

@@ -175,6 +175,13 @@ class ORBExtractor:
         _lib.check(self._L.orbx_tap_level_counts(self._h, frame, _vp(c)))
         return c[: self.n_levels].copy()
 
+    def tap_sincos(self, angles_deg):
+        """(cos, sin) pairs of the descriptor rotation as the device evaluates them (orbx_tap_sincos)."""
+        a = np.ascontiguousarray(angles_deg, np.float32)
+        out = np.zeros((a.size, 2), np.float32)
+        _lib.check(self._L.orbx_tap_sincos(self._h, _vp(a), a.size, _vp(out)))
+        return out
+
     def set_stage_timing(self, enable=True):
         _lib.check(self._L.orbx_set_stage_timing(self._h, int(enable)))
 

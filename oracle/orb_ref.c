@@ -603,52 +603,99 @@ void orbref_gaussian_blur7(const orbref_cfg *cfg, const uint8_t *src, int w, int
 /* ------------------------------------------------------------------------- */
 /* rBRIEF -- modules/ORB/ORBExtractor.cpp:50-97                                 */
 /* ------------------------------------------------------------------------- */
-/* cosf/sinf of angle*pi/180: evaluated in double (Cody-Waite + fdlibm kernel
- * polynomials) and rounded once to float, with only +,-,* so that the HIP path
- * can reproduce it bit for bit.  Equals glibc's cosf/sinf except for
- * double-rounding cases (checked in tests/test_oracle_kat.py). */
-static double k_sin(double r)
+/* cos(angle), sin(angle) on a float (ORBExtractor.cpp:54; `using namespace std` at :11 makes these
+ * std::cos(float) / std::sin(float) = glibc cosf / sinf).  glibc is a third-party dependency outside
+ * /root/reference; this restates the published algorithm of glibc >= 2.28
+ * (sysdeps/ieee754/flt-32/s_sincosf.h, s_sinf.c, s_cosf.c, s_sincosf_data.c), pinned by the
+ * container's glibc 2.35: orbref_sincosf_check_libm() below compares it with the host libm and
+ * tests/test_oracle_kat.py runs that over every float in [0, 2*pi] (0 mismatches for sinf, cosf and
+ * sincosf; on that range the x86-64 FMA and SSE2 ifunc variants give the same floats, so the plain
+ * multiply-add form is restated).  Only the branches reachable for |y| < 120 are restated; the
+ * descriptor angle is in [0, 360) degrees. */
+static float sincosf_poly(double x, double x2, int negated, int odd)
 {
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double z = r * r;
-    double p = S6;
-    p = p * z + S5; p = p * z + S4; p = p * z + S3; p = p * z + S2; p = p * z + S1;
-    return r + r * (z * p);
+    /* __sincosf_table[0]; table[1] (used when n & 2) is the same with c0..c4 negated */
+    const double sg = negated ? -1.0 : 1.0;
+    const double c0 = sg * 0x1p0, c1 = sg * -0x1.ffffffd0c621cp-2, c2 = sg * 0x1.55553e1068f19p-5,
+                 c3 = sg * -0x1.6c087e89a359dp-10, c4 = sg * 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    if (!odd) {                         /* sinf_poly, (n & 1) == 0 */
+        double x3 = x * x2;
+        double t1 = s2 + x2 * s3;
+        double x7 = x3 * x2;
+        double t = x + x3 * s1;
+        return (float)(t + x7 * t1);
+    } else {
+        double x4 = x2 * x2;
+        double t2 = c3 + x2 * c4;
+        double t1 = c0 + x2 * c1;
+        double x6 = x4 * x2;
+        double t = t1 + x4 * c2;
+        return (float)(t + x6 * t2);
+    }
 }
-static double k_cos(double r)
+static uint32_t abstop12(float x)
 {
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double z = r * r;
-    double p = C6;
-    p = p * z + C5; p = p * z + C4; p = p * z + C3; p = p * z + C2; p = p * z + C1;
-    return 1.0 - (0.5 * z - z * (z * p));
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    return (u >> 20) & 0x7ff;
+}
+void orbref_sincosf(float y, float *sn, float *cs)
+{
+    double x = y;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) {
+            *sn = y;
+            *cs = 1.0f;
+            return;
+        }
+        double x2 = x * x;
+        *sn = sincosf_poly(x, x2, 0, 0);
+        *cs = sincosf_poly(x, x2, 0, 1);
+        return;
+    }
+    /* reduce_fast, !TOINT_INTRINSICS: hpi_inv prescaled by 2^24 */
+    double r = x * 0x1.45F306DC9C883p+23;
+    int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - n * 0x1.921FB54442D18p0;
+    static const double sign[4] = {1.0, -1.0, -1.0, 1.0};
+    double sg = sign[n & 3];
+    *sn = sincosf_poly(x * sg, x * x, (n & 2) != 0, n & 1);
+    *cs = sincosf_poly(x * sg, x * x, (n & 2) != 0, (n ^ 1) & 1);
+}
+
+/* Pins orbref_sincosf against the libm this library is linked with: the float bit patterns
+ * first, first + step, ... <= last are compared with sinf, cosf and sincosf.  Returns the number of
+ * inputs on which any of the four values differs.  Test infrastructure. */
+extern void sincosf(float, float *, float *);
+long orbref_sincosf_check_libm(uint32_t first, uint32_t last, uint32_t step)
+{
+    long bad = 0;
+    if (step == 0) step = 1;
+    for (uint64_t u = first; u <= last; u += step) {
+        uint32_t b = (uint32_t)u;
+        float y, s, c, s2, c2;
+        memcpy(&y, &b, 4);
+        orbref_sincosf(y, &s, &c);
+        volatile float yy = y;          /* keeps the compiler from folding the libm calls */
+        float ls = sinf(yy), lc = cosf(yy);
+        sincosf(yy, &s2, &c2);
+        if (memcmp(&s, &ls, 4) || memcmp(&c, &lc, 4) || memcmp(&s2, &ls, 4) || memcmp(&c2, &lc, 4)) ++bad;
+    }
+    return bad;
 }
 
 void orbref_sincos_deg(float angle_deg, float *c, float *s)
 {
     const float factorPI = (float)(3.14159265358979323846 / 180.f); /* :16 (double/float -> double, cast) */
     float a = angle_deg * factorPI;                                 /* :53 */
-    double x = (double)a;
-    const double two_over_pi = 6.36619772367581382433e-01;
-    const double pio2_hi = 1.57079632673412561417e+00; /* 33 bits of pi/2 */
-    const double pio2_lo = 6.07710050650619224932e-11; /* pi/2 - pio2_hi */
-    double kd = floor(x * two_over_pi + 0.5);
-    int k = (int)kd;
-    double r = (x - kd * pio2_hi) - kd * pio2_lo;
-    double sn = k_sin(r), cs = k_cos(r);
-    double cv, sv;
-    switch (k & 3) {
-    case 0: cv = cs; sv = sn; break;
-    case 1: cv = -sn; sv = cs; break;
-    case 2: cv = -cs; sv = -sn; break;
-    default: cv = sn; sv = -cs; break;
-    }
-    *c = (float)cv;
-    *s = (float)sv;
+    orbref_sincosf(a, s, c);                                        /* :54 */
+}
+
+/* n angles at once (test convenience): out = n (cos, sin) pairs */
+void orbref_sincos_deg_n(const float *angle_deg, int n, float *out)
+{
+    for (int i = 0; i < n; ++i) orbref_sincos_deg(angle_deg[i], &out[2 * i], &out[2 * i + 1]);
 }
 
 void orbref_brief(const uint8_t *blur, int stride, int x, int y, float angle_deg, uint8_t *desc)

@@ -94,6 +94,9 @@ float orbref_ic_angle(const orbref_cfg *cfg, const uint8_t *img, int stride, int
 void orbref_gaussian_blur7(const orbref_cfg *cfg, const uint8_t *src, int w, int h, int sstride,
                            uint8_t *dst, int dstride);
 void orbref_sincos_deg(float angle_deg, float *c, float *s);
+void orbref_sincosf(float y, float *sn, float *cs);
+void orbref_sincos_deg_n(const float *angle_deg, int n, float *out);
+long orbref_sincosf_check_libm(uint32_t first, uint32_t last, uint32_t step);
 void orbref_brief(const uint8_t *blur, int stride, int x, int y, float angle_deg, uint8_t *desc32);
 
 /* Full operator(): returns number of keypoints (0 -> outputs untouched), or -1

@@ -79,6 +79,10 @@ def lib():
         L.orbref_pattern.restype = C.POINTER(C.c_int8)
         L.orbref_cfg_init.argtypes = [C.POINTER(Cfg), C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
         L.orbref_sincos_deg.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orbref_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orbref_sincosf_check_libm.restype = C.c_long
+        L.orbref_sincos_deg_n.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orbref_sincosf_check_libm.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         L.orbref_ic_angle.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orbref_brief.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
         L.orbref_grid_build.restype = C.c_void_p

@@ -20,14 +20,17 @@ def built():
 def _declared(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(orb(?:x|m|ba)_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(orb(?:x|m|ba|f|v|d)_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_every_declared_symbol_is_exported(built):
     L = C.CDLL(built.LIB_PATH)
-    names = _declared("orbx.h") + _declared("orbm.h") + _declared("orbba.h") + _declared("orbf.h") + _declared("orbv.h")
+    names = _declared("orbx.h") + _declared("orbm.h") + _declared("orbba.h") + _declared("orbf.h") + _declared("orbv.h") + \
+        _declared("orbd.h")
     assert "orbba_linearize" in names
-    assert len(names) >= 25
+    assert len(names) >= 60
+    for prefix in ("orbx_", "orbm_", "orbba_", "orbf_", "orbv_", "orbd_"):
+        assert any(n.startswith(prefix) for n in names), prefix
     for n in names:
         assert hasattr(L, n), "liborbx.so does not export %s" % n
 

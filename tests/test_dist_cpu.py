@@ -123,6 +123,11 @@ def test_c_abi_sharding_arithmetic_matches_the_torch_path():
                 assert mine == D.shard_indices(n, rank, world)
                 seen += mine
             assert sorted(seen) == list(range(n))
+            # uneven shards (n % world != 0): the exchange moves equal blocks of orbd_shard_capacity frames, the
+            # padding the torch path's extract_sharded applies (per = ceil(n / world), padded counts = 0)
+            cap = D.RecordExchange.capacity(n, world)
+            assert cap == (n + world - 1) // world == max(len(D.shard_indices(n, r, world)) for r in range(world))
+            assert all(cap - len(D.shard_indices(n, r, world)) in (0, 1) for r in range(world))
 
 
 def test_c_abi_exchange_fails_loudly_without_a_gpu():

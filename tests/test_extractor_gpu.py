@@ -58,6 +58,24 @@ def test_single_frame_all_stages(oracle_mod, monkeypatch, w, h, nf, variant):
     _check_frame(ex, orc, img, kps, desc)
 
 
+def test_descriptor_rotation_is_glibc_sincosf(oracle_mod):
+    """ORBExtractor.cpp:53-54: the device's (cos, sin) against the oracle's restatement of glibc sincosf -- which
+    tests/test_oracle_kat.py pins against the host libm on every float in [0, 2*pi] -- on every 257th float bit
+    pattern of [0, 360] degrees (4.4 M angles), plus the neighbourhood of every multiple of 45 degrees."""
+    ex, _ = _mk(oracle_mod, 500, 640, 200)
+    L = oracle_mod.lib()
+    top = np.array([360.0], np.float32).view(np.uint32)[0]
+    bits = [np.arange(0, int(top) + 1, 257, dtype=np.uint32)]
+    for q in range(0, 9):
+        c = int(np.array([45.0 * q], np.float32).view(np.uint32)[0])
+        bits.append(np.arange(max(c - 2048, 0), min(c + 2048, int(top)) + 1, dtype=np.uint32))
+    ang = np.ascontiguousarray(np.concatenate(bits).view(np.float32))
+    got = ex.tap_sincos(ang)
+    want = np.zeros_like(got)
+    L.orbref_sincos_deg_n(ang.ctypes.data, ang.size, want.ctypes.data)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_batch_host(oracle_mod):
     w, h, nf = 1242, 375, 2000
     ex, orc = _mk(oracle_mod, nf, w, h, batch=4)

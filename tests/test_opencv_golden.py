@@ -73,12 +73,10 @@ def test_sincos_and_round(oracle_mod):
     o = oracle_mod.Oracle(1000, 1.2, 8, 20, 7)
     ang, want = _load("sincos_in.npy"), _load("sincos_out.npy")
     got = np.array([o.sincos_deg(float(a)) for a in ang], np.float32)
-    # columns 2:4 = the double routines rounded to float, which is what the oracle's sincos restates exactly;
-    # columns 0:2 = cosf/sinf, which glibc does not round correctly: allow 1 ulp there (what matters downstream is
-    # cvRound(x*b + y*a) for |x|,|y| <= 13, ORBExtractor.cpp:61-62).
-    assert np.array_equal(got, want[:, 2:4])
-    ulp = np.abs(got.view(np.int32).astype(np.int64) - np.ascontiguousarray(want[:, 0:2]).view(np.int32))
-    assert ulp.max() <= 1
+    # columns 0:2 = cosf / sinf, what ORBExtractor.cpp:54 calls; the oracle restates glibc's sincosf bit for bit
+    # (tests/test_oracle_kat.py::test_sincos_matches_libm).  Columns 2:4 (the double routines rounded once) differ from
+    # them on ~2.6 % of the angles and are kept in the dump only as a diagnostic.
+    assert np.array_equal(got, want[:, 0:2])
     rin, rout = _load("round_in.npy"), _load("round_out.npy")
     L = oracle_mod.lib()
     assert [L.orbref_round_f(float(v)) for v in rin] == list(rout)

@@ -5,6 +5,7 @@ oracle is pinned by (a) values derivable from the reference's code alone and (b)
 literal re-implementations in Python (real list / dict semantics) of the order-dependent
 routines.  Parity against the OpenCV-backed original stays UNPINNED.
 """
+import ctypes as C
 import hashlib
 import json
 import math
@@ -309,13 +310,33 @@ def test_fast_atan2(O):
 
 
 def test_sincos_matches_libm(O):
+    """ORBExtractor.cpp:54 calls glibc cosf / sinf (std::cos(float), `using namespace std` at :11).  The oracle restates
+    glibc's sincosf; this pins it against the libm of the machine the test runs on (glibc 2.35 here): every float bit
+    pattern in [0, 2*pi] with ORB_EXHAUSTIVE=1 (1.09e9 values, ~25 s), every 61st one otherwise, plus the whole first
+    and last 2^20 patterns and the quadrant boundaries."""
+    import struct
+    L = O.lib()
+    bits = lambda v: struct.unpack("<I", struct.pack("<f", v))[0]
+    top = bits(float(np.float32(360.0) * np.float32(math.pi / float(np.float32(180.0))))) + 64
+    assert top > bits(6.2831855)
+    step = 1 if os.environ.get("ORB_EXHAUSTIVE") == "1" else 61
+    assert L.orbref_sincosf_check_libm(0, top, step) == 0
+    if step != 1:
+        assert L.orbref_sincosf_check_libm(0, 1 << 20, 1) == 0
+        assert L.orbref_sincosf_check_libm(top - (1 << 20), top, 1) == 0
+        for q in range(1, 9):               # around every multiple of pi/4: the branch and quadrant switches
+            c = bits(float(np.float32(q * math.pi / 4)))
+            assert L.orbref_sincosf_check_libm(c - 4096, c + 4096, 1) == 0
+    # the angle path of the descriptor (degrees in, :53-54) goes through the same routine
     o = O.Oracle()
     f = np.float32
     fac = f(math.pi / float(f(180.0)))
-    for a in np.linspace(0, 360, 20001, dtype=np.float32):
+    s1, c1 = C.c_float(), C.c_float()
+    for a in np.linspace(0, 360, 2001, dtype=np.float32):
         c, s = o.sincos_deg(float(a))
-        r = float(f(a) * fac)
-        assert c == f(math.cos(r)) and s == f(math.sin(r))
+        L.orbref_sincosf(float(f(a) * fac), C.byref(s1), C.byref(c1))
+        assert (c, s) == (c1.value, s1.value)
+        assert abs(c - math.cos(math.radians(float(a)))) < 1e-6 and abs(s - math.sin(math.radians(float(a)))) < 1e-6
 
 
 def test_ic_angle_symmetry(O):

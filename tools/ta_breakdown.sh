@@ -1,15 +1,16 @@
 #!/bin/bash
-# Texture-addresser / L1 / TLB counters per kernel (three separate --pmc passes, no trace domains): what the per-key-point
+# L1 / TLB / texture-data counters per kernel (two separate --pmc passes, no trace domains): what the per-key-point
 # kernels wait for.  Output: gpurun_out/ta_breakdown.txt
 set -e -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp ORBX_STREAMS=1
 rm -rf /tmp/tab
-P1="GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
+# (a first pass with GRBM_GUI_ACTIVE + TA_TA_BUSY / TA_ADDR_STALLED_BY_TC / TA_DATA_STALLED_BY_TC hung rocprofv3 on this pool in
+# round 2 and was killed after 7 minutes of silence with an empty log -- profiles/README.md; that set is not collected any more)
 P2="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"
 P3="TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TD_TD_BUSY_sum"
 i=0
-for P in "$P1" "$P2" "$P3"; do
+for P in "$P2" "$P3"; do
   i=$((i+1))
   rocprofv3 --pmc $P --output-format csv -d /tmp/tab/p$i -o r -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --batch 256 > /dev/null 2> /tmp/tab$i.err || { tail -5 /tmp/tab$i.err; exit 1; }
 done
