@@ -371,6 +371,174 @@ __global__ __launch_bounds__(BM_WAVES * 64) void k_best2_mfma(const uint8_t *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same search on the FP4 matrix path of gfx950: v_mfma_f32_32x32x64_f8f6f4 with cbsz = blgp = 4 takes 64 k-values
+// per instruction in the 32 cycles the i8 form needs for 32 (tools/microbench/fp4_hamming.hip: 32.1 cycles either way,
+// products exact).  A bit needs no more than a sign and a one, which FP4 (e2m1) has: candidates unpack to 0.0 / 1.0
+// nibbles (0x0 / 0x2), queries to -1.0 / +1.0 (0xA / 0x2), and four MFMAs leave popcount(query) - hamming for 32 candidates
+// x 32 queries in f32, exact.  Against the i8 kernel: half the MFMAs, half the LDS bytes per candidate (144-byte rows),
+// half the LDS reads per tile and half the unpacking; and
+//   * a wave owns 64 queries (two B operand sets, 32 registers): every A fragment read from LDS feeds two MFMAs;
+//   * the keys cost nothing: the first MFMA of a chain takes (15 - r) / 4096 per accumulator register r as its C operand,
+//     (+ 512), so the accumulator IS the key -- larger = closer, ties to the lower register -- and the update is one med3 and
+//     one max per register.  Everything is a multiple of 2^-12 below 2^10: exact in f32.  Tiles are told
+//     apart as in the i8 kernel: the running state lives in the frame of the current tile (true key = key - 16 tile / 4096).
+// Operand layout (probed with exact data): lane (n = lane & 31, h = lane >> 5), step t: nibble i of operand dword j <-
+// bit 4 i + j of descriptor dword 2 t + h, the same rule for both operands.
+// ---------------------------------------------------------------------------------------------
+typedef int bm_v8i __attribute__((ext_vector_type(8)));
+typedef float bm_v16f __attribute__((ext_vector_type(16)));
+#ifndef BF_WAVES
+#define BF_WAVES 8
+#endif
+#define BF_TC 128   // candidates per stage
+#define BF_ROWB 144 // bytes per unpacked candidate in LDS: 128 + 16, so that 8 consecutive rows cover the 32 banks
+__device__ __forceinline__ bm_v16f bf_mfma(bm_v4i a, bm_v4i b, bm_v16f c)
+{
+    const bm_v8i A = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0, 0, 0); // scales 0: the unscaled form
+}
+__global__ __launch_bounds__(BF_WAVES * 64) void k_best2_fp4(const uint8_t *__restrict__ a, size_t a_stride,
+                                                             const int32_t *__restrict__ na_p, int na_max,
+                                                             const uint8_t *__restrict__ b, size_t b_stride,
+                                                             const int32_t *__restrict__ nb_p, int nb_max,
+                                                             const uint8_t *__restrict__ row_ok,
+                                                             int32_t *__restrict__ best_idx, uint16_t *__restrict__ best,
+                                                             uint16_t *__restrict__ second)
+{
+    __shared__ __align__(16) uint8_t sb[2][BF_TC * BF_ROWB];
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int na = na_p ? min(na_p[p], na_max) : na_max, nb = nb_p ? min(nb_p[p], nb_max) : nb_max;
+    const int row0 = blockIdx.x * (BF_WAVES * 64) + wave * 64;
+    const uint8_t *A = a + (size_t)p * a_stride * 32;
+    const uint8_t *B = b + (size_t)p * b_stride * 32;
+
+    // ---- this lane's two queries (rows row0 + n and row0 + 32 + n) as the B operands of the 4 steps
+    bm_v4i bq[2][4];
+    int pcq[2] = {0, 0};
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int row = min(row0 + 32 * g + n, max(na_max - 1, 0)); // clamped rows are computed but never stored
+        const uint32_t *pq = reinterpret_cast<const uint32_t *>(A + (size_t)row * 32);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t w0 = na_max > 0 ? pq[2 * t] : 0u, w1 = na_max > 0 ? pq[2 * t + 1] : 0u;
+            pcq[g] += __popc(w0) + __popc(w1);
+            const uint32_t w = h ? w1 : w0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bq[g][t][j] = (int)(0x22222222u | (((~w >> j) & 0x11111111u) << 3)); // set: +1.0, clear: -1.0
+        }
+    }
+    bm_v16f seed;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) seed[r] = 512.0f + (float)(15 - r) * (1.0f / 4096.0f);
+    // + 512 keeps every key a positive float (acc is in [-256, 256]), and positive floats order like their bit patterns:
+    // the update runs on the integer med3 / max (the float forms would first canonicalise their inputs).  A state of 0
+    // holds no candidate; the frame shifts move it by less than 1 in total, far below any key (>= 256).
+    uint32_t k1[2] = {0u, 0u}, k2[2] = {0u, 0u}; // the two largest keys per query, in the frame of tile `frame`
+    int frame = 0;
+
+    // ---- staging: thread -> (candidate tid / 8 (+ 64 per round) of the stage, descriptor dword tid % 8) -> 16 unpacked bytes
+    const int sr = tid >> 3, st = tid & 7;
+    auto stage = [&](int step, int buf) {
+        uint32_t w[BF_TC / (BF_WAVES * 8)];
+#pragma unroll
+        for (int q = 0; q < BF_TC / (BF_WAVES * 8); ++q) {
+            const int j = step * BF_TC + (BF_WAVES * 8) * q + sr;
+            w[q] = j < nb ? reinterpret_cast<const uint32_t *>(B + (size_t)j * 32)[st] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < BF_TC / (BF_WAVES * 8); ++q) {
+            const uint32_t M = 0x22222222u;
+            uint4 o;
+            o.x = (w[q] << 1) & M; o.y = w[q] & M; o.z = (w[q] >> 1) & M; o.w = (w[q] >> 2) & M;
+            *reinterpret_cast<uint4 *>(&sb[buf][((BF_WAVES * 8) * q + sr) * BF_ROWB + st * 16]) = o;
+        }
+    };
+    const int n_steps = (nb + BF_TC - 1) / BF_TC;
+    if (n_steps > 0) stage(0, 0);
+    __syncthreads();
+    for (int s = 0; s < n_steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < n_steps) stage(s + 1, buf ^ 1);
+#pragma unroll
+        for (int tl = 0; tl < BF_TC / 32; ++tl) {
+            const int tile = (BF_TC / 32) * s + tl, nvalid = nb - tile * 32; // candidates of this tile that exist
+            if (nvalid <= 0) break;
+            const uint8_t *src = &sb[buf][(tl * 32 + n) * BF_ROWB + h * 16];
+            bm_v4i af[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const bm_v4i *>(src + t * 32);
+            bm_v16f acc[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                acc[g] = bf_mfma(af[0], bq[g][0], seed);
+#pragma unroll
+                for (int t = 1; t < 4; ++t) acc[g] = bf_mfma(af[t], bq[g][t], acc[g]);
+            }
+            const float adv = (float)(16 * (tile - frame)) * (1.0f / 4096.0f); // into this tile's frame
+            frame = tile;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                k1[g] = __float_as_uint(__uint_as_float(k1[g]) + adv);
+                k2[g] = __float_as_uint(__uint_as_float(k2[g]) + adv);
+                if (nvalid >= 32) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t k = __float_as_uint(acc[g][r]);
+                        k2[g] = med3_u32(k, k1[g], k2[g]);
+                        k1[g] = max(k, k1[g]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        uint32_t k = __float_as_uint(acc[g][r]);
+                        if ((r & 3) + 8 * (r >> 2) + 4 * h >= nvalid) k = 0u; // accumulator row of register r (C/D layout)
+                        k2[g] = med3_u32(k, k1[g], k2[g]);
+                        k1[g] = max(k, k1[g]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- decode (distance, candidate) of both states, make them comparable across the lane pair (n, n + 32) that holds
+    // one query's two candidate halves -- final key = (acc + 256) << 13 | (8191 - candidate), 0 = none -- and merge
+    auto final_key = [&](uint32_t sb_) -> uint32_t {
+        const float sk = __uint_as_float(sb_);
+        if (sk < 128.0f) return 0u;
+        // 4096 acc + 15 - (16 tile + r), exact
+        const int K = (int)((sk - 512.0f - (float)(16 * frame) * (1.0f / 4096.0f)) * 4096.0f);
+        const int t2 = K - 15;
+        const int acc = (t2 + 4095) >> 12;                                           // ceil: 0 <= 16 tile + r < 4096
+        const uint32_t i16 = (uint32_t)(4096 * acc - t2), r = i16 & 15u, tile = i16 >> 4;
+        const uint32_t cand = tile * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
+        return ((uint32_t)(acc + 256) << 13) | (8191u - cand);
+    };
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        uint32_t f1 = final_key(k1[g]), f2 = final_key(k2[g]);
+        {
+            const uint32_t o1 = __shfl_xor(f1, 32), o2 = __shfl_xor(f2, 32);
+            f2 = max(max(f2, o2), min(f1, o1));
+            f1 = max(f1, o1);
+        }
+        const int row = row0 + 32 * g + n;
+        if (h == 0 && row < na_max) {
+            const size_t orow = (size_t)p * a_stride + row;
+            const bool live = row < na && (!row_ok || row_ok[orow]);
+            // hamming = popcount(query) - acc
+            const uint32_t d1 = f1 == 0 ? 256u : (uint32_t)(pcq[g] - ((int)(f1 >> 13) - 256));
+            const uint32_t ss = f2 == 0 ? 256u : (uint32_t)(pcq[g] - ((int)(f2 >> 13) - 256));
+            // a 256-distance candidate never beats the initial 256 of the reference loop
+            best_idx[orow] = (live && d1 < 256) ? (int32_t)(8191u - (f1 & 8191u)) : -1;
+            best[orow] = live ? (uint16_t)min(d1, 256u) : (uint16_t)256;
+            second[orow] = live ? (uint16_t)min(ss, 256u) : (uint16_t)256;
+        }
+    }
+}
+
 // distances for explicit candidate lists; one wave per query
 __global__ __launch_bounds__(256) void k_hamming_lists(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
                                                        const int32_t *__restrict__ q_idx,
@@ -736,7 +904,18 @@ extern "C" int orbm_best2_device(orbm_t *c, int n_pairs, const uint8_t *d_a, siz
     // the matrix-pipe kernel takes every problem without a candidate mask and at most BM_MAX_CAND (8160) candidates --
     // 16 * tile + register must stay below the 4096 free low bits of its keys; anything else runs k_best2;
     // ORBM_BEST2=valu keeps everything on the VALU kernel (its parity twin)
-    static const bool use_mfma = [] { const char *e = getenv("ORBM_BEST2"); return !(e && strcmp(e, "valu") == 0); }();
+    static const int variant = [] { // ORBM_BEST2 = fp4 (default) | i8 | valu
+        const char *e = getenv("ORBM_BEST2");
+        return !e ? 2 : strcmp(e, "valu") == 0 ? 0 : strcmp(e, "i8") == 0 ? 1 : 2;
+    }();
+    const bool use_mfma = variant != 0;
+    if (variant == 2 && !d_col_ok && nb_max <= BM_MAX_CAND) {
+        dim3 grid((na_max + BF_WAVES * 64 - 1) / (BF_WAVES * 64), n_pairs);
+        hipLaunchKernelGGL(k_best2_fp4, grid, dim3(BF_WAVES * 64), 0, s, d_a, a_stride, d_na, na_max, d_b, b_stride, d_nb,
+                           nb_max, d_row_ok, d_best_idx, d_best, d_second);
+        M_TRY(hipGetLastError());
+        return ORBX_OK;
+    }
     if (use_mfma && !d_col_ok && nb_max <= BM_MAX_CAND) {
         dim3 grid((na_max + BM_WAVES * 32 - 1) / (BM_WAVES * 32), n_pairs);
         hipLaunchKernelGGL(k_best2_mfma, grid, dim3(BM_WAVES * 64), 0, s, d_a, a_stride, d_na, na_max, d_b, b_stride, d_nb,
