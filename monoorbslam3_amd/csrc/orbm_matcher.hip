@@ -391,14 +391,16 @@ typedef float bm_v16f __attribute__((ext_vector_type(16)));
 #ifndef BF_WAVES
 #define BF_WAVES 8
 #endif
+#ifndef BF_TC
 #define BF_TC 128   // candidates per stage
+#endif
 #define BF_ROWB 144 // bytes per unpacked candidate in LDS: 128 + 16, so that 8 consecutive rows cover the 32 banks
 __device__ __forceinline__ bm_v16f bf_mfma(bm_v4i a, bm_v4i b, bm_v16f c)
 {
     const bm_v8i A = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0, 0, 0); // scales 0: the unscaled form
 }
-__global__ __launch_bounds__(BF_WAVES * 64) void k_best2_fp4(const uint8_t *__restrict__ a, size_t a_stride,
+__global__ __launch_bounds__(BF_WAVES * 64, 4) void k_best2_fp4(const uint8_t *__restrict__ a, size_t a_stride,
                                                              const int32_t *__restrict__ na_p, int na_max,
                                                              const uint8_t *__restrict__ b, size_t b_stride,
                                                              const int32_t *__restrict__ nb_p, int nb_max,
@@ -433,10 +435,11 @@ __global__ __launch_bounds__(BF_WAVES * 64) void k_best2_fp4(const uint8_t *__re
     bm_v16f seed;
 #pragma unroll
     for (int r = 0; r < 16; ++r) seed[r] = 512.0f + (float)(15 - r) * (1.0f / 4096.0f);
-    // + 512 keeps every key a positive float (acc is in [-256, 256]), and positive floats order like their bit patterns:
-    // the update runs on the integer med3 / max (the float forms would first canonicalise their inputs).  A state of 0
-    // holds no candidate; the frame shifts move it by less than 1 in total, far below any key (>= 256).
-    uint32_t k1[2] = {0u, 0u}, k2[2] = {0u, 0u}; // the two largest keys per query, in the frame of tile `frame`
+    // + 512 keeps every key a positive float (acc is in [-256, 256]).  The update is two v_med3_f32 per register -- the
+    // max as med3(k, k1, 3e38): fmaxf (and a med3 with +inf, which the compiler folds into it) would first canonicalise its inputs, and an inline-asm integer med3 / max on the bit
+    // patterns hides from the compiler that it reads an MFMA result (the wait states between the two are the compiler's
+    // to insert).  A state of 0 holds no candidate; the frame shifts move it by less than 1 in total, far below any key.
+    float k1[2] = {0.f, 0.f}, k2[2] = {0.f, 0.f}; // the two largest keys per query, in the frame of tile `frame`
     int frame = 0;
 
     // ---- staging: thread -> (candidate tid / 8 (+ 64 per round) of the stage, descriptor dword tid % 8) -> 16 unpacked bytes
@@ -456,57 +459,50 @@ __global__ __launch_bounds__(BF_WAVES * 64) void k_best2_fp4(const uint8_t *__re
             *reinterpret_cast<uint4 *>(&sb[buf][((BF_WAVES * 8) * q + sr) * BF_ROWB + st * 16]) = o;
         }
     };
-    const int n_steps = (nb + BF_TC - 1) / BF_TC;
+    // One tile = 32 candidates x this wave's 64 queries.  Full tiles (every candidate exists) run without any per-row test;
+    // the one partial tile a problem can end with is done apart, after the loop of its stage, so that its row masks are
+    // not computed (the compiler would hoist them under the MFMAs) for the tiles that do not need them.
+    auto do_tile = [&](int buf, int tl, int tile, int nvalid, bool partial) {
+        const uint8_t *src = &sb[buf][(tl * 32 + n) * BF_ROWB + h * 16];
+        bm_v4i af[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const bm_v4i *>(src + t * 32);
+        bm_v16f acc[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            acc[g] = bf_mfma(af[0], bq[g][0], seed);
+#pragma unroll
+            for (int t = 1; t < 4; ++t) acc[g] = bf_mfma(af[t], bq[g][t], acc[g]);
+        }
+        const float adv = (float)(16 * (tile - frame)) * (1.0f / 4096.0f); // into this tile's frame
+        frame = tile;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            k1[g] += adv;
+            k2[g] += adv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float k = acc[g][r];
+                if (partial && (r & 3) + 8 * (r >> 2) + 4 * h >= nvalid) k = 0.f; // accumulator row of register r (C/D layout)
+                k2[g] = __builtin_amdgcn_fmed3f(k, k1[g], k2[g]);
+                k1[g] = __builtin_amdgcn_fmed3f(k, k1[g], 3.0e38f);
+            }
+        }
+    };
+    const int n_steps = (nb + BF_TC - 1) / BF_TC, n_full = nb >> 5;
     if (n_steps > 0) stage(0, 0);
     __syncthreads();
     for (int s = 0; s < n_steps; ++s) {
         const int buf = s & 1;
         if (s + 1 < n_steps) stage(s + 1, buf ^ 1);
-#pragma unroll
-        for (int tl = 0; tl < BF_TC / 32; ++tl) {
-            const int tile = (BF_TC / 32) * s + tl, nvalid = nb - tile * 32; // candidates of this tile that exist
-            if (nvalid <= 0) break;
-            const uint8_t *src = &sb[buf][(tl * 32 + n) * BF_ROWB + h * 16];
-            bm_v4i af[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const bm_v4i *>(src + t * 32);
-            bm_v16f acc[2];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                acc[g] = bf_mfma(af[0], bq[g][0], seed);
-#pragma unroll
-                for (int t = 1; t < 4; ++t) acc[g] = bf_mfma(af[t], bq[g][t], acc[g]);
-            }
-            const float adv = (float)(16 * (tile - frame)) * (1.0f / 4096.0f); // into this tile's frame
-            frame = tile;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                k1[g] = __float_as_uint(__uint_as_float(k1[g]) + adv);
-                k2[g] = __float_as_uint(__uint_as_float(k2[g]) + adv);
-                if (nvalid >= 32) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const uint32_t k = __float_as_uint(acc[g][r]);
-                        k2[g] = med3_u32(k, k1[g], k2[g]);
-                        k1[g] = max(k, k1[g]);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        uint32_t k = __float_as_uint(acc[g][r]);
-                        if ((r & 3) + 8 * (r >> 2) + 4 * h >= nvalid) k = 0u; // accumulator row of register r (C/D layout)
-                        k2[g] = med3_u32(k, k1[g], k2[g]);
-                        k1[g] = max(k, k1[g]);
-                    }
-                }
-            }
-        }
+        const int t0 = (BF_TC / 32) * s, nt = min(n_full - t0, BF_TC / 32);
+        for (int tl = 0; tl < nt; ++tl) do_tile(buf, tl, t0 + tl, 32, false);
+        if (s + 1 == n_steps && (nb & 31)) do_tile(buf, n_full - t0, n_full, nb & 31, true);
         __syncthreads();
     }
     // ---- decode (distance, candidate) of both states, make them comparable across the lane pair (n, n + 32) that holds
     // one query's two candidate halves -- final key = (acc + 256) << 13 | (8191 - candidate), 0 = none -- and merge
-    auto final_key = [&](uint32_t sb_) -> uint32_t {
-        const float sk = __uint_as_float(sb_);
+    auto final_key = [&](float sk) -> uint32_t {
         if (sk < 128.0f) return 0u;
         // 4096 acc + 15 - (16 tile + r), exact
         const int K = (int)((sk - 512.0f - (float)(16 * frame) * (1.0f / 4096.0f)) * 4096.0f);
