@@ -946,6 +946,19 @@ extern "C" const char *orbx_last_error(void) { return g_err.c_str(); }
 extern "C" const char *orbx_version(void) { return "orbx 0.1 (gfx950)"; }
 
 #ifdef OCT_PROF
+unsigned long long *orbx_dev_fast_prof_symbol();
+// development build only (make prof): k_fast_strip's stage counters since the last reset (tools/fast_mix.py)
+extern "C" int orbx_dev_fast_prof(orbx_t *c, unsigned long long *out16, int reset)
+{
+    if (!c || !out16) return fail(ORBX_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long *sym = orbx_dev_fast_prof_symbol();
+    if (!sym) return fail(ORBX_E_ARG, "no counter symbol");
+    HIP_TRY(hipMemcpy(out16, sym, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(sym, 0, sizeof(unsigned long long) * 16));
+    return ORBX_OK;
+}
 // development build only (make prof): the quadtree kernel's phase time stamps of frame 0 (tools/octree_phases.py)
 extern "C" int orbx_dev_octree_phases(orbx_t *c, unsigned long long *out, int n_levels)
 {

@@ -410,6 +410,8 @@ struct __attribute__((aligned(8))) FastStrip { // 8-byte aligned: one scalar loa
 // The queues are written and read by the one wave of the workgroup, and a wave's LDS instructions execute in issue
 // order: what is needed between a producer and a consumer stage is only that the compiler keeps that order.
 #define FS_WAVE_ORDER() asm volatile("" ::: "memory")
+// the same barrier, leaving a named comment in the ISA: tools/isa_mix.py counts the instructions between "name_begin" and "name_end"
+#define FS_MARK(name) asm volatile("; FSM " name ::: "memory")
 
 // bit 7 of every byte set <=> at least 9 contiguous (cyclic) of the 16 flags x[k] have bit 7 set in that byte
 __device__ __forceinline__ uint32_t swar_arc9(const uint32_t x[16])
@@ -435,7 +437,22 @@ __device__ __forceinline__ int wave_rank(u64 mk)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
 }
+// base + rank: the lane count instructions add their third operand, so a queue position costs no separate addition
+__device__ __forceinline__ int wave_rank_from(u64 mk, int base)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, (uint32_t)base));
+}
 
+#ifdef OCT_PROF
+// development build only (make prof): how often a wave runs each stage of k_fast_strip, summed over the launch
+// (tools/fast_mix.py weighs the kernel's instruction mix with these): strips, tile loads, compass steps, 16-point
+// batches, strength batches, NMS list batches, passes, items queued, pixels queued
+__device__ unsigned long long g_fs_prof[16];
+#define FS_COUNT(i, n) do { if (lane == 0) atomicAdd(&g_fs_prof[i], (unsigned long long)(n)); } while (0)
+unsigned long long *orbx_dev_fast_prof_symbol() { unsigned long long *p = nullptr; (void)hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_fs_prof)); return p; }
+#else
+#define FS_COUNT(i, n) do { } while (0)
+#endif
 __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels *__restrict__ levels,
                                                    const FastStrip *__restrict__ strips, u64 *__restrict__ cand,
                                                    size_t cand_fs, int *__restrict__ cand_count, int n_strips,
@@ -467,7 +484,10 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
     const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level] + (size_t)(y0 - 3) * pitch + (x0 - 4);
 
     if (lane < FS_K) s_cellkeep[lane] = 0;
+    FS_COUNT(0, 1);
     auto load_tile = [&]() {
+        FS_COUNT(1, 1);
+        FS_MARK("tile_begin");
         // tile column tc <-> level x = x0 - 4 + tc; region columns are tc in [4, 4 + Ws); the ring of the last region
         // column ends at tc = Ws + 6.  Lane = (8-byte item tx, row ty mod 4); nine row groups, all requested before the
         // first is stored (row and item clamped instead of branching: surplus lanes repeat the last row / item).  The
@@ -487,7 +507,7 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         for (int k = 0; k < 9; ++k) {
             *reinterpret_cast<unsigned long long *>(&tile[dst[k]]) = v[k];
         }
-            FS_WAVE_ORDER();
+        FS_MARK("tile_end");
     };
     __syncthreads();
 
@@ -498,6 +518,8 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
 
     // ---- stage 4: exact strength of `n` queued pixels (n <= 64)
     auto stage_score = [&](int n) {
+        FS_COUNT(4, 1); FS_COUNT(8, n);
+        FS_MARK("score_begin");
         const bool live = lane < n;
         const int e = cq[(cq_head + min(lane, n - 1)) & (FS_CQ - 1)];
         cq_head += n;
@@ -525,12 +547,15 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         const bool corner = live && sc >= thr;
         const int c = tc - 4;
         const u64 mk = __ballot(corner);
-        const int pos = list_n + wave_rank(mk);
+        const int pos = wave_rank_from(mk, list_n);
         if (corner && pos < FS_LIST) list[pos] = (uint32_t)r | ((uint32_t)c << 8) | ((uint32_t)sc << 16);
         list_n += (int)__popcll(mk); // may exceed FS_LIST: the pass is then redone in narrow column ranges
+        FS_MARK("score_end");
     };
     // ---- stage 3: the full 16-point test of `n` queued items on the 6-bit tile, four pixels per operation
     auto stage_arc = [&](int n) {
+        FS_COUNT(3, 1); FS_COUNT(7, n);
+        FS_MARK("arc_begin");
         const uint32_t e = iq[(iq_head + min(lane, n - 1)) & (FS_IQ - 1)];
         iq_head += n;
         const int r = e & 31, g = (e >> 8) & 31;
@@ -570,7 +595,7 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
             const bool hit = (m >> (8 * j + 7)) & 1u;
             const u64 mk = __ballot(hit);
             const uint32_t tag = (j == 0 ? (mb << 8) : (mb >> (8 * j - 8))) & 0x8000u;
-            if (hit) cq[(cq_tail + wave_rank(mk)) & (FS_CQ - 1)] = (uint16_t)((ent + j) | tag);
+            if (hit) cq[wave_rank_from(mk, cq_tail) & (FS_CQ - 1)] = (uint16_t)((ent + j) | tag);
             cq_tail += (int)__popcll(mk);
         }
         if (both_possible) {
@@ -578,10 +603,11 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
             for (int j = 0; j < 4; ++j) {
                 const bool hit = ((md & mb) >> (8 * j + 7)) & 1u;
                 const u64 mk = __ballot(hit);
-                if (hit) cq[(cq_tail + wave_rank(mk)) & (FS_CQ - 1)] = (uint16_t)(ent + j);
+                if (hit) cq[wave_rank_from(mk, cq_tail) & (FS_CQ - 1)] = (uint16_t)(ent + j);
                 cq_tail += (int)__popcll(mk);
             }
         }
+        FS_MARK("arc_end");
     };
 
     // One pass = every corner of the region columns [col_lo, col_hi) at threshold `thr`, and of those with a column in
@@ -593,16 +619,30 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         const int arc_batch = both_possible ? 32 : 64; // a batch of items queues at most 256 pixel entries
         iq_head = iq_tail = cq_head = cq_tail = 0;
         list_n = 0;
+        FS_COUNT(6, 1);
         // ---- stage 2: compass test.  Lane = (group of four region columns, row mod FS_R), fixed for the pass: the
         // validity mask and every address offset are per-lane constants, a step advances FS_R rows.
         {
             const int g_lo = col_lo >> 2, g_hi = (col_hi + 3) >> 2;
-            const int g = min(g_lo + (lane & (FS_LG - 1)), g_hi - 1), rsub = lane / FS_LG;
-            const uint32_t vm = (g_lo + (lane & (FS_LG - 1)) < g_hi)
+            // lanes per tile row: the smallest power of two that holds the range's groups -- a one-cell retry pass (8 groups)
+            // then takes 8 rows per step instead of 2 with three quarters of the wave idle
+            const int lg_sh = (g_hi - g_lo) <= 8 ? 3 : (g_hi - g_lo) <= 16 ? 4 : 5, lgm = (1 << lg_sh) - 1, R = 64 >> lg_sh;
+            static_assert(FS_LG <= 32 && 36 + 8 <= FS_TROWS + 6, "a step of 8 rows must stay inside the tile");
+            const int g = min(g_lo + (lane & lgm), g_hi - 1), rsub = lane >> lg_sh;
+            const uint32_t vm = (g_lo + (lane & lgm) < g_hi)
                                     ? (0x80808080u & byte_prefix_mask(col_hi - 4 * g) & ~byte_prefix_mask(col_lo - 4 * g)) : 0u;
             const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile[rsub * FS_TP + 4 * g]); // (row r - 3, column tc - 4)
             uint32_t ent = (uint32_t)rsub | ((uint32_t)g << 8);
-            for (int r0 = 0; r0 < ch; r0 += FS_R, t += FS_R * (FS_TP / 4), ent += FS_R) {
+            const int t_step = R * (FS_TP / 4);
+            // rows this lane still has below it, kept in a vector register and turned into a mask arithmetically
+            // ((left - 1) >> 31 is all ones once left <= 0): subtract, shift and a three-input logic operation are in the cheap
+            // issue class, the add-with-a-scalar, compare and select they replace are not (profiles/r03_valu_ops3.txt)
+            int left = ch - rsub;
+            int vstep = R;
+            asm volatile("" : "+v"(vstep)); // a vector register operand: the same subtraction with a scalar one issues at half the rate
+            for (int r0 = 0; r0 < ch; r0 += R, t += t_step, ent += (uint32_t)R, left -= vstep) {
+                FS_COUNT(2, 1);
+                FS_MARK("compass_begin");
                 const uint32_t M6 = 0x3F3F3F3Fu;
                 const uint32_t cm = t[3 * (FS_TP / 4)], cr = t[3 * (FS_TP / 4) + 1], cp = t[3 * (FS_TP / 4) + 2];
                 const uint32_t up = (t[1] >> 2) & M6, dn = (t[6 * (FS_TP / 4) + 1] >> 2) & M6, c0 = (cr >> 2) & M6;
@@ -611,12 +651,12 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
                 // a 9-arc holds two adjacent compass points: (S or N) and (E or W), all darker or all brighter
                 uint32_t m = ((Vd - dn) | (Vd - up)) & ((Vd - E) | (Vd - Wv));
                 m |= ((Vb + dn) | (Vb + up)) & ((Vb + E) | (Vb + Wv));
-                m &= (r0 + rsub < ch) ? vm : 0u;
+                m &= vm & ~(uint32_t)((left - 1) >> 31);
                 const bool surv = m != 0;
                 const u64 mk = __ballot(surv);
-                if (surv) iq[(iq_tail + wave_rank(mk)) & (FS_IQ - 1)] = m | ent;
+                if (surv) iq[wave_rank_from(mk, iq_tail) & (FS_IQ - 1)] = m | ent;
                 iq_tail += (int)__popcll(mk);
-                FS_WAVE_ORDER();
+                FS_MARK("compass_end");
                 while (iq_tail - iq_head >= 64) {
                     stage_arc(arc_batch);
                     FS_WAVE_ORDER();
@@ -647,6 +687,8 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         int n_keep = 0;
         // keepers are compacted in place: a batch is read before it is written, at positions <= the ones just read
         for (int i0 = 0; i0 < list_n; i0 += 64) {
+            FS_COUNT(5, 1);
+            FS_MARK("nms_begin");
             const int i = min(i0 + lane, list_n - 1);
             const uint32_t e = list[i];
             const int r = e & 255, c = (e >> 8) & 255, sc = e >> 16;
@@ -659,6 +701,7 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
             FS_WAVE_ORDER();
             if (keep) list[n_keep + wave_rank(mk)] = e;
             n_keep += (int)__popcll(mk);
+            FS_MARK("nms_end");
         }
         if (n_keep == 0) return true;
         int base = 0;
