@@ -651,7 +651,9 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
                 // a 9-arc holds two adjacent compass points: (S or N) and (E or W), all darker or all brighter
                 uint32_t m = ((Vd - dn) | (Vd - up)) & ((Vd - E) | (Vd - Wv));
                 m |= ((Vb + dn) | (Vb + up)) & ((Vb + E) | (Vb + Wv));
-                m &= vm & ~(uint32_t)((left - 1) >> 31);
+                uint32_t gone; // all ones once left <= 0 (written as an instruction: the compiler would turn the shift back into compare + select)
+                asm("v_ashrrev_i32 %0, 31, %1" : "=v"(gone) : "v"(left - 1));
+                m &= vm & ~gone;
                 const bool surv = m != 0;
                 const u64 mk = __ballot(surv);
                 if (surv) iq[wave_rank_from(mk, iq_tail) & (FS_IQ - 1)] = m | ent;
