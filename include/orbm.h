@@ -159,6 +159,31 @@ int orbm_window_lists_device(orbm_t *h, const void *d_kps, const uint8_t *d_desc
                              const int32_t *d_q_max_level, const uint8_t *d_q_ok, int nq, int strict,
                              const float *d_sigma2, int cap, int32_t *d_counts, uint32_t *d_lists, void *stream);
 
+/* The two SearchByProjection calls of the tracking thread (Tracking.cpp:289-336) on a device-resident frame record, greedy
+ * pass included (modules/ORB/ORBMatcher.cpp:229-246 and :379-407): nothing returns to the host between the extraction,
+ * orbf_frame_post_device and the matched map points.  Queries (device arrays, as the host entry points above take them):
+ * descriptors, projections, radii, octave / predicted level, angle (frame -> frame only), q_ok.  The frame: d_kps2 / d_desc2 /
+ * CSR grid as for orbm_window_lists_device, n2 key points.  d_frame_mp [n2], in/out, the meaning of the host entry points:
+ * -1 = free, anything else = occupied; matched entries receive the query index.
+ * The greedy order of the reference -- query i takes its closest candidate not taken by a query before it -- is reproduced
+ * by a fixed-point iteration on the device (every query re-chooses among the candidates no EARLIER query currently holds,
+ * until nothing changes); the rotation histogram and ComputeThreeMaxima (:594-622) run there too.
+ * list_cap = the pool of window-list entries is nq * list_cap (48 covers the tracking radii; the reference's lists have
+ * no bound).  d_result (int32 x 8, device): [0] matches (the return value), [1] = 1 if the lists did not fit the pool --
+ * then nothing was changed and the call is to be repeated with a larger list_cap --, [2] sweeps of the fixed point,
+ * [3] window-list entries; map points -> frame: [4] numOutViewAndBad, [5] fail1, [6] fail2 (:353-354).
+ * nq + n2 <= 38400.  Enqueued on `stream` (NULL = the handle's); no host synchronisation. */
+int orbm_search_by_projection_frame_device(orbm_t *h, int check_orientation, const uint8_t *d_q_desc, const float *d_q_xy,
+                                           const float *d_q_radius, const int32_t *d_q_octave, const float *d_q_angle,
+                                           const uint8_t *d_q_ok, int nq, const void *d_kps2, const uint8_t *d_desc2,
+                                           const int32_t *d_cell_start, const int32_t *d_cell_items, int grid_cols, int grid_rows,
+                                           int n2, int list_cap, int32_t *d_frame_mp, int32_t *d_result, void *stream);
+int orbm_search_by_projection_points_device(orbm_t *h, float nn_ratio, const uint8_t *d_q_desc, const float *d_q_xy,
+                                            const float *d_q_radius, const int32_t *d_q_level, const uint8_t *d_q_ok, int nq,
+                                            const void *d_kps2, const uint8_t *d_desc2, const int32_t *d_cell_start,
+                                            const int32_t *d_cell_items, int grid_cols, int grid_rows, int n2, int list_cap,
+                                            int32_t *d_frame_mp, int32_t *d_result, void *stream);
+
 /* MapPoint::computeDescriptor (modules/BasicObject/MapPoint.cpp:103-152) for n_groups map points at once.
  * Group g = the descriptors desc[off[g] .. off[g+1]) of one point's observations (the caller skips bad key frames,
  * :115-120).  best_idx[g] = index inside the group of the descriptor with the least median Hamming distance to the

@@ -811,6 +811,151 @@ struct PinBuf {
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+// ---------------------------------------------------------------------------------------------
+// The greedy pass of SearchByProjection on the device (ORBMatcher.cpp:229-246 frame -> frame, :379-407 map points ->
+// frame).  The reference walks the queries in order and lets each take its closest candidate that is still free, where
+// "free" depends on what the queries BEFORE it took -- a sequential chain.  Fixed point instead: every query holds a
+// tentative choice; one sweep recomputes all choices at once, query i seeing a candidate as free iff no query j < i
+// currently holds it (owner[c] = the smallest holder, one atomicMin per query).  Query 0 depends on nothing, so it is
+// final after the first sweep; query i is final one sweep after everything before it is: the sweeps reach the sequential
+// result in at most nq + 1 rounds (a handful in practice: a round per link of the longest displacement chain), and a
+// sweep that changes nothing proves it.  The rotation histogram, ComputeThreeMaxima (:594-622) and the removal of the
+// matches outside the three main bins (:261-271) run in the same kernel.  One workgroup per call: every step is a
+// barrier apart.  MODE 0 = frame -> frame (best only, TH_HIGH), MODE 1 = map points -> frame (best / second with their
+// levels and the ratio test of :402).
+// result[0] = matches, [1] = 1 when the packed lists overflowed the pool (nothing done), [2] = sweeps, [3] = list
+// entries; MODE 1: [4] = queries switched off (numOutViewAndBad), [5] = fail1, [6] = fail2.
+// ---------------------------------------------------------------------------------------------
+#define PR_T 1024
+template <int MODE>
+__global__ __launch_bounds__(PR_T) void k_projection_resolve(const int32_t *__restrict__ counts, const int32_t *__restrict__ offs,
+                                                             const uint32_t *__restrict__ pool, int pool_cap,
+                                                             const int32_t *__restrict__ total, int nq, int n2,
+                                                             const orbx_kp *__restrict__ kps2, const float *__restrict__ q_angle,
+                                                             float nn_ratio, int check_orientation,
+                                                             int32_t *__restrict__ frame_mp, int32_t *__restrict__ result)
+{
+    extern __shared__ int32_t pr_lds[];
+    int32_t *owner = pr_lds, *assign = pr_lds + n2; // owner[n2], assign[nq]
+    __shared__ int s_hist[ORBM_HISTO_LENGTH], s_keep[3], s_n[4];
+    const int tid = threadIdx.x;
+    const int tot = *total;
+    if (tot > pool_cap) { // a window list longer than the pool: the caller repeats the call with a larger one
+        if (tid == 0) { result[0] = 0; result[1] = 1; result[2] = 0; result[3] = tot; }
+        return;
+    }
+    for (int i = tid; i < nq; i += PR_T) assign[i] = -1;
+    if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
+    if (tid < 4) s_n[tid] = 0;
+    // one sweep's outcome for query i: the candidate it takes (-1 none), and for MODE 1 why not (1 = ratio test, 2 = too far)
+    auto choose = [&](int i, int *why) -> int {
+        const int n = counts[i];
+        *why = 0;
+        if (n <= 0) return -1;
+        const uint32_t *e = pool + offs[i];
+        if (MODE == 0) {
+            int best = ORBM_TH_HIGH + 1, idx = -1;
+            for (int t = 0; t < n; ++t) {
+                const int c = (int)(e[t] & 0x3FFFFFu), d = (int)(e[t] >> 22);
+                if (owner[c] < i) continue; // taken before this call (-1) or by an earlier query (:235)
+                if (d < best) { best = d; idx = c; }
+            }
+            return best <= ORBM_TH_HIGH ? idx : -1; // :244
+        }
+        int best = 256, bestLevel = -1, second = 257, secondLevel = -1, idx = -1;
+        for (int t = 0; t < n; ++t) {
+            const int c = (int)(e[t] & 0x3FFFFFu), d = (int)(e[t] >> 22);
+            if (owner[c] < i) continue; // :383
+            if (d < best) { second = best; best = d; secondLevel = bestLevel; bestLevel = kps2[c].octave; idx = c; }
+            else if (d < second) { second = d; secondLevel = kps2[c].octave; }
+        }
+        if (best <= ORBM_TH_HIGH) {
+            if (bestLevel == secondLevel && (float)best > nn_ratio * (float)second) { *why = 1; return -1; } // :402
+            return idx;
+        }
+        *why = 2;
+        return -1;
+    };
+    int sweeps = 0;
+    for (;;) {
+        __syncthreads();
+        for (int c = tid; c < n2; c += PR_T) owner[c] = frame_mp[c] != -1 ? -1 : INT_MAX;
+        __syncthreads();
+        for (int i = tid; i < nq; i += PR_T)
+            if (assign[i] >= 0) atomicMin(&owner[assign[i]], i);
+        __syncthreads();
+        int changed = 0;
+        for (int i = tid; i < nq; i += PR_T) {
+            int why;
+            const int c = choose(i, &why);
+            if (c != assign[i]) { assign[i] = c; changed = 1; }
+        }
+        ++sweeps;
+        if (!__syncthreads_or(changed) || sweeps > nq + 1) break;
+    }
+    // ---- the stable choices become the frame's map points; counters; rotation histogram
+    // (owner[] of the last sweep is consistent with the stable assign[]: choose() gives the final outcome again)
+    for (int i = tid; i < nq; i += PR_T) {
+        int why;
+        const int c = choose(i, &why);
+        if (MODE == 1) {
+            if (counts[i] < 0) atomicAdd(&s_n[1], 1);
+            if (why == 1) atomicAdd(&s_n[2], 1);
+            if (why == 2) atomicAdd(&s_n[3], 1);
+        }
+        if (c < 0) continue;
+        atomicAdd(&s_n[0], 1);
+        if (MODE == 0 && check_orientation) {
+            const float factor = 1.f / ORBM_HISTO_LENGTH; // :205: only bins 0..12 fill up
+            float rot = ORB_FSUB(q_angle[i], kps2[c].angle);
+            if (rot < 0.f) rot = ORB_FADD(rot, 360.f);
+            int bin = orb_round_f(ORB_FMUL(rot, factor));
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            atomicAdd(&s_hist[bin], 1);
+        }
+    }
+    __syncthreads();
+    if (MODE == 0 && check_orientation && tid == 0) { // ComputeThreeMaxima (:594-622)
+        int max1 = 0, max2 = -1, max3 = -2, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < ORBM_HISTO_LENGTH; ++i) {
+            const int n = s_hist[i];
+            if (n > max1) { max3 = max2; max2 = max1; max1 = n; i3 = i2; i2 = i1; i1 = i; }
+            else if (n > max2) { max3 = max2; max2 = n; i3 = i2; i2 = i; }
+            else if (n > max3) { max3 = n; i3 = i; }
+        }
+        if (max2 < max1 / 10) { i2 = -1; i3 = -1; }
+        else if (max3 < max1 / 10) i3 = -1;
+        s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+    }
+    __syncthreads();
+    for (int i = tid; i < nq; i += PR_T) {
+        const int c = assign[i];
+        if (c < 0) continue;
+        bool keep = true;
+        if (MODE == 0 && check_orientation) {
+            const float factor = 1.f / ORBM_HISTO_LENGTH;
+            float rot = ORB_FSUB(q_angle[i], kps2[c].angle);
+            if (rot < 0.f) rot = ORB_FADD(rot, 360.f);
+            int bin = orb_round_f(ORB_FMUL(rot, factor));
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            keep = bin == s_keep[0] || bin == s_keep[1] || bin == s_keep[2];
+            if (!keep) atomicSub(&s_n[0], 1);
+        }
+        if (keep) frame_mp[c] = i; // :245 / :406
+    }
+    __syncthreads();
+    if (tid == 0) {
+        result[0] = s_n[0]; result[1] = 0; result[2] = sweeps; result[3] = tot;
+        if (MODE == 1) { result[4] = s_n[1]; result[5] = s_n[2]; result[6] = s_n[3]; }
+    }
+}
+// window levels of the two searches: octave - 1 .. octave + hi (:226-229 hi = 1, :367-369 hi = 0)
+__global__ void k_projection_levels(const int32_t *__restrict__ lv, int n, int hi, int32_t *__restrict__ lo_out, int32_t *__restrict__ hi_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { lo_out[i] = lv[i] - 1; hi_out[i] = lv[i] + hi; }
+}
+
 struct orbm_ctx {
     int device;
     hipStream_t stream;
@@ -1732,6 +1877,70 @@ extern "C" int orbm_search_fuse(orbm_t *c, const uint8_t *q_desc, const float *q
     }
     *n_found = found;
     return ORBX_OK;
+}
+
+// SearchByProjection on a device-resident frame record, greedy pass included: window lists (k_window_lists, packed) and
+// k_projection_resolve enqueued back to back on one stream; frame_mp is read and written in device memory.
+static int projection_device(orbm_ctx *c, int mode, float nn_ratio, int check_orientation, const uint8_t *d_q_desc,
+                             const float *d_q_xy, const float *d_q_radius, const int32_t *d_q_level, const float *d_q_angle,
+                             const uint8_t *d_q_ok, int nq, const void *d_kps2, const uint8_t *d_desc2,
+                             const int32_t *d_cell_start, const int32_t *d_cell_items, int grid_cols, int grid_rows, int n2,
+                             int list_cap, int32_t *d_frame_mp, int32_t *d_result, void *stream)
+{
+    if (!c || !d_q_desc || !d_q_xy || !d_q_radius || !d_q_level || !d_q_ok || !d_kps2 || !d_desc2 || !d_cell_start ||
+        !d_cell_items || !d_frame_mp || !d_result || (mode == 0 && !d_q_angle) || grid_cols < 1 || grid_rows < 1 || nq < 0 ||
+        n2 < 0 || list_cap < 1)
+        return orbx_set_error(ORBX_E_ARG, "bad argument");
+    if (n2 >= (1 << 22)) return orbx_set_error(ORBX_E_UNSUPPORTED, "more than 2^22 key points");
+    const size_t lds = ((size_t)n2 + (size_t)nq) * 4;
+    if (lds > 150 * 1024) return orbx_set_error(ORBX_E_UNSUPPORTED, "nq + n2 above 38400: the greedy pass keeps both in LDS");
+    M_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // scratch: [total, pad x3][counts nq][offs nq][lo nq][hi nq][pool nq * list_cap]
+    const size_t pool_cap = (size_t)nq * list_cap, head = 16 + (size_t)nq * 16;
+    M_TRY(c->w_out.need(head + pool_cap * 4 + 16));
+    int32_t *d_total = (int32_t *)c->w_out.p, *d_counts = d_total + 4, *d_offs = d_counts + nq, *d_lo = d_offs + nq, *d_hi = d_lo + nq;
+    uint32_t *d_pool = (uint32_t *)(d_hi + nq);
+    M_TRY(hipMemsetAsync(d_total, 0, 16, s));
+    if (nq > 0) {
+        hipLaunchKernelGGL(k_projection_levels, dim3((nq + 255) / 256), dim3(256), 0, s, d_q_level, nq, mode == 0 ? 1 : 0, d_lo, d_hi);
+        hipLaunchKernelGGL(k_window_lists, dim3((nq + 3) / 4), dim3(256), 0, s, (const orbx_kp *)d_kps2, d_desc2, d_cell_start,
+                           d_cell_items, grid_cols, grid_rows, d_q_desc, d_q_xy, d_q_radius, d_lo, d_hi, d_q_ok, nq, 0, nullptr,
+                           (int)std::min(pool_cap, (size_t)INT_MAX), d_counts, d_pool, d_total, d_offs);
+    }
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_projection_resolve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_projection_resolve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        configured = true;
+    }
+    if (mode == 0)
+        hipLaunchKernelGGL(k_projection_resolve<0>, dim3(1), dim3(PR_T), lds, s, d_counts, d_offs, d_pool, (int)std::min(pool_cap, (size_t)INT_MAX),
+                           d_total, nq, n2, (const orbx_kp *)d_kps2, d_q_angle, nn_ratio, check_orientation, d_frame_mp, d_result);
+    else
+        hipLaunchKernelGGL(k_projection_resolve<1>, dim3(1), dim3(PR_T), lds, s, d_counts, d_offs, d_pool, (int)std::min(pool_cap, (size_t)INT_MAX),
+                           d_total, nq, n2, (const orbx_kp *)d_kps2, d_q_angle, nn_ratio, check_orientation, d_frame_mp, d_result);
+    M_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+extern "C" int orbm_search_by_projection_frame_device(orbm_t *c, int check_orientation, const uint8_t *d_q_desc, const float *d_q_xy,
+                                                      const float *d_q_radius, const int32_t *d_q_octave, const float *d_q_angle,
+                                                      const uint8_t *d_q_ok, int nq, const void *d_kps2, const uint8_t *d_desc2,
+                                                      const int32_t *d_cell_start, const int32_t *d_cell_items, int grid_cols,
+                                                      int grid_rows, int n2, int list_cap, int32_t *d_frame_mp, int32_t *d_result,
+                                                      void *stream)
+{
+    return projection_device(c, 0, 0.f, check_orientation, d_q_desc, d_q_xy, d_q_radius, d_q_octave, d_q_angle, d_q_ok, nq, d_kps2,
+                             d_desc2, d_cell_start, d_cell_items, grid_cols, grid_rows, n2, list_cap, d_frame_mp, d_result, stream);
+}
+extern "C" int orbm_search_by_projection_points_device(orbm_t *c, float nn_ratio, const uint8_t *d_q_desc, const float *d_q_xy,
+                                                       const float *d_q_radius, const int32_t *d_q_level, const uint8_t *d_q_ok, int nq,
+                                                       const void *d_kps2, const uint8_t *d_desc2, const int32_t *d_cell_start,
+                                                       const int32_t *d_cell_items, int grid_cols, int grid_rows, int n2, int list_cap,
+                                                       int32_t *d_frame_mp, int32_t *d_result, void *stream)
+{
+    return projection_device(c, 1, nn_ratio, 0, d_q_desc, d_q_xy, d_q_radius, d_q_level, nullptr, d_q_ok, nq, d_kps2, d_desc2,
+                             d_cell_start, d_cell_items, grid_cols, grid_rows, n2, list_cap, d_frame_mp, d_result, stream);
 }
 
 // The window lists of one device-resident frame record (orbx_extract_batch_device -> orbf_frame_post_device): the grid

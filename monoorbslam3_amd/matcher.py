@@ -51,6 +51,10 @@ def _mlib():
             "orbm_search_by_projection_points": (i32, [vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp,
                                                        C.POINTER(i32), vp]),
             "orbm_search_fuse": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp, C.POINTER(i32)]),
+            "orbm_search_by_projection_frame_device": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32,
+                                                             vp, vp, vp]),
+            "orbm_search_by_projection_points_device": (i32, [vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32,
+                                                              vp, vp, vp]),
             "orbm_window_lists_device": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]),
             "orbm_distinctive_descriptors": (i32, [vp, vp, vp, i32, vp]),
             "orbm_distinctive_descriptors_device": (i32, [vp, vp, vp, i32, vp, vp]),
@@ -258,6 +262,25 @@ class ORBMatcher:
                                                             _vp(qk), len(qd), _vp(k2), _vp(d2), len(k2), img_w, img_h,
                                                             _vp(mp), C.byref(n), _vp(cnt)))
         return n.value, mp, tuple(cnt.tolist())
+
+    # -- the same two searches on a device-resident frame record, greedy pass on the device -----------------------
+    def SearchByProjectionDevice(self, mode, d, nq, n2, grid_cols, grid_rows, list_cap=48, stream=None):
+        """mode "frame" | "points".  d: dict of torch device tensors -- q_desc [nq,32] u8, q_xy [nq,2] f32, q_radius f32,
+        q_level i32 (octave / predicted level), q_angle f32 (frame only), q_ok u8, kps2 (undistorted records, u8 [*,28]),
+        desc2 u8 [*,32], cell_start i32, cell_items i32, frame_mp i32 [n2] (in/out), result i32 [8] (out).  Enqueues on
+        `stream`; nothing is copied or synchronised (orbm_search_by_projection_{frame,points}_device)."""
+        import torch
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        p = lambda k: d[k].data_ptr()  # noqa: E731
+        if mode == "frame":
+            _lib.check(self._L.orbm_search_by_projection_frame_device(
+                self._hd._h, int(self.be_check_orientation), p("q_desc"), p("q_xy"), p("q_radius"), p("q_level"), p("q_angle"),
+                p("q_ok"), nq, p("kps2"), p("desc2"), p("cell_start"), p("cell_items"), grid_cols, grid_rows, n2, list_cap,
+                p("frame_mp"), p("result"), st))
+        else:
+            _lib.check(self._L.orbm_search_by_projection_points_device(
+                self._hd._h, self.nn_ratio, p("q_desc"), p("q_xy"), p("q_radius"), p("q_level"), p("q_ok"), nq, p("kps2"),
+                p("desc2"), p("cell_start"), p("cell_items"), grid_cols, grid_rows, n2, list_cap, p("frame_mp"), p("result"), st))
 
     # -- static SearchByProjection(keyFrame, mapPoints, Map*, th): the fuse (ORBMatcher.cpp:524-592) ------------
     def SearchFuse(self, q_desc, q_xy, q_radius, q_level, q_ok, kps, desc, img_w, img_h, sigma2):

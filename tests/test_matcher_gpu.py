@@ -507,3 +507,163 @@ def test_window_searches_device_lists_equal_the_host_twin(oracle_mod, monkeypatc
     got = m.SearchByProjectionFrame(d1[:50], q_xy[:50], big[:50], k1["octave"][:50], k1["angle"][:50], np.ones(50, np.uint8), k2, d2, w, h, mp0)
     ref = oracle_mod.search_by_projection_frame(False, d1[:50], q_xy[:50], big[:50], k1["octave"][:50], k1["angle"][:50], np.ones(50, np.uint8), k2, d2, w, h, mp0)
     assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
+
+
+def _device_record(w, h, nf, seed):
+    """extract -> orbf frame record, everything left on the device; returns the tensors and host copies for the oracle"""
+    import torch
+    from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
+    from monoorbslam3_amd.frame import FramePost
+    dev = torch.device("cuda", 0)
+    img = torch.from_numpy(synth.make_frames(1, w, h, seed=seed)).to(dev)
+    ex = ORBExtractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    cap = ex.max_keypoints(w, h)
+    d_kp = torch.zeros((1, cap, 28), dtype=torch.uint8, device=dev)
+    d_un = torch.zeros((1, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ex.extract_batch_device(img.data_ptr(), 1, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), st)
+    fp = FramePost(w, h, 458.654, 457.296, 367.215, 248.375, dist=(-0.2834, 0.0739, 1.9e-4, 1.8e-5))
+    d_start = torch.zeros((1, fp.n_cells + 1), dtype=torch.int32, device=dev)
+    d_items = torch.zeros((1, cap), dtype=torch.int32, device=dev)
+    fp.post_device(1, d_kp.data_ptr(), d_n.data_ptr(), cap, d_un.data_ptr(), d_start.data_ptr(), d_items.data_ptr(), st)
+    torch.cuda.synchronize()
+    n = int(d_n[0])
+    kps = np.frombuffer(d_un[0, :n].cpu().numpy().tobytes(), KP_DTYPE)
+    desc = d_desc[0, :n].cpu().numpy()
+    return dict(dev=dev, n=n, kps=kps, desc=desc, d_un=d_un, d_desc=d_desc, d_start=d_start, d_items=d_items, cols=fp.cols,
+                rows=fp.rows)
+
+
+@pytest.mark.parametrize("mode", ["frame", "points"])
+@pytest.mark.parametrize("scene", ["tracking", "contended", "crowded_window"])
+def test_search_by_projection_greedy_pass_on_the_device(oracle_mod, mode, scene):
+    """ORBMatcher.cpp:229-246 / :379-407 with the greedy claim order resolved on the device (fixed point over the window
+    lists) against the oracle's sequential loops: identical frame_mp, match count and counters.
+    tracking: every query near its own key point (few conflicts).  contended: 1500 queries drawn around 40 key points with
+    radii that cover many of them -- most queries lose their first choice, some several times, chains of displacements.
+    crowded_window: every query sees the same few candidates (all 600 queries at one spot), most end without a match."""
+    import torch
+    from monoorbslam3_amd.matcher import ORBMatcher
+    w, h = 752, 480
+    R = _device_record(w, h, 1500, seed=91)
+    dev, n, kps, desc = R["dev"], R["n"], R["kps"], R["desc"]
+    rng = np.random.RandomState({"tracking": 1, "contended": 2, "crowded_window": 3}[scene])
+    if scene == "tracking":
+        nq = 1200
+        pick = rng.randint(0, n, nq)
+        q_xy = np.stack([kps["x"][pick] + rng.normal(0, 3, nq), kps["y"][pick] + rng.normal(0, 3, nq)], 1)
+        q_r = (7.0 * 1.2 ** kps["octave"][pick]).astype(np.float32)
+        flip = 0.04
+    elif scene == "contended":
+        nq = 1500
+        hubs = rng.randint(0, n, 40)
+        pick = hubs[rng.randint(0, 40, nq)]
+        q_xy = np.stack([kps["x"][pick] + rng.normal(0, 10, nq), kps["y"][pick] + rng.normal(0, 10, nq)], 1)
+        q_r = rng.choice([15.0, 25.0, 40.0], nq).astype(np.float32)
+        flip = 0.12
+    else:
+        nq = 600
+        pick = np.full(nq, rng.randint(0, n))
+        q_xy = np.tile([[kps["x"][pick[0]], kps["y"][pick[0]]]], (nq, 1)) + rng.normal(0, 1.5, (nq, 2))
+        q_r = np.full(nq, 30.0, np.float32)
+        flip = 0.2
+    q_xy = q_xy.astype(np.float32)
+    q_level = np.clip(kps["octave"][pick] + rng.randint(-1, 2, nq), 0, 7).astype(np.int32)
+    q_angle = ((kps["angle"][pick] + rng.normal(0, 20, nq)) % 360).astype(np.float32)
+    q_ok = (rng.uniform(size=nq) > 0.07).astype(np.uint8)
+    q_desc = (desc[pick] ^ np.packbits(rng.uniform(size=(nq, 256)) < flip, axis=1, bitorder="little")).astype(np.uint8)
+    mp0 = np.where(rng.uniform(size=n) < 0.15, 7, -1).astype(np.int32)      # some slots already hold a map point
+    m = ORBMatcher(0.8, True)
+    # the oracle's sequential loops (and the host entry point, whose greedy pass is the reference's loop on the same lists)
+    if mode == "frame":
+        want_n, want_mp = oracle_mod.search_by_projection_frame(True, q_desc, q_xy, q_r, q_level, q_angle, q_ok, kps, desc, w, h, mp0)
+        host_n, host_mp = m.SearchByProjectionFrame(q_desc, q_xy, q_r, q_level, q_angle, q_ok, kps, desc, w, h, mp0)
+        want_cnt = None
+    else:
+        want_n, want_mp, want_cnt = oracle_mod.search_by_projection_points(0.8, q_desc, q_xy, q_r, q_level, q_ok, kps, desc, w, h, mp0)
+        host_n, host_mp, host_cnt = m.SearchByProjectionPoints(q_desc, q_xy, q_r, q_level, q_ok, kps, desc, w, h, mp0)
+        assert tuple(host_cnt) == tuple(want_cnt)
+    assert host_n == want_n and np.array_equal(host_mp, want_mp)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    mp_full = np.full(R["d_un"].shape[1], 5, np.int32)
+    mp_full[:n] = mp0
+    d = dict(q_desc=t(q_desc), q_xy=t(q_xy), q_radius=t(q_r), q_level=t(q_level), q_angle=t(q_angle), q_ok=t(q_ok),
+             kps2=R["d_un"], desc2=R["d_desc"], cell_start=R["d_start"], cell_items=R["d_items"], frame_mp=t(mp_full),
+             result=torch.full((8,), -7, dtype=torch.int32, device=dev))
+    cap = 48
+    for attempt in range(6):     # the documented protocol: a pool that is too small reports it and changes nothing
+        d["frame_mp"] = t(mp_full)
+        m.SearchByProjectionDevice(mode, d, nq, n, R["cols"], R["rows"], list_cap=cap)
+        torch.cuda.synchronize()
+        res = d["result"].cpu().numpy()
+        if res[1] == 0:
+            break
+        assert np.array_equal(d["frame_mp"].cpu().numpy(), mp_full)
+        cap *= 4
+    assert res[1] == 0
+    got_mp = d["frame_mp"].cpu().numpy()
+    print("%s / %s: %d queries, %d list entries, %d matches, %d sweeps, list_cap %d" % (mode, scene, nq, res[3], res[0], res[2], cap))
+    assert res[0] == want_n
+    assert np.array_equal(got_mp[:n], want_mp) and np.all(got_mp[n:] == 5)
+    if mode == "points":
+        assert tuple(res[4:7]) == tuple(want_cnt)
+    if scene != "tracking":
+        assert res[2] >= 3        # the scene really needs the iteration
+
+
+@pytest.mark.parametrize("mode", ["frame", "points"])
+def test_search_by_projection_device_longest_displacement_chain(oracle_mod, mode):
+    """The worst case for the fixed point: 96 candidates in one window, every query carries the same descriptor and so
+    wants them in the same order -- query i ends with the (i+1)-th closest one after being displaced i times.  The record
+    is hand-made (positions, descriptors with 1, 2, 3 ... bits flipped, the oracle's CSR grid), uploaded, and the device
+    result must still be the sequential loop's, in about as many sweeps as the chain is long."""
+    import torch
+    from monoorbslam3_amd.extractor import KP_DTYPE
+    from monoorbslam3_amd.matcher import ORBMatcher
+    dev = torch.device("cuda", 0)
+    w, h, n, nq = 752, 480, 96, 120
+    rng = np.random.RandomState(11)
+    kps = np.zeros(n, KP_DTYPE)
+    kps["x"] = 300 + rng.uniform(-8, 8, n).astype(np.float32)
+    kps["y"] = 200 + rng.uniform(-8, 8, n).astype(np.float32)
+    kps["size"], kps["octave"], kps["class_id"] = 1.0, 2, -1
+    kps["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    base = rng.randint(0, 256, 32).astype(np.uint8)
+    desc = np.tile(base, (n, 1))
+    order = rng.permutation(n)              # candidate order[k] is the k-th closest: k + 1 flipped bits
+    for k, c in enumerate(order):
+        bits = np.zeros(256, bool)
+        bits[rng.choice(256, k + 1, replace=False)] = True
+        desc[c] ^= np.packbits(bits, bitorder="little")
+    _, un, start, items = oracle_mod.frame_post(w, h, 458.654, 457.296, 367.215, 248.375, (0.0, 0.0, 0.0, 0.0), kps, undistort=False)
+    q_desc = np.tile(base, (nq, 1))
+    q_xy = np.tile(np.float32([[300, 200]]), (nq, 1))
+    q_r = np.full(nq, 25.0, np.float32)
+    q_level = np.full(nq, 2, np.int32)
+    q_angle = rng.uniform(0, 360, nq).astype(np.float32)
+    q_ok = np.ones(nq, np.uint8)
+    mp0 = np.full(n, -1, np.int32)
+    if mode == "frame":
+        want_n, want_mp = oracle_mod.search_by_projection_frame(False, q_desc, q_xy, q_r, q_level, q_angle, q_ok, un, desc, w, h, mp0)
+        assert want_n == n and np.array_equal(want_mp[order], np.arange(n))    # query i holds the i-th closest candidate
+    else:
+        want_n, want_mp, want_cnt = oracle_mod.search_by_projection_points(0.8, q_desc, q_xy, q_r, q_level, q_ok, un, desc, w, h, mp0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    cols, rows = (w + 39) // 40, (h + 39) // 40
+    assert len(start) == cols * rows + 1
+    d = dict(q_desc=t(q_desc), q_xy=t(q_xy), q_radius=t(q_r), q_level=t(q_level), q_angle=t(q_angle), q_ok=t(q_ok),
+             kps2=t(np.frombuffer(un.tobytes(), np.uint8).reshape(n, 28).copy()), desc2=t(desc), cell_start=t(start.astype(np.int32)),
+             cell_items=t(items.astype(np.int32)), frame_mp=t(mp0), result=torch.zeros(8, dtype=torch.int32, device=dev))
+    m = ORBMatcher(0.8, False)
+    m.SearchByProjectionDevice(mode, d, nq, n, cols, rows, list_cap=128)
+    torch.cuda.synchronize()
+    res = d["result"].cpu().numpy()
+    print("%s: %d matches in %d sweeps over %d list entries" % (mode, res[0], res[2], res[3]))
+    assert res[1] == 0 and res[3] == nq * n
+    assert res[0] == want_n and np.array_equal(d["frame_mp"].cpu().numpy(), want_mp)
+    if mode == "frame":
+        assert res[2] >= n // 2
+    else:
+        assert tuple(res[4:7]) == tuple(want_cnt)
