@@ -29,9 +29,17 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-# integer VALU issue ceiling measured on MI355X with tools/microbench/valu_peak.hip (xor + v_bcnt mix, 2048 x 256
-# threads): 557 G wave-instructions/s = 35.7 T lane-ops/s.  The Hamming brute force needs >= 16 of them per pair.
-VALU_PEAK_GWINST = 557.4
+# VALU issue rates measured on MI355X (tools/microbench/valu_ops2.hip, valu_ops3.hip -> profiles/r02_valu_ops2.txt,
+# r03_valu_ops3.txt), G wave-instructions/s over the chip: the plain 32-bit and / or / xor / add / sub / lshr / mov /
+# v_bitop3 class against everything else (VOP3, packed, SDWA, DPP, min / max, compares, shifts left, scalar operands).
+# A kernel's issue floor is the sum over its instructions of 1 / rate(class): tools/isa_mix.py does that for FAST
+# (profiles/fast_mix.json); one number for every stage would be wrong by up to 1.7 x either way.
+VALU_RATE_CHEAP_GWINST = 850.0
+VALU_RATE_SLOW_GWINST = 540.0
+# dense FP4 matrix rate: v_mfma_f32_32x32x64_f8f6f4 (cbsz = blgp = 4) issues every 32 cycles per SIMD (measured,
+# tools/microbench/fp4_hamming.hip) = 2048 multiply-adds = 4096 operations per cycle per SIMD; x 1024 SIMDs x 2.4 GHz =
+# 10.07 POP/s at the nominal clock (MI355X_MICROARCH.md: ~10 PF dense FP4)
+MFMA_FP4_PEAK_TOPS = 10066.0
 
 
 def baseline_metric():
@@ -372,6 +380,34 @@ def main():
         torch.cuda.synchronize()
         match_ms += ev_m0.elapsed_time(ev_m1) / n_prof
     ex.set_stage_timing(False)
+    # ---- the same kernels timed INSIDE overlapped steps (three streams as in the timed region): FAST by events on its own
+    # launch streams (orbx_set_stage_timing(2)), the match by events on the match stream
+    fast_in_step_ms, match_in_step_ms = None, None
+    if hasattr(ex, "fast_time_in_step_ms"):
+        torch.cuda.synchronize()
+        ex.set_stage_timing(2)
+        accf, accm, n_in = 0.0, 0.0, 6
+        evm = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_in + 2)]
+        for k in range(n_in + 2):
+            i = step_no[0] % NBUF
+            step_no[0] += 1
+            side.wait_event(ev_matched[i])
+            ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, d_kp[i].data_ptr(), d_desc[i].data_ptr(), cap,
+                                    d_n[i].data_ptr(), stream)
+            ev_extracted[i].record(side)
+            if not args.no_match:
+                mstream.wait_event(ev_extracted[i])
+                evm[k][0].record(mstream)
+                match(i, mstream.cuda_stream)
+                evm[k][1].record(mstream)
+            ev_matched[i].record(mstream)
+            if k >= 2:  # the FAST events of this step are read before the next step re-records them
+                accf += ex.fast_time_in_step_ms()[0] / n_in
+        torch.cuda.synchronize()
+        if not args.no_match:
+            accm = sum(evm[k][0].elapsed_time(evm[k][1]) for k in range(2, n_in + 2)) / n_in
+        ex.set_stage_timing(False)
+        fast_in_step_ms, match_in_step_ms = accf, (accm if not args.no_match else None)
     counts = d_n[0].cpu().numpy()
     # ---- the timed match is checked, not only timed: a sample of frame 0's rows against frame 1 by a numpy popcount scan
     match_check = None
@@ -396,10 +432,11 @@ def main():
     acc_all["match_best2"] = match_ms
     alg["match_best2"] = int(2 * round(kp_mean) * 32 + round(kp_mean) * 8)
     stage_gbs["match_best2"] = alg["match_best2"] * B / (match_ms * 1e-3) / 1e9 if match_ms > 0 else None
-    # `roofline` is reported for the kernel that takes the most time among ALL stages of a step, the match included
-    # (stage times: HIP events on the launch stream, one stream, no overlap -- see stages_ms_note).
+    # `roofline` is reported for the kernel that takes the most time among ALL stages of a step, the match included, by its
+    # time INSIDE an overlapped step where that was measured (FAST, match), else by its isolated time.
     acc = acc_all
-    dominant = max(acc, key=lambda k: acc[k])
+    in_step = {"fast": fast_in_step_ms, "match_best2": match_in_step_ms}
+    dominant = max(acc, key=lambda k: in_step.get(k) or acc[k])
     # HBM bytes / VALU instructions per stage from separate rocprofv3 --pmc passes (tools/profile_round.sh).  They are
     # REPLAYED from files under profiles/, not measured in this run: each carries the hash of the kernel sources it was
     # collected on, and is dropped from the line when the sources have changed since.
@@ -423,26 +460,54 @@ def main():
     vj, valu_source = replayed("pmc_valu.json")
     valu = None
     if vj:
-        valu = {k: {"wave_instr_per_step": int(n),
-                    "achieved_gwinst_s": round(n / (acc[k] * 1e-3) / 1e9, 1),
-                    "frac_of_calibrated_peak": round(n / (acc[k] * 1e-3) / 1e9 / VALU_PEAK_GWINST, 3)}
+        valu = {k: {"wave_instr_per_step": int(n), "achieved_gwinst_s": round(n / (acc[k] * 1e-3) / 1e9, 1)}
                 for k, n in vj.get("wave_instr_per_step", {}).items() if k in acc and acc[k] > 0}
+    # FAST's mix-weighted issue floor (tools/isa_mix.py: instruction classes from the ISA x measured stage counts, priced
+    # with the measured per-class issue rates); replayed like the counters, for this batch size only
+    fast_mix = None
+    try:
+        fm = json.load(open(os.path.join(ROOT, "profiles", "fast_mix.json")))
+        if fm.get("frames") == B and fm.get("kernels_sha16") == src_hash and (W, H, NF) == (1242, 375, 2000):
+            fast_mix = fm
+    except Exception:
+        pass
     fb_ms = acc["fast"] + acc["orient_desc"]
     fast_brief_gbs = 2 * P * B / (fb_ms * 1e-3) / 1e9
     pairs = float((counts.astype(np.float64) * np.roll(counts, -1)).sum())
 
     def roof(k):
-        """Achieved algorithmic HBM bytes per second of stage k against the 8 TB/s peak.  Every stage here is bounded by
-        integer VALU issue before it is bounded by HBM; `limiter` says so where the instruction
-        counts are available."""
+        """Achieved algorithmic HBM bytes per second of stage k against the 8 TB/s peak, from the isolated launch time and --
+        where measured -- from the time inside an overlapped step.  Every stage here is bounded by instruction issue before
+        it is bounded by HBM; `limiter` says by how much where the instruction mix was priced."""
         g = stage_gbs.get(k)
         r = {"kernel": k, "bound": "hbm", "achieved": round(g, 1) if g else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(g / HBM_PEAK_GBS, 4) if g else None,
              "traffic": (tj["bytes_per_launch"].get(k) if tj else None), "traffic_source": traffic_source,
              "algorithmic_bytes_per_launch": int(alg[k] * B), "launch_ms": round(acc[k], 4)}
-        if valu and k in valu:
-            r["limiter"] = {"kind": "valu_issue", "frac_of_calibrated_peak": valu[k]["frac_of_calibrated_peak"]}
+        if in_step.get(k):
+            gi = alg[k] * B / (in_step[k] * 1e-3) / 1e9
+            r["launch_ms_in_step"] = round(in_step[k], 4)
+            r["achieved_in_step"] = round(gi, 1)
+            r["frac_in_step"] = round(gi / HBM_PEAK_GBS, 4)
+            r["in_step_note"] = ("HIP events on the kernel's own stream(s) inside overlapped steps issued one at a time "
+                                 "(the previous step's match still in flight); FAST = its two launches summed")
+        if k == "fast" and fast_mix:
+            r["limiter"] = {"kind": "valu_issue_mix_weighted", "issue_floor_ms": fast_mix["issue_floor_ms_per_launch"],
+                            "frac_of_floor": round(fast_mix["issue_floor_ms_per_launch"] / acc[k], 3),
+                            "cheap_class_fraction": fast_mix.get("cheap_fraction_marked"),
+                            "source": "profiles/fast_mix.json (tools/isa_mix.py: ISA instruction classes x stage counts of "
+                                      "tools/fast_mix.py x issue rates of profiles/r02_valu_ops2.txt, r03_valu_ops3.txt; replayed)"}
         return r
+
+    # the dense match runs on the FP4 matrix path: 256 multiply-adds per descriptor pair
+    mfma = None
+    if match_ms > 0:
+        tops = pairs * 512 / (match_ms * 1e-3) / 1e12
+        mfma = {"pairs_per_step": int(pairs), "gpairs_per_s": round(pairs / (match_ms * 1e-3) / 1e9, 2),
+                "pipe": "v_mfma_f32_32x32x64_f8f6f4 (FP4 operands)" if os.environ.get("ORBM_BEST2", "fp4") == "fp4" else os.environ.get("ORBM_BEST2"),
+                "achieved_TOPS": round(tops, 1), "peak_TOPS": MFMA_FP4_PEAK_TOPS, "frac_of_dense_fp4_peak": round(tops / MFMA_FP4_PEAK_TOPS, 3),
+                "note": "2 x 256 operations per 256-bit pair; peak = 4096 operations per cycle per SIMD x 1024 SIMDs x 2.4 GHz "
+                        "(32 cycles per 32x32x64 instruction, measured by tools/microbench/fp4_hamming.hip)"}
 
     out = {
         "metric": baseline_metric(),
@@ -481,18 +546,15 @@ def main():
         "stages_ms_note": "HIP events around each stage with every kernel on ONE stream (orbx_set_stage_timing), extra untimed "
                           "steps; the timed steps overlap FAST / blur / match on three streams, so the stages sum to more "
                           "than ms_per_step",
+        "stages_ms_in_step": {k: (round(v, 4) if v else None) for k, v in in_step.items()},
         "roofline": roof(dominant),
         "roofline_fast": roof("fast"),
-        "roofline_match": dict(roof("match_best2"), valu_popcount={
-            "pairs_per_step": int(pairs), "gpairs_per_s": round(pairs / (match_ms * 1e-3) / 1e9, 2) if match_ms > 0 else None,
-            "frac_of_calibrated_xor_bcnt_peak": round((pairs * 16 / 64) / (match_ms * 1e-3) / (VALU_PEAK_GWINST * 1e9), 3)
-            if match_ms > 0 else None,
-            "note": "16 VALU lane-operations per 256-bit pair at least (8 xor + 8 popcount); peak = %.1f G wave-instructions/s "
-                    "measured with tools/microbench/valu_peak.hip" % VALU_PEAK_GWINST}),
+        "roofline_match": dict(roof("match_best2"), mfma=mfma),
         "roofline_fast_plus_brief": {"bound": "hbm", "achieved": round(fast_brief_gbs, 1), "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": round(fast_brief_gbs / HBM_PEAK_GBS, 4),
                                      "algorithmic_bytes_per_frame": 2 * P},
-        "valu_issue": {"peak_gwinst_s": VALU_PEAK_GWINST, "stages": valu, "source": valu_source},
+        "valu_issue": {"rates_gwinst_s": {"cheap_class": VALU_RATE_CHEAP_GWINST, "slow_class": VALU_RATE_SLOW_GWINST},
+                       "stages": valu, "source": valu_source},
     }
     if e2e is not None:
         out["value_end_to_end"] = e2e

@@ -127,8 +127,14 @@ int orbx_tap_sincos(orbx_t *h, const float *angles_deg, int n, float *cos_sin);
 #define ORBX_STAGE_OCTREE 3
 #define ORBX_STAGE_DESC 4
 #define ORBX_N_STAGES 5
-/* enable = 1: every later extract call records HIP events around each stage */
+/* enable = 1: every later extract call records HIP events around each stage, with every kernel on ONE stream (isolated
+ * stage times).  enable = 2: the call keeps its streams (FAST, blur and the caller's other work overlap as in production) and
+ * events on each FAST launch's own stream bracket it: orbx_fast_times_in_step_ms then gives the kernel's time as it runs
+ * beside the others. */
 int orbx_set_stage_timing(orbx_t *h, int enable);
+/* timing mode 2: sum over the last extract call's FAST launches (one or two: level 0 may start early on the side stream) of
+ * the time between the events around each launch, and their number.  Synchronises on those events. */
+int orbx_fast_times_in_step_ms(orbx_t *h, float *ms_sum, int *n_launches);
 /* milliseconds each stage took in the last extract call (synchronises) */
 int orbx_stage_times_ms(orbx_t *h, float *ms /* ORBX_N_STAGES */);
 

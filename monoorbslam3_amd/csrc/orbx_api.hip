@@ -48,6 +48,7 @@ struct orbx_ctx {
     OrbxLevels *d_levels;
     OrbxTap *d_xtap[ORBX_MAX_LEVELS], *d_ytap[ORBX_MAX_LEVELS];
     int *d_umax, *d_taps;
+    hipEvent_t ev_fast_t[4]; int fast_t_n; // timing mode 2: events around the (up to two) FAST launches of a step
     uint16_t *d_fast_cells; int n_fast_cells;
     uint16_t *d_fast_strips; int n_fast_strips, n_fast_strips0; // strips of all levels / of level 0
     int fast_variant;                                           // 2 = strips (default), 1 = one wave per cell
@@ -489,6 +490,7 @@ extern "C" void orbx_destroy(orbx_t *c)
         if (c->d_ytap[l]) (void)hipFree(c->d_ytap[l]);
     }
     for (int i = 0; i <= ORBX_N_STAGES; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 4; ++i) if (c->ev_fast_t[i]) (void)hipEventDestroy(c->ev_fast_t[i]);
     for (int i = 0; i < 8; ++i) {
         if (c->sub[i]) { (void)hipStreamSynchronize(c->sub[i]); (void)hipStreamDestroy(c->sub[i]); }
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -589,9 +591,16 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     const uint16_t *d_units = strips ? c->d_fast_strips : c->d_fast_cells;
     const int n_units = strips ? c->n_fast_strips : c->n_fast_cells;
     const int n_cells0 = strips ? c->n_fast_strips0 : LV.lv[0].n_cols * LV.lv[0].n_rows;
+    int fast_launch_no = 0;
     auto launch_fast = [&](hipStream_t st, const uint16_t *units, int n) {
+        // timing mode 2: the step keeps its streams, and HIP events on the launch's own stream bracket each FAST launch, so
+        // that the kernel is timed as it runs beside the others (orbx_fast_times_in_step_ms)
+        const bool ft = c->timing == 2 && fast_launch_no < 2 && c->ev_fast_t[0];
+        if (ft) (void)hipEventRecord(c->ev_fast_t[2 * fast_launch_no], st);
         if (strips) orbx_launch_fast_strips(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, units, n, n_frames);
         else orbx_launch_fast(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, units, n, n_frames);
+        if (ft) { (void)hipEventRecord(c->ev_fast_t[2 * fast_launch_no + 1], st); c->fast_t_n = fast_launch_no + 1; }
+        ++fast_launch_no;
     };
     // 7x7 Gaussian of levels [lb, le): on the matrix pipe for the levels that are large enough when the call is a batch
     // (ORBX_BLUR=mfma forces it for any batch, =valu switches it off), the VALU kernels for the rest
@@ -700,8 +709,8 @@ static int enqueue_batch(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t
                          orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n, bool latency)
 {
     c->last_l0 = d_l0; c->last_l0_fs = l0_fs; c->last_l0_pitch = l0_pitch; c->last_frames = n_frames;
-    const int ns = c->timing ? 1 : std::min(c->n_sub, n_frames / 8);
-    if (ns <= 1) return enqueue(c, s, d_l0, l0_fs, l0_pitch, 0, n_frames, d_kp, d_desc, cap, d_n, c->timing != 0, 8, latency);
+    const int ns = c->timing == 1 ? 1 : std::min(c->n_sub, n_frames / 8);
+    if (ns <= 1) return enqueue(c, s, d_l0, l0_fs, l0_pitch, 0, n_frames, d_kp, d_desc, cap, d_n, c->timing == 1, 8, latency);
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     for (int i = 0; i < ns; ++i) {
         const int f0 = (int)((long long)n_frames * i / ns), f1 = (int)((long long)n_frames * (i + 1) / ns);
@@ -929,6 +938,28 @@ extern "C" int orbx_set_stage_timing(orbx_t *c, int enable)
     if (!c) return fail(ORBX_E_ARG, "null handle");
     c->timing = enable;
     c->ev_valid = false;
+    c->fast_t_n = 0;
+    if (enable == 2 && !c->ev_fast_t[0]) {
+        HIP_TRY(hipSetDevice(c->device));
+        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&c->ev_fast_t[i]));
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_fast_times_in_step_ms(orbx_t *c, float *ms_sum, int *n_launches)
+{
+    if (!c || !ms_sum) return fail(ORBX_E_ARG, "null argument");
+    if (c->timing != 2 || c->fast_t_n < 1) return fail(ORBX_E_ARG, "no extract call in timing mode 2 yet");
+    HIP_TRY(hipSetDevice(c->device));
+    float sum = 0.f;
+    for (int i = 0; i < c->fast_t_n; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(c->ev_fast_t[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_fast_t[2 * i], c->ev_fast_t[2 * i + 1]));
+        sum += ms;
+    }
+    *ms_sum = sum;
+    if (n_launches) *n_launches = c->fast_t_n;
     return ORBX_OK;
 }
 

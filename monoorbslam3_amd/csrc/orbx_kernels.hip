@@ -19,16 +19,29 @@ typedef unsigned long long u64;
 // XCD-aware work mapping (speed only, never correctness).  Workgroups are dealt round-robin over the 8 XCDs,
 // each with a private 4 MB L2; linear block id -> (xcd = id % 8, j = id / 8) and XCD x takes the frames
 // congruent to x (mod 8), so everything that touches one frame's pyramid meets in one L2.
+// A call with fewer than 8 frames would leave XCDs idle that way -- a single frame would run on ONE XCD, an eighth of
+// the chip, which is what a latency-bound call can least afford -- so below 8 frames the blocks are dealt in plain order
+// (frame = id / per_frame) and every frame spreads over all XCDs.
 // Launch with orbx_xcd_grid(per_frame, n_frames) blocks.
 __device__ __forceinline__ bool xcd_remap(int per_frame, int n_frames, int *frame, int *item)
 {
+    if (n_frames < 8) {
+        const int id = blockIdx.x, f = id / per_frame;
+        *item = id - f * per_frame;
+        *frame = f;
+        return f < n_frames;
+    }
     const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
     const int g = j / per_frame;
     *item = j - g * per_frame;
     *frame = g * 8 + xcd;
     return *frame < n_frames;
 }
-static inline unsigned orbx_xcd_grid(int per_frame, int n_frames) { return 8u * (unsigned)((n_frames + 7) / 8) * (unsigned)per_frame; }
+static inline unsigned orbx_xcd_grid(int per_frame, int n_frames)
+{
+    if (n_frames < 8) return (unsigned)n_frames * (unsigned)per_frame;
+    return 8u * (unsigned)((n_frames + 7) / 8) * (unsigned)per_frame;
+}
 
 __constant__ __attribute__((aligned(16))) int8_t c_pattern[ORB_PATTERN_POINTS * 2] = {ORB_PATTERN_INT8_LIST};
 
@@ -1665,9 +1678,14 @@ struct OctL {
 #define OCT_NORANK 0xFFFFu
 #define OCT_RANK_BY_COUNTING 320 // final-phase keys up to which ranks are counted instead of sorted
 
+#ifndef OCT_UNROLL
 #define OCT_UNROLL 4
+#endif
 #define OCT_DIGITS0 6 // descent digits computed up front (see more_digits)
-#define OCT_REG 8 // candidates per thread whose (node, descent code, record) live in registers: the first 4096 of a level
+#ifndef OCT_REG
+#define OCT_REG 8
+#endif
+// OCT_REG: candidates per thread whose (node, descent code, record) live in registers: the first 4096 of a level
 // One pass = one call: the nodes ranked below `nsplit` are replaced by their non-empty children (pushed to the front in
 // creation order, i.e. reversed), the others keep their relative order behind them; every candidate moves to its new node
 // AND is counted into that node's child quadrants, so the next pass (or the stop search of the final phase) finds the

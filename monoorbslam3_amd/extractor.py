@@ -185,6 +185,12 @@ class ORBExtractor:
     def set_stage_timing(self, enable=True):
         _lib.check(self._L.orbx_set_stage_timing(self._h, int(enable)))
 
+    def fast_time_in_step_ms(self):
+        """Timing mode 2 (set_stage_timing(2)): FAST's launches of the last call, timed on their own streams."""
+        ms, n = C.c_float(), C.c_int()
+        _lib.check(self._L.orbx_fast_times_in_step_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def stage_times_ms(self):
         ms = np.zeros(len(STAGES), np.float32)
         _lib.check(self._L.orbx_stage_times_ms(self._h, _vp(ms)))

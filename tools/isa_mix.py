@@ -168,6 +168,9 @@ def main():
         print("stage calls per launch:", calls)
         print("VALU in marked stages %.1f M (cheap class %.0f %%), launch total %s; mix-weighted issue floor %.3f ms per launch"
               % (known_n / 1e6, 100 * known_cheap / known_n, ("%.1f M" % (total_n / 1e6)) if total_n else "unknown", floor_ms))
+        sys.path.insert(0, ROOT)
+        from monoorbslam3_amd._lib import kernels_sha16
+        out["kernels_sha16"] = kernels_sha16()       # bench.py drops the file from its line once the kernel sources change
         json.dump(out, open(os.path.join(ROOT, "profiles", "fast_mix.json"), "w"), indent=1)
 
 
