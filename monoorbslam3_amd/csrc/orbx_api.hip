@@ -47,6 +47,8 @@ struct orbx_ctx {
     OrbxBuffers buf;
     OrbxLevels *d_levels;
     OrbxTap *d_xtap[ORBX_MAX_LEVELS], *d_ytap[ORBX_MAX_LEVELS];
+    bool resize2_ok[ORBX_MAX_LEVELS]; // [l]: levels l and l + 1 can come out of one launch (k_resize2's patch fits)
+    int resize2;                      // ORBX_RESIZE2: 0 = never two levels per launch, 1 = calls with few frames (default), 2 = always
     int *d_umax, *d_taps;
     hipEvent_t ev_fast_t[4]; int fast_t_n; // timing mode 2: events around the (up to two) FAST launches of a step
     uint16_t *d_fast_cells; int n_fast_cells;
@@ -363,16 +365,18 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
             if (!bh.empty()) HIP_TRY(hipMemcpy(c->d_band_h, bh.data(), bh.size(), hipMemcpyHostToDevice));
             if (!bv.empty()) HIP_TRY(hipMemcpy(c->d_band_v, bv.data(), bv.size(), hipMemcpyHostToDevice));
         }
-        std::vector<OrbxTap> taps;
+        std::vector<OrbxTap> taps, ytaps;
         for (int l = 1; l < c->levels.n_levels; ++l) {
             const OrbxLevel &d = c->levels.lv[l], &s = c->levels.lv[l - 1];
             linear_taps(d.w, s.w, true, taps);
             while (taps.size() % 4) taps.push_back(taps.back()); // k_resize reads the column taps four at a time
             HIP_TRY(dev_alloc(&c->d_xtap[l], taps.size()));
             HIP_TRY(hipMemcpy(c->d_xtap[l], taps.data(), taps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice));
-            linear_taps(d.h, s.h, false, taps);
-            HIP_TRY(dev_alloc(&c->d_ytap[l], taps.size()));
-            HIP_TRY(hipMemcpy(c->d_ytap[l], taps.data(), taps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice));
+            linear_taps(d.h, s.h, false, ytaps);
+            HIP_TRY(dev_alloc(&c->d_ytap[l], ytaps.size()));
+            HIP_TRY(hipMemcpy(c->d_ytap[l], ytaps.data(), ytaps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice));
+            // levels l - 1 and l from one launch (source: level l - 2): the patch of level l - 1 a tile of level l needs
+            c->resize2_ok[l - 1] = l >= 2 && orbx_resize2_fits(taps.data(), ytaps.data(), s.w, s.h, d.w, d.h);
         }
     }
     // frame strides of the arenas are the allocated ones
@@ -440,6 +444,10 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
         c->fast_variant = fv ? atoi(fv) : 2;
         const char *bl = getenv("ORBX_BLUR");
         c->blur_mfma = bl ? (strcmp(bl, "valu") == 0 ? 0 : strcmp(bl, "mfma") == 0 ? 2 : 1) : 1;
+    }
+    {
+        const char *e = getenv("ORBX_RESIZE2"); // 0: one level per launch (k_resize only), the parity twin of k_resize2
+        c->resize2 = e ? atoi(e) : 1;
     }
     {
         const char *e = getenv("ORBX_STREAMS");
@@ -582,6 +590,23 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         if (l == 0) { *p = d_l0; *fs = l0_fs; *pitch = l0_pitch; }
         else { *p = b.img_arena + LV.lv[l].raw_off; *fs = b.img_frame_stride; *pitch = LV.lv[l].pitch; }
     };
+    // level l from level l - 1 -- and level l + 1 with it when the two fit one launch (k_resize2): returns the last level made
+    auto launch_resize = [&](hipStream_t st, int l, int *zero_counts) -> int {
+        const uint8_t *sp; size_t sfs; int spitch;
+        raw(l - 1, &sp, &sfs, &spitch);
+        // (small calls only: per 512 frames the pyramid takes 0.71 ms this way against 0.47 -- a workgroup's two phases run one
+        // after the other -- while a single 1242x375 frame is back 20 us sooner, 157 -> 138 us; ORBX_RESIZE2=2 forces it)
+        if ((c->resize2 == 2 || (c->resize2 == 1 && n_frames < 24)) && l + 1 < L && c->resize2_ok[l]) {
+            orbx_launch_resize2(st, sp, sfs, spitch, LV.lv[l - 1].w, LV.lv[l - 1].h, b.img_arena + LV.lv[l].raw_off, b.img_frame_stride,
+                                LV.lv[l].pitch, LV.lv[l].w, LV.lv[l].h, c->d_xtap[l], c->d_ytap[l], b.img_arena + LV.lv[l + 1].raw_off,
+                                b.img_frame_stride, LV.lv[l + 1].pitch, LV.lv[l + 1].w, LV.lv[l + 1].h, c->d_xtap[l + 1],
+                                c->d_ytap[l + 1], n_frames, zero_counts);
+            return l + 1;
+        }
+        orbx_launch_resize(st, sp, sfs, spitch, LV.lv[l - 1].w, LV.lv[l - 1].h, b.img_arena + LV.lv[l].raw_off, b.img_frame_stride,
+                           LV.lv[l].pitch, LV.lv[l].w, LV.lv[l].h, c->d_xtap[l], c->d_ytap[l], n_frames, zero_counts);
+        return l;
+    };
     const bool side_ok = !t && c->side_blur && slot >= 0;
     // FAST work units (strips of cells, or single cells for ORBX_FAST_VARIANT=1); both lists are level-major
     // Strips need a few thousand waves in flight to pay (two cells per wave, a long rolling pipeline); a call with a
@@ -634,13 +659,12 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         int cells_before[ORBX_MAX_LEVELS + 1];
         cells_before[0] = 0;
         for (int l = 0; l < L; ++l) cells_before[l + 1] = cells_before[l] + LV.lv[l].n_cols * LV.lv[l].n_rows;
-        for (int l = 1; l < L; ++l) {
-            const uint8_t *sp; size_t sfs; int spitch;
-            raw(l - 1, &sp, &sfs, &spitch);
-            orbx_launch_resize(s, sp, sfs, spitch, LV.lv[l - 1].w, LV.lv[l - 1].h, b.img_arena + LV.lv[l].raw_off,
-                               b.img_frame_stride, LV.lv[l].pitch, LV.lv[l].w, LV.lv[l].h, c->d_xtap[l], c->d_ytap[l],
-                               n_frames, l == 1 ? b.cand_count : nullptr); // the first one clears the candidate counters
-            if (l == std::max(G - 1, 1)) HIP_TRY(hipEventRecord(c->ev_start[slot], s)); // counters are zero, levels < G exist
+        bool started = false;
+        for (int l = 1; l < L;) {
+            // the first launch also clears the candidate counters
+            const int done = launch_resize(s, l, l == 1 ? b.cand_count : nullptr); // last level this launch produced
+            if (!started && done >= std::max(G - 1, 1)) { HIP_TRY(hipEventRecord(c->ev_start[slot], s)); started = true; } // counters are zero, levels < G exist
+            l = done + 1;
         }
         HIP_TRY(hipEventRecord(c->ev_pyr[bslot], s));
         if (cells_before[L] > cells_before[G]) launch_fast(s, d_units + 4 * cells_before[G], cells_before[L] - cells_before[G]);
@@ -666,13 +690,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         if (c->early_fast > 1) // level 0 needs no pyramid for its blur either
             launch_blur(c->side[slot], 0, 1);
     }
-    for (int l = 1; l < L; ++l) {
-        const uint8_t *sp; size_t sfs; int spitch;
-        raw(l - 1, &sp, &sfs, &spitch);
-        orbx_launch_resize(s, sp, sfs, spitch, LV.lv[l - 1].w, LV.lv[l - 1].h, b.img_arena + LV.lv[l].raw_off,
-                           b.img_frame_stride, LV.lv[l].pitch, LV.lv[l].w, LV.lv[l].h, c->d_xtap[l], c->d_ytap[l],
-                           n_frames);
-    }
+    for (int l = 1; l < L;) l = launch_resize(s, l, nullptr) + 1;
     if (t) HIP_TRY(hipEventRecord(c->ev[1], s));
     const bool side = !t && c->side_blur && slot >= 0;
     auto fork_blur = [&]() -> int { // the blur only needs the pyramid: side stream, joined before the descriptor kernel

@@ -69,6 +69,11 @@ struct OrbxBuffers {
 void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh,
                         uint8_t *dst, size_t dst_fs, int dst_pitch, int dw, int dh,
                         const OrbxTap *xtap, const OrbxTap *ytap, int n_frames, int *zero_counts = nullptr);
+// two levels per launch (k_resize2): src = level l, d1 = level l+1, d2 = level l+2; usable when orbx_resize2_fits
+bool orbx_resize2_fits(const OrbxTap *xtap2, const OrbxTap *ytap2, int w1, int h1, int w2, int h2);
+void orbx_launch_resize2(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh, uint8_t *d1, size_t d1_fs,
+                         int d1_pitch, int w1, int h1, const OrbxTap *xtap1, const OrbxTap *ytap1, uint8_t *d2, size_t d2_fs,
+                         int d2_pitch, int w2, int h2, const OrbxTap *xtap2, const OrbxTap *ytap2, int n_frames, int *zero_counts);
 void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                       const OrbxLevels &levels, const OrbxBuffers &b, const void *d_cells, int n_cells, int n_frames);
 int orbx_build_fast_cells(const OrbxLevels &levels, uint16_t *out);

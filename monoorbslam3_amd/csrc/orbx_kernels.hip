@@ -124,6 +124,135 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two pyramid levels per launch.  Level l+2 is resampled from level l+1's ROUNDED pixels (ComputePyramid resizes from the
+// level before, :565), so the two steps cannot be merged arithmetically -- but a workgroup that owns a 64 x 16 tile of
+// level l+2 can compute the (<= 24 x 96) patch of level l+1 it needs from level l into LDS, write the part of that patch
+// it OWNS to memory, and resample its tile from LDS: level l+1 is written once and never read back, and the pyramid
+// takes four dependent launches instead of seven (what a single-frame call waits for).
+// Ownership: tile (bx, by) owns the level-(l+1) columns [cb(bx), cb(bx+1)) and rows [rb(by), rb(by+1)), cb = the first
+// source column of the tile's first pixel rounded down to 4 (dword stores), rb = the first source row of its first row;
+// the last tiles own up to the padded width / the height.  A patch always covers what its tile owns (scale < 2: the next
+// tile's first source column is at most two beyond this tile's last one), and about an eighth of level l+1 is computed
+// twice.  Same arithmetic as k_resize, pixel for pixel.
+// ---------------------------------------------------------------------------------------------
+#define R2_TW 64
+#define R2_TH 16
+#define R2_RW 104 // LDS pitch of the level-(l+1) patch: 4 * groups computed + 8 spare bytes, a multiple of 4
+#define R2_RH 24
+// 4 adjacent output pixels from two 8-byte source windows (w0 = row sy0, w1 = row sy1), k_resize's inner loop
+__device__ __forceinline__ uint32_t resize_quad(uint32_t w0l, uint32_t w0h, uint32_t w1l, uint32_t w1h, const uint32_t sel[4],
+                                                const uint32_t cc[4], int b0, int b1)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u16x2 cv = __builtin_bit_cast(u16x2, cc[i]);
+        const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w0h, w0l, sel[i])), cv, 0u, false);
+        const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w1h, w1l, sel[i])), cv, 0u, false);
+        const int v = (((int)__umul24((uint32_t)b0, (uint32_t)(r0 >> 4)) >> 16) + ((int)__umul24((uint32_t)b1, (uint32_t)(r1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)v << (8 * i);
+    }
+    return packed;
+}
+struct Resize2Args { // level l (source), l+1 and l+2
+    const uint8_t *src; size_t src_fs; int src_pitch, sw, sh;
+    uint8_t *d1; size_t d1_fs; int d1_pitch, w1, h1; const OrbxTap *xtap1, *ytap1;
+    uint8_t *d2; size_t d2_fs; int d2_pitch, w2, h2; const OrbxTap *xtap2, *ytap2;
+    int gx, gy, n_frames; int *zero_counts;
+};
+__global__ __launch_bounds__(256) void k_resize2(Resize2Args a)
+{
+    __shared__ __align__(16) uint8_t patch[R2_RH * R2_RW];
+    int frame, blk;
+    if (!xcd_remap(a.gx * a.gy, a.n_frames, &frame, &blk)) return;
+    const int tid = threadIdx.x;
+    if (a.zero_counts && blk == 0 && tid < ORBX_MAX_LEVELS) a.zero_counts[frame * ORBX_MAX_LEVELS + tid] = 0;
+    const int by = blk / a.gx, bx = blk - by * a.gx;
+    const int X0 = bx * R2_TW, Y0 = by * R2_TH, X1 = min(X0 + R2_TW, a.w2), Y1 = min(Y0 + R2_TH, a.h2);
+    // the level-(l+1) patch: columns [cb, cend), rows [rb, rend); owned: columns below cn, rows below rn
+    const int cb = a.xtap2[X0].ofs & ~3;
+    const int cn = bx + 1 < a.gx ? (a.xtap2[X0 + R2_TW].ofs & ~3) : ((a.w1 + 3) & ~3);
+    const int cend = max(min(a.xtap2[X1 - 1].ofs + 1, a.w1 - 1) + 1, cn);
+    const int rb = max(a.ytap2[Y0].ofs, 0);
+    const int rn = by + 1 < a.gy ? max(a.ytap2[Y0 + R2_TH].ofs, 0) : a.h1;
+    const int rend = max(min(a.ytap2[Y1 - 1].ofs + 1, a.h1 - 1) + 1, rn);
+    const int ncol4 = (cend - cb + 3) >> 2, nrow = rend - rb; // the host checked: 4 ncol4 + 8 <= R2_RW, nrow <= R2_RH
+    const uint8_t *S = a.src + (size_t)frame * a.src_fs;
+    uint8_t *D1 = a.d1 + (size_t)frame * a.d1_fs, *D2 = a.d2 + (size_t)frame * a.d2_fs;
+    // ---- level l -> the patch of level l+1 (item = 4 pixels of one row)
+    for (int it = tid; it < ncol4 * nrow; it += 256) {
+        const int ry = it / ncol4, g4 = it - ry * ncol4;
+        const int y1 = rb + ry, x1 = cb + 4 * g4;
+        const OrbxTap ty = a.ytap1[min(y1, a.h1 - 1)];
+        const int sy0 = min(max(ty.ofs, 0), a.sh - 1), sy1 = min(max(ty.ofs + 1, 0), a.sh - 1);
+        const uint4 t01 = reinterpret_cast<const uint4 *>(a.xtap1 + x1)[0], t23 = reinterpret_cast<const uint4 *>(a.xtap1 + x1)[1];
+        const int ofs[4] = {(int)t01.x, (int)t01.z, (int)t23.x, (int)t23.z};
+        const uint32_t cc[4] = {t01.y, t01.w, t23.y, t23.w};
+        const int sx0 = ofs[0], sxl = min(sx0, a.sw - 8); // a window that would pass the end of the row: k_resize's shift
+        const uint32_t sft = (uint32_t)(sx0 - sxl) * 8u;
+        unsigned long long w0 = reinterpret_cast<const UnalignedU64 *>(S + (size_t)sy0 * a.src_pitch + sxl)->v;
+        unsigned long long w1 = reinterpret_cast<const UnalignedU64 *>(S + (size_t)sy1 * a.src_pitch + sxl)->v;
+        w0 >>= sft; w1 >>= sft;
+        uint32_t sel[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sel[i] = (uint32_t)(ofs[i] - sx0) * 0x00010001u + 0x0c010c00u;
+        const uint32_t q = resize_quad((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32), sel, cc, ty.c0, ty.c1);
+        *reinterpret_cast<uint32_t *>(&patch[ry * R2_RW + 4 * g4]) = q;
+        if (y1 < rn && x1 < cn) *reinterpret_cast<uint32_t *>(D1 + (size_t)y1 * a.d1_pitch + x1) = q; // rows are padded to 64 bytes
+    }
+    __syncthreads();
+    // ---- the patch -> this tile of level l+2 (thread = 4 pixels of one row)
+    const int X = X0 + 4 * (tid & 15), Y = Y0 + (tid >> 4);
+    if (X >= a.w2 || Y >= a.h2) return;
+    const OrbxTap ty = a.ytap2[Y];
+    const int r0 = min(max(ty.ofs, 0), a.h1 - 1) - rb, r1 = min(max(ty.ofs + 1, 0), a.h1 - 1) - rb;
+    const uint4 t01 = reinterpret_cast<const uint4 *>(a.xtap2 + X)[0], t23 = reinterpret_cast<const uint4 *>(a.xtap2 + X)[1];
+    const int ofs[4] = {(int)t01.x, (int)t01.z, (int)t23.x, (int)t23.z};
+    const uint32_t cc[4] = {t01.y, t01.w, t23.y, t23.w};
+    const int off = ofs[0] - cb;
+    const uint32_t sh8 = (uint32_t)(off & 3) * 8u;
+    const uint32_t *p0 = reinterpret_cast<const uint32_t *>(&patch[r0 * R2_RW + (off & ~3)]);
+    const uint32_t *p1 = reinterpret_cast<const uint32_t *>(&patch[r1 * R2_RW + (off & ~3)]);
+    const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], c0 = p1[0], c1 = p1[1], c2 = p1[2];
+    uint32_t sel[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sel[i] = (uint32_t)(ofs[i] - ofs[0]) * 0x00010001u + 0x0c010c00u;
+    const uint32_t q = resize_quad(__builtin_amdgcn_alignbit(a1, a0, sh8), __builtin_amdgcn_alignbit(a2, a1, sh8),
+                                   __builtin_amdgcn_alignbit(c1, c0, sh8), __builtin_amdgcn_alignbit(c2, c1, sh8), sel, cc, ty.c0, ty.c1);
+    *reinterpret_cast<uint32_t *>(D2 + (size_t)Y * a.d2_pitch + X) = q;
+}
+// whether every tile's patch of level l+1 fits k_resize2's LDS array (host tap tables of levels l+1 -> l+2)
+bool orbx_resize2_fits(const OrbxTap *xtap2, const OrbxTap *ytap2, int w1, int h1, int w2, int h2)
+{
+    const int gx = (w2 + R2_TW - 1) / R2_TW, gy = (h2 + R2_TH - 1) / R2_TH;
+    for (int bx = 0; bx < gx; ++bx) {
+        const int X0 = bx * R2_TW, X1 = std::min(X0 + R2_TW, w2);
+        const int cb = xtap2[X0].ofs & ~3, cn = bx + 1 < gx ? (xtap2[X0 + R2_TW].ofs & ~3) : ((w1 + 3) & ~3);
+        const int cend = std::max(std::min(xtap2[X1 - 1].ofs + 1, w1 - 1) + 1, cn);
+        if (cn < cb || 4 * ((cend - cb + 3) >> 2) + 8 > R2_RW) return false;
+    }
+    for (int by = 0; by < gy; ++by) {
+        const int Y0 = by * R2_TH, Y1 = std::min(Y0 + R2_TH, h2);
+        const int rb = std::max(ytap2[Y0].ofs, 0), rn = by + 1 < gy ? std::max(ytap2[Y0 + R2_TH].ofs, 0) : h1;
+        const int rend = std::max(std::min(ytap2[Y1 - 1].ofs + 1, h1 - 1) + 1, rn);
+        if (rn < rb || rend - rb > R2_RH) return false;
+    }
+    return true;
+}
+void orbx_launch_resize2(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh, uint8_t *d1, size_t d1_fs,
+                         int d1_pitch, int w1, int h1, const OrbxTap *xtap1, const OrbxTap *ytap1, uint8_t *d2, size_t d2_fs,
+                         int d2_pitch, int w2, int h2, const OrbxTap *xtap2, const OrbxTap *ytap2, int n_frames, int *zero_counts)
+{
+    Resize2Args a;
+    a.src = src; a.src_fs = src_fs; a.src_pitch = src_pitch; a.sw = sw; a.sh = sh;
+    a.d1 = d1; a.d1_fs = d1_fs; a.d1_pitch = d1_pitch; a.w1 = w1; a.h1 = h1; a.xtap1 = xtap1; a.ytap1 = ytap1;
+    a.d2 = d2; a.d2_fs = d2_fs; a.d2_pitch = d2_pitch; a.w2 = w2; a.h2 = h2; a.xtap2 = xtap2; a.ytap2 = ytap2;
+    a.gx = (w2 + R2_TW - 1) / R2_TW; a.gy = (h2 + R2_TH - 1) / R2_TH; a.n_frames = n_frames; a.zero_counts = zero_counts;
+    hipLaunchKernelGGL(k_resize2, dim3(orbx_xcd_grid(a.gx * a.gy, n_frames)), dim3(256), 0, s, a);
+}
+
 void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh,
                         uint8_t *dst, size_t dst_fs, int dst_pitch, int dw, int dh, const OrbxTap *xtap,
                         const OrbxTap *ytap, int n_frames, int *zero_counts)

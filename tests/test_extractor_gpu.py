@@ -167,6 +167,26 @@ def test_odd_sizes_and_strides(oracle_mod):
         _check_frame(ex, orc, img, kps, desc, stages=True)
 
 
+@pytest.mark.parametrize("resize2", ["0", "2"])
+@pytest.mark.parametrize("w,h,nf,sf,levels,batch", [(1242, 375, 2000, 1.2, 8, 1), (333, 251, 300, 1.2, 8, 3), (641, 479, 700, 1.1, 9, 2),
+                                                    (800, 600, 900, 1.5, 5, 1), (1920, 1080, 2000, 1.2, 8, 1), (405, 607, 500, 1.3, 6, 26)])
+def test_pyramid_two_levels_per_launch(oracle_mod, monkeypatch, resize2, w, h, nf, sf, levels, batch):
+    """ORBExtractor.cpp:559-570 through k_resize2 (levels l+1 and l+2 from one launch, ORBX_RESIZE2=2: forced, also for a
+    batch) and through k_resize alone (=0): every level bit-exact against the oracle either way -- widths that are not
+    multiples of 4, an odd number of levels (the last one on its own), scale factors whose patches are wider (1.5: the
+    launch falls back to single levels where a patch would not fit)."""
+    monkeypatch.setenv("ORBX_RESIZE2", resize2)  # read when the extractor is created
+    ex, orc = _mk(oracle_mod, nf, w, h, n_levels=levels, sf=sf, batch=batch)
+    imgs = synth.make_frames(batch, w, h, seed=w + 7 * h)
+    if batch == 1:
+        kps, desc = ex(imgs[0])
+        _check_frame(ex, orc, imgs[0], kps, desc, stages=True)
+    else:
+        out = ex.extract_batch(imgs)
+        for f in (0, batch - 1):
+            _check_frame(ex, orc, imgs[f], out[f][0], out[f][1], frame=f, stages=True)
+
+
 @pytest.mark.parametrize("nf,sf,levels,ini,mn", [(800, 1.5, 4, 30, 10), (1200, 1.1, 12, 12, 5), (600, 1.2, 8, 7, 20),
                                                  (500, 1.2, 1, 20, 7)])
 def test_other_constructor_arguments(oracle_mod, nf, sf, levels, ini, mn):

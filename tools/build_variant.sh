@@ -4,7 +4,7 @@ set -e
 cd /root/repo/monoorbslam3_amd/csrc
 mkdir -p ../lib/variants
 name=$1; shift
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-result --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1"
 objs=""
 for f in orbx_kernels orbx_api orbm_matcher orbba orbf_frame orbv_vocab orbd_dist; do
   if [[ " $VARIANT_FILES " == *" $f "* ]]; then
