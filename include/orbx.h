@@ -103,6 +103,11 @@ int orbx_extract_batch(orbx_t *h, const uint8_t *imgs, int n_frames, int width, 
 int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_imgs, int n_frames, int width, int height,
                               int stride, size_t frame_stride, orbx_kp *d_out_kp, uint8_t *d_out_desc,
                               int cap, int32_t *d_n_out, void *stream);
+/* Scheduling aid for a caller that pipelines other GPU work beside the extraction (no reference counterpart): makes `stream`
+ * (hipStream_t) wait until the FAST stage of the most recently enqueued orbx_extract_batch_device call has finished.  FAST
+ * saturates the vector ALUs; the quadtree and the orientation that follow are latency-bound and leave them mostly idle, so
+ * ALU-heavy work of the caller -- bench.py: the Hamming match of the previous batch -- costs least when it starts there. */
+int orbx_stream_wait_fast(orbx_t *h, void *stream);
 /* Block until everything enqueued on the handle's stream has finished. */
 int orbx_synchronize(orbx_t *h);
 

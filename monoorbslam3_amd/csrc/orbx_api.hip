@@ -50,6 +50,7 @@ struct orbx_ctx {
     bool resize2_ok[ORBX_MAX_LEVELS]; // [l]: levels l and l + 1 can come out of one launch (k_resize2's patch fits)
     int resize2;                      // ORBX_RESIZE2: 0 = never two levels per launch, 1 = calls with few frames (default), 2 = always
     int *d_umax, *d_taps;
+    hipEvent_t ev_after_fast; bool after_fast_valid; // recorded behind the FAST launches of every call (orbx_stream_wait_fast)
     hipEvent_t ev_fast_t[4]; int fast_t_n; // timing mode 2: events around the (up to two) FAST launches of a step
     uint16_t *d_fast_cells; int n_fast_cells;
     uint16_t *d_fast_strips; int n_fast_strips, n_fast_strips0; // strips of all levels / of level 0
@@ -499,6 +500,7 @@ extern "C" void orbx_destroy(orbx_t *c)
     }
     for (int i = 0; i <= ORBX_N_STAGES; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 4; ++i) if (c->ev_fast_t[i]) (void)hipEventDestroy(c->ev_fast_t[i]);
+    if (c->ev_after_fast) (void)hipEventDestroy(c->ev_after_fast);
     for (int i = 0; i < 8; ++i) {
         if (c->sub[i]) { (void)hipStreamSynchronize(c->sub[i]); (void)hipStreamDestroy(c->sub[i]); }
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -708,6 +710,9 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         launch_fast(s, d_units, n_units);
     }
     if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
+    if (!c->ev_after_fast) HIP_TRY(hipEventCreateWithFlags(&c->ev_after_fast, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_after_fast, s)); // what follows (quadtree, orientation) leaves the vector ALUs mostly idle
+    c->after_fast_valid = true;
     if (side && c->side_blur != 1) { int rc = fork_blur(); if (rc) return rc; } // next to the quadtree and orientation
     if (!side)
         launch_blur(s, 0, L);
@@ -961,6 +966,15 @@ extern "C" int orbx_set_stage_timing(orbx_t *c, int enable)
         HIP_TRY(hipSetDevice(c->device));
         for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&c->ev_fast_t[i]));
     }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_stream_wait_fast(orbx_t *c, void *stream)
+{
+    if (!c || !stream) return fail(ORBX_E_ARG, "null argument");
+    if (!c->after_fast_valid) return fail(ORBX_E_ARG, "no batched extract call enqueued yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, c->ev_after_fast, 0));
     return ORBX_OK;
 }
 

@@ -152,6 +152,10 @@ class ORBExtractor:
         _lib.check(self._L.orbx_extract_batch_device(self._h, d_imgs_ptr, n_frames, w, h, stride, frame_stride,
                                                      d_kp_ptr, d_desc_ptr, cap, d_n_ptr, stream))
 
+    def stream_wait_fast(self, stream):
+        """`stream` (raw hipStream_t as int) waits for the FAST stage of the last enqueued batch (orbx_stream_wait_fast)."""
+        _lib.check(self._L.orbx_stream_wait_fast(self._h, stream))
+
     def synchronize(self):
         _lib.check(self._L.orbx_synchronize(self._h))
 
