@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 typedef struct orbba_problem {
-    double fx, fy, cx, cy;      /* Pinhole intrinsics */
+    double fx, fy, cx, cy;      /* intrinsics (both camera models) */
     double huber_delta;         /* (double)sqrtf(5.991) in the reference; <= 0 disables the robust kernel */
     int32_t n_poses, n_points, n_edges;
     const double *pose_R;       /* n_poses x 9, row-major R_cw (VertexSE3 estimate, G2oTypes.h:96-116) */
@@ -36,6 +36,11 @@ typedef struct orbba_problem {
     const int32_t *edge_point;  /* n_edges, non-decreasing (edges are built map point by map point, Optimize.cpp:860-889) */
     const double *edge_z;       /* n_edges x 2 measured pixel (kp.pt) */
     const double *edge_inv_sigma2; /* n_edges, 1/kp.size^2 (Optimize.cpp:877) */
+    /* camera->project / getProjJacobian (G2oTypes.cpp:42): 0 = Pinhole (modules/Sensor/Pinhole.cpp:28-53), 1 = Fisheye, the
+     * Kannala-Brandt model of modules/Sensor/Fisheye.cpp:35-49, :83-108 with dist_coeffs k1..k4 as the reference reads them
+     * (float values widened to double).  A zero-initialised tail is the pinhole camera. */
+    int32_t camera_model;
+    double fisheye_k[4];
 } orbba_problem;
 
 typedef struct orbba_result {
@@ -103,6 +108,8 @@ typedef struct orbba_pose_problem {
     const double *points;           /* n_edges x 3: mp->getPos() */
     const double *edge_z;           /* n_edges x 2: kp.pt */
     const double *edge_inv_sigma2;  /* n_edges: 1 / kp.size^2 (:478) */
+    int32_t camera_model;           /* as in orbba_problem */
+    double fisheye_k[4];
 } orbba_pose_problem;
 
 typedef struct orbba_pose_result {

@@ -16,7 +16,15 @@ class _Problem(C.Structure):
                 ("huber_delta", C.c_double), ("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
                 ("pose_R", C.c_void_p), ("pose_t", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p),
                 ("edge_pose", C.c_void_p), ("edge_point", C.c_void_p), ("edge_z", C.c_void_p),
-                ("edge_inv_sigma2", C.c_void_p)]
+                ("edge_inv_sigma2", C.c_void_p), ("camera_model", C.c_int32), ("fisheye_k", C.c_double * 4)]
+
+
+def _cam_tail(cam):
+    """cam = (fx, fy, cx, cy) -> Pinhole; (fx, fy, cx, cy, k1, k2, k3, k4) -> Fisheye (Kannala-Brandt, Fisheye.cpp)"""
+    if len(cam) == 8:
+        return 1, (C.c_double * 4)(*[float(np.float32(v)) for v in cam[4:]])  # the reference keeps them as float
+    assert len(cam) == 4
+    return 0, (C.c_double * 4)(0, 0, 0, 0)
 
 
 class _Result(C.Structure):
@@ -45,7 +53,7 @@ def linearize(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, ed
            "H_ll": np.zeros((nl, 3, 3)), "b_l": np.zeros((nl, 3)), "H_lp": np.zeros((ne, 3, 6))}
     vp = lambda a: a.ctypes.data  # noqa: E731
     prob = _Problem(cam[0], cam[1], cam[2], cam[3], huber_delta, npz, nl, ne, vp(R), vp(t), vp(fix), vp(P), vp(ep), vp(el),
-                    vp(z), vp(w))
+                    vp(z), vp(w), *_cam_tail(cam))
     res = _Result(vp(out["chi2"]), vp(out["error"]), vp(out["H_pp"]), vp(out["b_p"]), vp(out["H_ll"]), vp(out["b_l"]),
                   vp(out["H_lp"]), 0.0)
     _lib.check(fn(C.byref(prob), C.byref(res), device))
@@ -71,7 +79,7 @@ def _problem(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, edg
             f8(points).reshape(-1, 3), np.ascontiguousarray(edge_pose, dtype=np.int32),
             np.ascontiguousarray(edge_point, dtype=np.int32), f8(edge_z).reshape(-1, 2), f8(edge_inv_sigma2)]
     prob = _Problem(cam[0], cam[1], cam[2], cam[3], huber_delta, len(keep[0]), len(keep[3]), len(keep[4]),
-                    *[a.ctypes.data for a in keep])
+                    *[a.ctypes.data for a in keep], *_cam_tail(cam))
     return prob, keep
 
 
@@ -126,7 +134,7 @@ class _PoseProblem(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("huber_delta", C.c_double),
                 ("n_frames", C.c_int32), ("rounds", C.c_int32), ("iterations", C.c_int32), ("edge_off", C.c_void_p),
                 ("pose_R", C.c_void_p), ("pose_t", C.c_void_p), ("points", C.c_void_p), ("edge_z", C.c_void_p),
-                ("edge_inv_sigma2", C.c_void_p)]
+                ("edge_inv_sigma2", C.c_void_p), ("camera_model", C.c_int32), ("fisheye_k", C.c_double * 4)]
 
 
 class _PoseResult(C.Structure):
@@ -149,7 +157,7 @@ def pose_optimize_batch(cam, pose_R, pose_t, edge_off, points, edge_z, edge_inv_
     out = {"pose_R": np.zeros((B, 3, 3)), "pose_t": np.zeros((B, 3)), "inlier": np.zeros(max(ne, 1), np.uint8),
            "n_inliers": np.zeros(B, np.int32), "chi2": np.zeros(max(ne, 1))}
     vp = lambda a: a.ctypes.data  # noqa: E731
-    prob = _PoseProblem(cam[0], cam[1], cam[2], cam[3], huber_delta, B, 0, 0, vp(off), vp(R), vp(t), vp(P), vp(z), vp(w))
+    prob = _PoseProblem(cam[0], cam[1], cam[2], cam[3], huber_delta, B, 0, 0, vp(off), vp(R), vp(t), vp(P), vp(z), vp(w), *_cam_tail(cam))
     res = _PoseResult(vp(out["pose_R"]), vp(out["pose_t"]), vp(out["inlier"]), vp(out["n_inliers"]), vp(out["chi2"]), 0.0)
     _lib.check(fn(C.byref(prob), C.byref(res), device))
     out["inlier"] = out["inlier"][:ne].astype(bool)

@@ -26,7 +26,51 @@ int orbx_set_error(int code, const std::string &msg);
             return orbx_set_error(ORBX_E_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-struct BaCam { double fx, fy, cx, cy, delta; };
+struct BaCam { double fx, fy, cx, cy, delta; int model; double k[4]; };
+static BaCam make_cam(double fx, double fy, double cx, double cy, double delta, int model, const double *k)
+{
+    BaCam c = {fx, fy, cx, cy, delta, model, {k[0], k[1], k[2], k[3]}};
+    return c;
+}
+// camera->project(Pc) (G2oTypes.h:250 through Camera): Pinhole.cpp:28-32, or the Kannala-Brandt model of Fisheye.cpp:35-49
+__device__ __forceinline__ void ba_project(const BaCam &cam, double X, double Y, double Z, double *u, double *v)
+{
+    if (cam.model == 0) {
+        *u = cam.fx * (X / Z) + cam.cx;
+        *v = cam.fy * (Y / Z) + cam.cy;
+        return;
+    }
+    const double a = X / Z, b = Y / Z;
+    const double r = sqrt(a * a + b * b);
+    const double theta = atan(r);
+    const double theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta2 * theta3, theta7 = theta2 * theta5,
+                 theta9 = theta2 * theta7;
+    const double theta_d = theta + cam.k[0] * theta3 + cam.k[1] * theta5 + cam.k[2] * theta7 + cam.k[3] * theta9;
+    *u = cam.fx * theta_d * a / r + cam.cx; // a point on the optical axis (r = 0) is 0 / 0 here as in the reference
+    *v = cam.fy * theta_d * b / r + cam.cy;
+}
+// camera->getProjJacobian(Pc) (G2oTypes.cpp:42): Pinhole.cpp:49-53 or Fisheye.cpp:83-108; row-major 2 x 3
+__device__ __forceinline__ void ba_proj_jacobian(const BaCam &cam, double X, double Y, double Z, double Jp[6])
+{
+    if (cam.model == 0) {
+        Jp[0] = cam.fx / Z; Jp[1] = 0.0; Jp[2] = -cam.fx * X / (Z * Z);
+        Jp[3] = 0.0; Jp[4] = cam.fy / Z; Jp[5] = -cam.fy * Y / (Z * Z);
+        return;
+    }
+    const double x2 = X * X, y2 = Y * Y, z2 = Z * Z;
+    const double r2 = x2 + y2, r = sqrt(r2), r3 = r2 * r;
+    const double theta = atan2(r, Z);
+    const double theta2 = theta * theta, theta3 = theta2 * theta, theta4 = theta2 * theta2, theta5 = theta4 * theta,
+                 theta6 = theta2 * theta4, theta7 = theta6 * theta, theta8 = theta4 * theta4, theta9 = theta8 * theta;
+    const double f = theta + theta3 * cam.k[0] + theta5 * cam.k[1] + theta7 * cam.k[2] + theta9 * cam.k[3];
+    const double fd = 1 + 3 * cam.k[0] * theta2 + 5 * cam.k[1] * theta4 + 7 * cam.k[2] * theta6 + 9 * cam.k[3] * theta8;
+    Jp[0] = cam.fx * (fd * Z * x2 / (r2 * (r2 + z2)) + f * y2 / r3);
+    Jp[3] = cam.fy * (fd * Z * Y * X / (r2 * (r2 + z2)) - f * Y * X / r3);
+    Jp[1] = cam.fx * (fd * Z * Y * X / (r2 * (r2 + z2)) - f * Y * X / r3);
+    Jp[4] = cam.fy * (fd * Z * y2 / (r2 * (r2 + z2)) + f * x2 / r3);
+    Jp[2] = -cam.fx * fd * X / (r2 + z2);
+    Jp[5] = -cam.fy * fd * Y / (r2 + z2);
+}
 
 __global__ __launch_bounds__(256) void k_ba_edges(BaCam cam, int n_edges, const double *__restrict__ pose_R,
                                                   const double *__restrict__ pose_t, const uint8_t *__restrict__ pose_fixed,
@@ -50,8 +94,9 @@ __global__ __launch_bounds__(256) void k_ba_edges(BaCam cam, int n_edges, const 
     const double X = R[0] * P[0] + R[1] * P[1] + R[2] * P[2] + t[0];
     const double Y = R[3] * P[0] + R[4] * P[1] + R[5] * P[2] + t[1];
     const double Z = R[6] * P[0] + R[7] * P[1] + R[8] * P[2] + t[2];
-    // Pinhole::project (Pinhole.cpp:28-32) and the residual (G2oTypes.h:250)
-    const double u = cam.fx * (X / Z) + cam.cx, v = cam.fy * (Y / Z) + cam.cy;
+    // camera->project and the residual (G2oTypes.h:250)
+    double u, v;
+    ba_project(cam, X, Y, Z, &u, &v);
     const double ex = edge_z[2 * e] - u, ey = edge_z[2 * e + 1] - v;
     const double om = edge_w[e];
     const double chi2 = om * (ex * ex + ey * ey);
@@ -60,8 +105,9 @@ __global__ __launch_bounds__(256) void k_ba_edges(BaCam cam, int n_edges, const 
     if (cam.delta > 0.0 && chi2 > cam.delta * cam.delta) rw = cam.delta / sqrt(chi2);
     // an edge at level 1 (Optimize.cpp:900-902) is not part of the active set: its chi2 is still reported
     const double W = (edge_active && !edge_active[e]) ? 0.0 : rw * om;
-    // Pinhole::getProjJacobian (Pinhole.cpp:49-53)
-    const double Jp[6] = {cam.fx / Z, 0.0, -cam.fx * X / (Z * Z), 0.0, cam.fy / Z, -cam.fy * Y / (Z * Z)};
+    // camera->getProjJacobian (G2oTypes.cpp:42)
+    double Jp[6];
+    ba_proj_jacobian(cam, X, Y, Z, Jp);
     // J_point = -Jp * R  (G2oTypes.cpp:44)
     double Jl[6];
 #pragma unroll
@@ -223,7 +269,7 @@ extern "C" int orbba_linearize(const orbba_problem *p, orbba_result *r, int devi
     B_TRY(hipMemcpy(dlo.p, point_off.data(), sizeof(int) * (NL + 1), hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     B_TRY(hipEventCreate(&e0)); B_TRY(hipEventCreate(&e1));
-    const BaCam cam = {p->fx, p->fy, p->cx, p->cy, p->huber_delta};
+    const BaCam cam = make_cam(p->fx, p->fy, p->cx, p->cy, p->huber_delta, p->camera_model, p->fisheye_k);
     B_TRY(hipEventRecord(e0, 0));
     if (NE)
         hipLaunchKernelGGL(k_ba_edges, dim3((NE + 255) / 256), dim3(256), 0, 0, cam, NE, dR.as<double>(), dt.as<double>(),
@@ -575,7 +621,7 @@ extern "C" int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o,
     B_TRY(hipMemcpy(dfree.p, free_pose.data(), 4 * NF, hipMemcpyHostToDevice));
     B_TRY(hipMemcpy(dslot.p, pose_slot.data(), 4 * NP, hipMemcpyHostToDevice));
     B_TRY(hipMemcpy(deo.p, edge_of.data(), (size_t)4 * NF * NL, hipMemcpyHostToDevice));
-    const BaCam cam = {p->fx, p->fy, p->cx, p->cy, p->huber_delta};
+    const BaCam cam = make_cam(p->fx, p->fy, p->cx, p->cy, p->huber_delta, p->camera_model, p->fisheye_k);
     hipEvent_t e0, e1;
     B_TRY(hipEventCreate(&e0)); B_TRY(hipEventCreate(&e1));
     B_TRY(hipEventRecord(e0, 0));
@@ -857,7 +903,8 @@ __global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, in
         const double X = Rc[0] * P[0] + Rc[1] * P[1] + Rc[2] * P[2] + tc[0];
         const double Y = Rc[3] * P[0] + Rc[4] * P[1] + Rc[5] * P[2] + tc[1];
         const double Z = Rc[6] * P[0] + Rc[7] * P[1] + Rc[8] * P[2] + tc[2];
-        const double u = cam.fx * (X / Z) + cam.cx, v = cam.fy * (Y / Z) + cam.cy;
+        double u, v;
+        ba_project(cam, X, Y, Z, &u, &v);
         *ex = z[(size_t)(e0 + e) * 2] - u;
         *ey = z[(size_t)(e0 + e) * 2 + 1] - v;
         Pc[0] = X; Pc[1] = Y; Pc[2] = Z;
@@ -899,7 +946,8 @@ __global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, in
                         double rw = 1.0, rc = c;
                         if (cam.delta > 0.0 && c > d2) { rw = cam.delta / sqrt(c); rc = 2.0 * cam.delta * sqrt(c) - d2; }
                         const double W = rw * w[e0 + e], X = Pc[0], Y = Pc[1], Z = Pc[2];
-                        const double Jp[6] = {cam.fx / Z, 0.0, -cam.fx * X / (Z * Z), 0.0, cam.fy / Z, -cam.fy * Y / (Z * Z)};
+                        double Jp[6];
+                        ba_proj_jacobian(cam, X, Y, Z, Jp);
                         double Jq[12];
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
@@ -1021,7 +1069,7 @@ extern "C" int orbba_pose_optimize_batch(const orbba_pose_problem *p, orbba_pose
         B_TRY(hipMemcpy(dz.p, p->edge_z, (size_t)16 * NE, hipMemcpyHostToDevice));
         B_TRY(hipMemcpy(dw.p, p->edge_inv_sigma2, (size_t)8 * NE, hipMemcpyHostToDevice));
     }
-    const BaCam cam = {p->fx, p->fy, p->cx, p->cy, p->huber_delta};
+    const BaCam cam = make_cam(p->fx, p->fy, p->cx, p->cy, p->huber_delta, p->camera_model, p->fisheye_k);
     hipEvent_t e0, e1;
     B_TRY(hipEventCreate(&e0)); B_TRY(hipEventCreate(&e1));
     B_TRY(hipEventRecord(e0, 0));

@@ -1922,7 +1922,10 @@ __device__ __forceinline__ void octl_apply(const OctL &c, int cur, int size, int
     *n_expand = E;
 }
 
-__global__ __launch_bounds__(ORBX_OCT_THREADS) void k_octree_lds(const OrbxLevels *__restrict__ levels, OrbxBuffers b, int level0)
+#ifndef OCT_MIN_WAVES
+#define OCT_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(ORBX_OCT_THREADS, OCT_MIN_WAVES) void k_octree_lds(const OrbxLevels *__restrict__ levels, OrbxBuffers b, int level0)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int lds[64];

@@ -118,12 +118,27 @@ def feature_vector_by_prefix(desc, bits):
     return node_ids.astype(np.uint32), offsets, order.astype(np.uint32)
 
 
-def make_ba_problem(n_poses=20, n_points=3000, seed=DEFAULT_SEED, width=1242, height=375, n_fixed=4):
+def make_ba_problem(n_poses=20, n_points=3000, seed=DEFAULT_SEED, width=1242, height=375, n_fixed=4, camera="pinhole"):
     """BASELINE config 5: poses on a 10 m arc looking at a 20 x 20 x 10 m box of points, pinhole
     fx = fy = 718.856, cx = 607.19, cy = 185.22; every point observed by every pose where it projects inside
-    the image; 1 px Gaussian pixel noise; octave-dependent 1/sigma^2.  Edges are grouped by point."""
+    the image; 1 px Gaussian pixel noise; octave-dependent 1/sigma^2.  Edges are grouped by point.
+    camera="fisheye": the same scene through a Kannala-Brandt camera (the reference's Fisheye model, 512 x 512, a
+    TUM-VI-like calibration); cam is then (fx, fy, cx, cy, k1, k2, k3, k4)."""
     rng = np.random.RandomState(seed + 29)
     cam = (718.856, 718.856, 607.19, 185.22)
+    if camera == "fisheye":
+        cam = (190.978477, 190.973307, 254.931706, 256.897442, 0.0034823894, 0.0007150348, -0.0020532361, 0.00020293673)
+        width = height = 512
+
+    def proj(pc):
+        if len(cam) == 4:
+            return cam[0] * pc[0] / pc[2] + cam[2], cam[1] * pc[1] / pc[2] + cam[3]
+        a, b = pc[0] / pc[2], pc[1] / pc[2]
+        r = np.sqrt(a * a + b * b)
+        th = np.arctan(r)
+        k = [float(np.float32(v)) for v in cam[4:]]
+        thd = th + k[0] * th ** 3 + k[1] * th ** 5 + k[2] * th ** 7 + k[3] * th ** 9
+        return cam[0] * thd * a / r + cam[2], cam[1] * thd * b / r + cam[3]
     pts = np.stack([rng.uniform(-10, 10, n_points), rng.uniform(-5, 5, n_points), rng.uniform(8, 28, n_points)], 1)
     R, t = [], []
     for k in range(n_poses):
@@ -140,8 +155,7 @@ def make_ba_problem(n_poses=20, n_points=3000, seed=DEFAULT_SEED, width=1242, he
             pc = R[k] @ pts[j] + t[k]
             if pc[2] <= 0.5:
                 continue
-            u = cam[0] * pc[0] / pc[2] + cam[2]
-            v = cam[1] * pc[1] / pc[2] + cam[3]
+            u, v = proj(pc)
             if 0 <= u < width and 0 <= v < height:
                 octave = rng.randint(0, 8)
                 sig = np.float32(1.2) ** octave

@@ -17,26 +17,73 @@ def hat(v):
                      np.stack([-v[:, 1], v[:, 0], z], 1)], 1)
 
 
+def project(cam, Pc):
+    """camera->project(Pc): cam = (fx, fy, cx, cy) is Pinhole::project (modules/Sensor/Pinhole.cpp:28-32);
+    (fx, fy, cx, cy, k1, k2, k3, k4) is Fisheye::project (modules/Sensor/Fisheye.cpp:35-49, Kannala-Brandt; the reference
+    keeps dist_coeffs as float, so k is rounded to float first)."""
+    fx, fy, cx, cy = cam[:4]
+    X, Y, Z = Pc[:, 0], Pc[:, 1], Pc[:, 2]
+    if len(cam) == 4:
+        return np.stack([fx * (X / Z) + cx, fy * (Y / Z) + cy], 1)
+    k = [float(np.float32(v)) for v in cam[4:8]]
+    a, b = X / Z, Y / Z
+    r = np.sqrt(a * a + b * b)
+    theta = np.arctan(r)
+    theta2 = theta * theta
+    theta3 = theta * theta2
+    theta5 = theta2 * theta3
+    theta7 = theta2 * theta5
+    theta9 = theta2 * theta7
+    theta_d = theta + k[0] * theta3 + k[1] * theta5 + k[2] * theta7 + k[3] * theta9
+    return np.stack([fx * theta_d * a / r + cx, fy * theta_d * b / r + cy], 1)
+
+
+def proj_jacobian(cam, Pc):
+    """camera->getProjJacobian(Pc) (G2oTypes.cpp:42), n x 2 x 3: Pinhole.cpp:49-53 or Fisheye.cpp:83-108."""
+    fx, fy, cx, cy = cam[:4]
+    X, Y, Z = Pc[:, 0], Pc[:, 1], Pc[:, 2]
+    zero = np.zeros_like(X)
+    if len(cam) == 4:
+        return np.stack([np.stack([fx / Z, zero, -fx * X / (Z * Z)], 1), np.stack([zero, fy / Z, -fy * Y / (Z * Z)], 1)], 1)
+    k = [float(np.float32(v)) for v in cam[4:8]]
+    x2, y2, z2 = X * X, Y * Y, Z * Z
+    r2 = x2 + y2
+    r = np.sqrt(r2)
+    r3 = r2 * r
+    theta = np.arctan2(r, Z)
+    theta2 = theta * theta
+    theta3 = theta2 * theta
+    theta4 = theta2 * theta2
+    theta5 = theta4 * theta
+    theta6 = theta2 * theta4
+    theta7 = theta6 * theta
+    theta8 = theta4 * theta4
+    theta9 = theta8 * theta
+    f = theta + theta3 * k[0] + theta5 * k[1] + theta7 * k[2] + theta9 * k[3]
+    fd = 1 + 3 * k[0] * theta2 + 5 * k[1] * theta4 + 7 * k[2] * theta6 + 9 * k[3] * theta8
+    j00 = fx * (fd * Z * x2 / (r2 * (r2 + z2)) + f * y2 / r3)
+    j10 = fy * (fd * Z * Y * X / (r2 * (r2 + z2)) - f * Y * X / r3)
+    j01 = fx * (fd * Z * Y * X / (r2 * (r2 + z2)) - f * Y * X / r3)
+    j11 = fy * (fd * Z * y2 / (r2 * (r2 + z2)) + f * x2 / r3)
+    j02 = -fx * fd * X / (r2 + z2)
+    j12 = -fy * fd * Y / (r2 + z2)
+    return np.stack([np.stack([j00, j01, j02], 1), np.stack([j10, j11, j12], 1)], 1)
+
+
 def residual(cam, R, t, P, z):
     """e = z - project(R P + t) for matched rows."""
-    fx, fy, cx, cy = cam
     Pc = np.einsum("eij,ej->ei", R, P) + t
-    u = fx * (Pc[:, 0] / Pc[:, 2]) + cx
-    v = fy * (Pc[:, 1] / Pc[:, 2]) + cy
-    return z - np.stack([u, v], 1), Pc
+    return z - project(cam, Pc), Pc
 
 
 def linearize(cam, pose_R, pose_t, pose_fixed, points, edge_pose, edge_point, edge_z, edge_inv_sigma2, huber_delta):
-    fx, fy, cx, cy = cam
     R = np.asarray(pose_R, np.float64).reshape(-1, 3, 3)[edge_pose]
     t = np.asarray(pose_t, np.float64).reshape(-1, 3)[edge_pose]
     P = np.asarray(points, np.float64).reshape(-1, 3)[edge_point]
     z = np.asarray(edge_z, np.float64).reshape(-1, 2)
     om = np.asarray(edge_inv_sigma2, np.float64)
     e, Pc = residual(cam, R, t, P, z)
-    X, Y, Z = Pc[:, 0], Pc[:, 1], Pc[:, 2]
-    zero = np.zeros_like(X)
-    Jp = np.stack([np.stack([fx / Z, zero, -fx * X / (Z * Z)], 1), np.stack([zero, fy / Z, -fy * Y / (Z * Z)], 1)], 1)
+    Jp = proj_jacobian(cam, Pc)
     Jl = -Jp @ R                                              # G2oTypes.cpp:44
     Jq = np.concatenate([Jp @ hat(Pc), -Jp], axis=2)          # G2oTypes.cpp:45-46
     chi2 = om * (e * e).sum(1)
@@ -203,7 +250,6 @@ def pose_optimize(cam, R0, t0, Pw, z, inv_sigma2, huber_delta, rounds=4, iterati
     four rounds of optimize(10), each restarted from the initial pose (:497) on the edges classified as inliers by the
     previous round (chi2 <= 5.991, :506-516; the `iter == 2` test at :518 never fires, so the kernel stays).  The LM loop
     is g2o 20201223's OptimizationAlgorithmLevenberg on the 6x6 system.  Returns dict(R, t, inlier, n_inliers, chi2)."""
-    fx, fy, cx, cy = cam
     R0 = np.array(R0, np.float64).reshape(3, 3)
     t0 = np.array(t0, np.float64).reshape(3)
     Pw = np.asarray(Pw, np.float64).reshape(-1, 3)
@@ -213,7 +259,7 @@ def pose_optimize(cam, R0, t0, Pw, z, inv_sigma2, huber_delta, rounds=4, iterati
     inlier = np.ones(n, bool)
     def err(R, t):
         Pc = Pw @ R.T + t
-        e = z - np.stack([fx * (Pc[:, 0] / Pc[:, 2]) + cx, fy * (Pc[:, 1] / Pc[:, 2]) + cy], 1)
+        e = z - project(cam, Pc)
         return e, Pc
 
     def chi_of(R, t):
@@ -232,9 +278,7 @@ def pose_optimize(cam, R0, t0, Pw, z, inv_sigma2, huber_delta, rounds=4, iterati
                 e, Pc = err(R, t)
                 chi = om * (e * e).sum(1)
                 current = robust_chi2(chi, huber_delta, act)
-                X, Y, Z = Pc[:, 0], Pc[:, 1], Pc[:, 2]
-                zero = np.zeros_like(X)
-                Jp = np.stack([np.stack([fx / Z, zero, -fx * X / (Z * Z)], 1), np.stack([zero, fy / Z, -fy * Y / (Z * Z)], 1)], 1)
+                Jp = proj_jacobian(cam, Pc)
                 Jq = np.concatenate([Jp @ hat(Pc), -Jp], axis=2)
                 rw = np.ones(n)
                 out = chi > huber_delta * huber_delta

@@ -270,3 +270,75 @@ def test_oracle_lm_reaches_the_same_minimum_as_scipy():
     e_ref, _ = ba_ref.residual(cam, ref["pose_R"][ep], ref["pose_t"][ep], ref["points"][el], z)
     e_sp, _ = ba_ref.residual(cam, R[ep], t[ep], P[el], z)
     assert np.abs(e_ref - e_sp).max() < 1e-3  # same reprojections (the gauge along the fixed poses is pinned by them)
+
+
+# ---------------------------------------------------------------- the Fisheye camera (modules/Sensor/Fisheye.cpp:35-108)
+def test_fisheye_jacobian_matches_numeric_differences():
+    """Fisheye::getProjJacobian (Fisheye.cpp:83-108) against central differences of Fisheye::project (:35-49), and the
+    edge Jacobians built from it (G2oTypes.cpp:42-46) against differences of the residual."""
+    from oracle import ba_ref
+    pr = synth.make_ba_problem(4, 60, seed=8, camera="fisheye")
+    cam = pr["cam"]
+    assert len(cam) == 8 and len(pr["edge_pose"]) > 100
+    rng = np.random.RandomState(2)
+    Pc = np.stack([rng.uniform(-6, 6, 50), rng.uniform(-6, 6, 50), rng.uniform(2, 9, 50)], 1)   # up to ~70 degrees off axis
+    J = ba_ref.proj_jacobian(cam, Pc)
+    h = 1e-6
+    for k in range(3):
+        d = np.zeros(3); d[k] = h
+        num = (ba_ref.project(cam, Pc + d) - ba_ref.project(cam, Pc - d)) / (2 * h)
+        assert np.allclose(num, J[:, :, k], rtol=1e-6, atol=1e-6)
+    lin = ba_ref.linearize(cam, pr["pose_R"], pr["pose_t"], pr["pose_fixed"], pr["points"], pr["edge_pose"], pr["edge_point"],
+                           pr["edge_z"], pr["edge_inv_sigma2"], 0.0)
+    R = pr["pose_R"].reshape(-1, 3, 3)
+    for e in range(0, len(pr["edge_pose"]), 11):
+        ip, il = pr["edge_pose"][e], pr["edge_point"][e]
+        z = pr["edge_z"][e:e + 1]
+        res = lambda Rm, tv, P: ba_ref.residual(cam, Rm[None], tv[None], P[None], z)[0][0]  # noqa: E731
+        for k in range(6):
+            d = np.zeros(6); d[k] = h
+            Rp, tp = ba_ref.se3_exp(d)
+            Rm, tm = ba_ref.se3_exp(-d)
+            num = (res(Rp @ R[ip], Rp @ pr["pose_t"][ip] + tp, pr["points"][il]) -
+                   res(Rm @ R[ip], Rm @ pr["pose_t"][ip] + tm, pr["points"][il])) / (2 * h)
+            assert np.allclose(num, lin["J_pose"][e][:, k], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_fisheye_matches_oracle():
+    """The three BA entry points with camera_model = 1: linearisation blocks, the LM loop and the batched poseOptimize
+    against the numpy oracle (float64; tolerances as for the pinhole tests -- atan / atan2 / sqrt are the device's)."""
+    from oracle import ba_ref
+    from monoorbslam3_amd import ba
+    pr = synth.make_ba_problem(6, 400, seed=4, camera="fisheye")
+    cam = pr["cam"]
+    args = (cam, pr["pose_R"], pr["pose_t"], pr["pose_fixed"], pr["points"], pr["edge_pose"], pr["edge_point"], pr["edge_z"],
+            pr["edge_inv_sigma2"])
+    want = ba_ref.linearize(*args, ba.HUBER_MONO)
+    got = ba.linearize(*args, ba.HUBER_MONO)
+    for k in ("chi2", "error", "H_pp", "b_p", "H_ll", "b_l", "H_lp"):
+        scale = max(1.0, float(np.abs(want[k]).max()))
+        assert np.abs(got[k] - want[k]).max() <= 1e-9 * scale, k
+    # the pinhole path is untouched by the new field: same problem geometry through the pinhole model differs
+    pin = ba.linearize(cam[:4], *args[1:], ba.HUBER_MONO)
+    assert np.abs(pin["error"] - got["error"]).max() > 1.0
+    w_lm = ba_ref.lm_optimize(*args, ba.HUBER_MONO, 5)
+    g_lm = ba.optimize(*args, huber_delta=ba.HUBER_MONO, iterations=5)
+    assert (g_lm["iterations"], g_lm["trials"]) == (w_lm["iterations"], w_lm["trials"])
+    for k in ("pose_R", "pose_t", "points"):
+        assert _close(g_lm[k], w_lm[k], 1e-6), k
+    assert g_lm["chi2_final"] < g_lm["chi2_initial"]
+    # poseOptimize: every pose against the points it observes
+    R = pr["pose_R"].reshape(-1, 3, 3)
+    off, P, z, w = [0], [], [], []
+    for k in range(len(R)):
+        sel = np.flatnonzero(pr["edge_pose"] == k)
+        P.append(pr["points"][pr["edge_point"][sel]]); z.append(pr["edge_z"][sel]); w.append(pr["edge_inv_sigma2"][sel])
+        off.append(off[-1] + len(sel))
+    P, z, w = np.concatenate(P), np.concatenate(z), np.concatenate(w)
+    t0 = pr["pose_t"] + 0.02
+    out = ba.pose_optimize_batch(cam, R, t0, np.array(off, np.int32), P, z, w)
+    for k in range(len(R)):
+        ref = ba_ref.pose_optimize(cam, R[k], t0[k], P[off[k]:off[k + 1]], z[off[k]:off[k + 1]], w[off[k]:off[k + 1]], ba.HUBER_MONO)
+        assert np.abs(out["pose_t"][k] - ref["t"]).max() < 1e-7 and np.abs(out["pose_R"][k] - ref["R"]).max() < 1e-8
+        assert out["n_inliers"][k] == ref["n_inliers"]

@@ -8,6 +8,9 @@ cd $ROOT
 bash tools/profile_round.sh > $O/profile_round.log 2>&1 || { tail -5 $O/profile_round.log; exit 1; }
 cp gpurun_out/prof/pmc_traffic.json gpurun_out/prof/pmc_valu.json profiles/   # the bench line below replays them
 echo "pmc done"
+# FAST's mix-weighted issue floor: stage counts from the probe build, instruction classes from the ISA (hipcc is on the box)
+make -C monoorbslam3_amd/csrc -s -j8 prof > $O/make_prof.log 2>&1 && python3 tools/fast_mix.py 512 > $O/fast_stage_counts.txt 2>&1 \
+  && python3 tools/isa_mix.py > $O/fast_mix.txt 2>&1 && cp profiles/fast_mix.json $O/ ; echo "fast mix done"
 python3 bench.py > $O/final_bench.json 2> $O/final_bench.err || { tail -5 $O/final_bench.err; exit 1; }
 echo "bench done: $(cut -c1-160 $O/final_bench.json)"
 bash tools/kernel_stats.sh > $O/kernel_stats_overlapped.txt 2>&1; echo "kernel stats done"
@@ -17,5 +20,8 @@ bash tools/batch_sweep.sh > $O/batch_sweep.txt 2> $O/batch_sweep.err; echo "swee
 { python3 tools/latency.py 1242 375 2000; python3 tools/latency.py 752 480 1000; python3 tools/latency.py 1920 1080 2000; bash tools/latency_c.sh; } 2>&1 | grep -v amdgpu.ids > $O/single_frame_latency.txt; echo "latency done"
 python3 tools/match_latency.py 2>&1 | grep -v amdgpu.ids > $O/match_latency.txt; echo "match latency done"
 python3 tools/octree_phases.py 1 2>&1 | grep -v amdgpu.ids > $O/octree_phases.txt || true
+python3 tools/octree_phases.py 1 1920 1080 2>&1 | grep -v amdgpu.ids > $O/octree_phases_1080.txt || true
+bash tools/ta_breakdown.sh > $O/tcp.log 2>&1; cp gpurun_out/ta_breakdown.txt $O/tcp_counters.txt; echo "tcp done"
+for m in valu_ops3 fp4_hamming; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/microbench/$m.hip -o /tmp/$m && /tmp/$m > $O/$m.txt 2>&1; done; echo "microbench done"
 cp gpurun_out/prof/*_counter_collection.csv gpurun_out/prof/kernel_stats.csv gpurun_out/prof/bench_under_rocprof.json $O/
 ls $O

@@ -13,6 +13,12 @@ cp $R/batch_sweep.txt profiles/${T}_batch_sweep.txt
 cp $R/single_frame_latency.txt profiles/${T}_single_frame_latency.txt
 cp $R/match_latency.txt profiles/${T}_match_latency.txt
 cp $R/octree_phases.txt profiles/${T}_octree_phases.txt
+cp $R/octree_phases_1080.txt profiles/${T}_octree_phases_1080.txt
+cp $R/tcp_counters.txt profiles/${T}_tcp_counters.txt
+cp $R/valu_ops3.txt profiles/${T}_valu_ops3.txt
+cp $R/fp4_hamming.txt profiles/${T}_fp4_hamming.txt
+cp $R/fast_mix.txt profiles/${T}_fast_mix.txt
+cp $R/fast_stage_counts.txt profiles/${T}_fast_stage_counts.txt
 mkdir -p profiles/${T}_pmc
 cp $R/*_counter_collection.csv profiles/${T}_pmc/
 cp gpurun_out/prof/pmc_traffic.json gpurun_out/prof/pmc_valu.json profiles/
