@@ -122,6 +122,20 @@ typedef struct orbba_pose_result {
 
 int orbba_pose_optimize_batch(const orbba_pose_problem *p, orbba_pose_result *r, int device);
 
+/* The same with every array of both structs in DEVICE memory (chi2 must be given), enqueued on `stream` (hipStream_t)
+ * without a copy or a wait: the last step of the tracking chain extract -> frame record -> SearchByProjection -> pose
+ * (Tracking.cpp:289-336) when the steps before it left their results on the device. */
+int orbba_pose_optimize_batch_device(const orbba_pose_problem *p, orbba_pose_result *r, void *stream);
+/* poseOptimize's edges (Optimize.cpp:468-490) from a device-resident frame: for every key point i, in index order, whose
+ * d_frame_mp[i] (as orbm_search_by_projection_*_device leaves it) is a query index q in [0, nq): the map point position
+ * d_q_points[3q..] (float, mp->getPos()), the measurement kp.pt of d_kps[i] (orbx_kp records, undistorted) and
+ * invSigma2 = 1.f / kp.size / kp.size (:479).  d_edge_off receives {0, n_edges} (one frame); d_points / d_edge_z /
+ * d_edge_inv_sigma2 need room for n2 edges; d_edge_kp (may be NULL) receives i per edge -- the vecIndices of :464 that the
+ * caller uses to drop the outliers from the frame (:531-537).  Enqueued on `stream`. */
+int orbba_pose_edges_device(int n2, int nq, const int32_t *d_frame_mp, const void *d_kps, const float *d_q_points,
+                            int32_t *d_edge_off, double *d_points, double *d_edge_z, double *d_edge_inv_sigma2,
+                            int32_t *d_edge_kp, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,3 +164,28 @@ def pose_optimize_batch(cam, pose_R, pose_t, edge_off, points, edge_z, edge_inv_
     out["chi2"] = out["chi2"][:ne]
     out["kernel_ms"] = float(res.kernel_ms)
     return out
+
+
+def pose_edges_device(n2, nq, d_frame_mp, d_kps, d_q_points, d_edge_off, d_points, d_z, d_w, d_edge_kp=None, stream=None):
+    """orbba_pose_edges_device on torch device tensors: poseOptimize's edges from a device-resident frame's frame_mp."""
+    import torch
+    L = _lib.lib()
+    fn = L.orbba_pose_edges_device
+    fn.restype, fn.argtypes = C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 9
+    st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    _lib.check(fn(n2, nq, d_frame_mp.data_ptr(), d_kps.data_ptr(), d_q_points.data_ptr(), d_edge_off.data_ptr(), d_points.data_ptr(),
+                  d_z.data_ptr(), d_w.data_ptr(), d_edge_kp.data_ptr() if d_edge_kp is not None else None, st))
+
+
+def pose_optimize_batch_device(cam, d_R, d_t, d_edge_off, d_points, d_z, d_w, d_R_out, d_t_out, d_inlier, d_n_inliers, d_chi2,
+                               n_frames=1, huber_delta=HUBER_MONO, stream=None):
+    """orbba_pose_optimize_batch_device: every array a torch device tensor (float64 / int32 / uint8), nothing copied."""
+    import torch
+    L = _lib.lib()
+    fn = L.orbba_pose_optimize_batch_device
+    fn.restype, fn.argtypes = C.c_int, [C.POINTER(_PoseProblem), C.POINTER(_PoseResult), C.c_void_p]
+    st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    prob = _PoseProblem(cam[0], cam[1], cam[2], cam[3], huber_delta, n_frames, 0, 0, d_edge_off.data_ptr(), d_R.data_ptr(),
+                        d_t.data_ptr(), d_points.data_ptr(), d_z.data_ptr(), d_w.data_ptr(), *_cam_tail(cam))
+    res = _PoseResult(d_R_out.data_ptr(), d_t_out.data_ptr(), d_inlier.data_ptr(), d_n_inliers.data_ptr(), d_chi2.data_ptr(), 0.0)
+    _lib.check(fn(C.byref(prob), C.byref(res), st))

@@ -1091,3 +1091,68 @@ extern "C" int orbba_pose_optimize_batch(const orbba_pose_problem *p, orbba_pose
     if (NE && r->chi2) B_TRY(hipMemcpy(r->chi2, dchi.p, (size_t)8 * NE, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The tracking chain without a host hop (Tracking.cpp:289-336): the matched map points of a device-resident frame record
+// (orbm_search_by_projection_*_device wrote frame_mp) become the edges of poseOptimize (Optimize.cpp:468-490) on the
+// device, and orbba_pose_optimize_batch_device runs k_pose_optimize on device arrays.
+// ---------------------------------------------------------------------------------------------
+// edges in key-point order (:470): for key point i with frame_mp[i] in [0, nq): the map point's position, kp.pt, 1 / size^2
+__global__ __launch_bounds__(1024) void k_pose_edges(int n2, int nq, const int32_t *__restrict__ frame_mp,
+                                                     const orbx_kp *__restrict__ kps, const float *__restrict__ q_points,
+                                                     int32_t *__restrict__ edge_off, double *__restrict__ points,
+                                                     double *__restrict__ z, double *__restrict__ w, int32_t *__restrict__ edge_kp)
+{
+    __shared__ int s_wave[16], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n2; i0 += 1024) {
+        const int i = i0 + tid;
+        const int q = i < n2 ? frame_mp[i] : -1;
+        const bool on = q >= 0 && q < nq;
+        const unsigned long long mk = __ballot(on);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        if (lane == 0) s_wave[wv] = (int)__popcll(mk);
+        __syncthreads();
+        int before = s_base;
+        for (int k = 0; k < wv; ++k) before += s_wave[k];
+        if (on) {
+            const int e = before + rank;
+            const orbx_kp kp = kps[i];
+            points[3 * e] = (double)q_points[3 * q]; points[3 * e + 1] = (double)q_points[3 * q + 1]; points[3 * e + 2] = (double)q_points[3 * q + 2];
+            z[2 * e] = (double)kp.x; z[2 * e + 1] = (double)kp.y;           // setMeasurement({kp.pt.x, kp.pt.y}) (:478)
+            w[e] = (double)__fdiv_rn(__fdiv_rn(1.f, kp.size), kp.size);     // invSigma2 = 1.f / kp.size / kp.size (:479)
+            if (edge_kp) edge_kp[e] = i;
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += s_wave[k]; s_base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) { edge_off[0] = 0; edge_off[1] = s_base; }
+}
+extern "C" int orbba_pose_edges_device(int n2, int nq, const int32_t *d_frame_mp, const void *d_kps, const float *d_q_points,
+                                       int32_t *d_edge_off, double *d_points, double *d_edge_z, double *d_edge_inv_sigma2,
+                                       int32_t *d_edge_kp, void *stream)
+{
+    if (n2 < 0 || nq < 0 || !d_frame_mp || !d_kps || !d_q_points || !d_edge_off || !d_points || !d_edge_z || !d_edge_inv_sigma2)
+        return orbx_set_error(ORBX_E_ARG, "bad argument");
+    hipLaunchKernelGGL(k_pose_edges, dim3(1), dim3(1024), 0, (hipStream_t)stream, n2, nq, d_frame_mp, (const orbx_kp *)d_kps,
+                       d_q_points, d_edge_off, d_points, d_edge_z, d_edge_inv_sigma2, d_edge_kp);
+    B_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+extern "C" int orbba_pose_optimize_batch_device(const orbba_pose_problem *p, orbba_pose_result *r, void *stream)
+{
+    if (!p || !r) return orbx_set_error(ORBX_E_ARG, "null argument");
+    if (p->n_frames < 1 || !p->edge_off || !p->pose_R || !p->pose_t || !p->points || !p->edge_z || !p->edge_inv_sigma2 ||
+        !r->pose_R || !r->pose_t || !r->n_inliers || !r->inlier || !r->chi2)
+        return orbx_set_error(ORBX_E_ARG, "null array (every pointer is device memory here, chi2 included)");
+    const BaCam cam = make_cam(p->fx, p->fy, p->cx, p->cy, p->huber_delta, p->camera_model, p->fisheye_k);
+    hipLaunchKernelGGL(k_pose_optimize, dim3(p->n_frames), dim3(256), 0, (hipStream_t)stream, cam, p->rounds > 0 ? p->rounds : 4,
+                       p->iterations > 0 ? p->iterations : 10, p->edge_off, p->pose_R, p->pose_t, p->points, p->edge_z,
+                       p->edge_inv_sigma2, r->pose_R, r->pose_t, r->inlier, r->n_inliers, r->chi2);
+    B_TRY(hipGetLastError());
+    r->kernel_ms = 0.f;
+    return ORBX_OK;
+}

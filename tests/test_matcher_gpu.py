@@ -412,6 +412,7 @@ def test_window_lists_on_a_device_resident_frame_record(oracle_mod):
     d_n = torch.zeros((1,), dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     ex.extract_batch_device(img.data_ptr(), 1, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), st)
+    torch.cuda.synchronize()  # st is torch's default stream = NULL = "the handle's own stream" to the C ABI: order by hand
     fp = FramePost(w, h, 458.654, 457.296, 367.215, 248.375, dist=(-0.2834, 0.0739, 1.9e-4, 1.8e-5))
     d_start = torch.zeros((1, fp.n_cells + 1), dtype=torch.int32, device=dev)
     d_items = torch.zeros((1, cap), dtype=torch.int32, device=dev)
@@ -524,6 +525,7 @@ def _device_record(w, h, nf, seed):
     d_n = torch.zeros((1,), dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     ex.extract_batch_device(img.data_ptr(), 1, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), st)
+    torch.cuda.synchronize()  # st is torch's default stream = NULL = "the handle's own stream" to the C ABI: order by hand
     fp = FramePost(w, h, 458.654, 457.296, 367.215, 248.375, dist=(-0.2834, 0.0739, 1.9e-4, 1.8e-5))
     d_start = torch.zeros((1, fp.n_cells + 1), dtype=torch.int32, device=dev)
     d_items = torch.zeros((1, cap), dtype=torch.int32, device=dev)

@@ -61,3 +61,98 @@ def test_track_one_frame_against_ground_truth():
                                                                                100 * good[out["inlier"]].mean()))
     assert out["n_inliers"][0] > 0.6 * len(idx2)
     assert good[out["inlier"]].mean() > 0.95
+
+
+def test_tracking_chain_stays_on_the_device():
+    """Tracking.cpp:289-336 with no host hop: orbx_extract_batch_device -> orbf_frame_post_device ->
+    orbm_search_by_projection_points_device -> orbba_pose_edges_device -> orbba_pose_optimize_batch_device, one stream,
+    nothing copied or waited for in between; the pose, the inlier flags and the matches must equal what the same steps
+    give through the host entry points (same kernels underneath, same edge order)."""
+    import torch
+    from monoorbslam3_amd import ba
+    from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
+    from monoorbslam3_amd.frame import FramePost
+    from monoorbslam3_amd.matcher import ORBMatcher
+    dev = torch.device("cuda", 0)
+    w, h, Z = 752, 480, 10.0
+    fx = fy = 460.0
+    cx, cy = 376.0, 240.0
+    cam = (fx, fy, cx, cy)
+    canvas = synth.make_canvas(w + 80, h + 60, seed=2024)
+    dx, dy = 9, 6
+    f1 = np.ascontiguousarray(canvas[30:30 + h, 40:40 + w])
+    f2 = np.ascontiguousarray(canvas[30 + dy:30 + dy + h, 40 + dx:40 + dx + w])
+    ex = ORBExtractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    post = FramePost(w, h, fx, fy, cx, cy)
+    # view 1 (the "local map") through the host path
+    k1, d1 = ex(f1)
+    _, k1u, _, _ = post(k1)
+    nq = len(k1u)
+    Pw = np.stack([(k1u["x"] - cx) * Z / fx, (k1u["y"] - cy) * Z / fy, np.full(nq, Z)], 1).astype(np.float32)
+    q_xy = np.stack([k1u["x"], k1u["y"]], 1).astype(np.float32)
+    q_level = k1u["octave"].astype(np.int32)
+    q_radius = (16.0 * 1.2 ** q_level).astype(np.float32)
+    q_ok = np.ones(nq, np.uint8)
+    # ---- view 2: the device chain
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    capk = ex.max_keypoints(w, h)
+    img = t(f2[None])
+    d_kp = torch.zeros((1, capk, 28), dtype=torch.uint8, device=dev)
+    d_un = torch.zeros((1, capk, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((1, capk, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+    d_start = torch.zeros((1, post.n_cells + 1), dtype=torch.int32, device=dev)
+    d_items = torch.zeros((1, capk), dtype=torch.int32, device=dev)
+    # ONE explicit stream for the whole chain: the C ABI reads a NULL stream as "the handle's own stream", and torch's
+    # default stream is NULL -- four handles on four private streams would not be ordered against each other
+    chain = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(chain)
+    st = chain.cuda_stream
+    assert st != 0
+    ex.extract_batch_device(img.data_ptr(), 1, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), capk, d_n.data_ptr(), st)
+    post.post_device(1, d_kp.data_ptr(), d_n.data_ptr(), capk, d_un.data_ptr(), d_start.data_ptr(), d_items.data_ptr(), st)
+    # the key-point count is needed as a host integer by the next two calls' signatures: capk (slots past the count hold
+    # no grid items, so the search never returns them) keeps the chain free of a read-back
+    d = dict(q_desc=t(d1), q_xy=t(q_xy), q_radius=t(q_radius), q_level=t(q_level), q_ok=t(q_ok), kps2=d_un, desc2=d_desc,
+             cell_start=d_start, cell_items=d_items, frame_mp=torch.full((capk,), -1, dtype=torch.int32, device=dev),
+             result=torch.zeros(8, dtype=torch.int32, device=dev))
+    m = ORBMatcher(0.8, True)
+    m.SearchByProjectionDevice("points", d, nq, capk, post.cols, post.rows, list_cap=64, stream=st)
+    e_off = torch.zeros(2, dtype=torch.int32, device=dev)
+    e_P = torch.zeros((capk, 3), dtype=torch.float64, device=dev)
+    e_z = torch.zeros((capk, 2), dtype=torch.float64, device=dev)
+    e_w = torch.zeros(capk, dtype=torch.float64, device=dev)
+    e_kp = torch.zeros(capk, dtype=torch.int32, device=dev)
+    d_Pw = t(Pw)
+    ba.pose_edges_device(capk, nq, d["frame_mp"], d_un, d_Pw, e_off, e_P, e_z, e_w, e_kp, stream=st)
+    R0, t0 = t(np.eye(3)[None]), t(np.zeros((1, 3)))
+    R_out = torch.zeros((1, 3, 3), dtype=torch.float64, device=dev)
+    t_out = torch.zeros((1, 3), dtype=torch.float64, device=dev)
+    inl = torch.zeros(capk, dtype=torch.uint8, device=dev)
+    n_inl = torch.zeros(1, dtype=torch.int32, device=dev)
+    chi2 = torch.zeros(capk, dtype=torch.float64, device=dev)
+    ba.pose_optimize_batch_device(cam, R0, t0, e_off, e_P, e_z, e_w, R_out, t_out, inl, n_inl, chi2, stream=st)
+    torch.cuda.synchronize()   # the first wait of the chain
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))
+    # ---- the same through the host entry points
+    n2 = int(d_n[0])
+    k2u = np.frombuffer(d_un[0, :n2].cpu().numpy().tobytes(), KP_DTYPE)
+    d2 = d_desc[0, :n2].cpu().numpy()
+    n_match, mp, _ = m.SearchByProjectionPoints(d1, q_xy, q_radius, q_level, q_ok, k2u, d2, w, h, np.full(n2, -1, np.int32))
+    got_mp = d["frame_mp"].cpu().numpy()
+    print("device chain: result", d["result"].cpu().numpy().tolist(), "host matches", n_match, "key points", n2, "queries", nq)
+    assert int(d["result"][1]) == 0 and int(d["result"][0]) == n_match and n_match > 300
+    assert np.array_equal(got_mp[:n2], mp) and np.all(got_mp[n2:] == -1)
+    idx2 = np.flatnonzero(mp >= 0)
+    idx1 = mp[idx2]
+    ne = int(e_off[1])
+    assert ne == len(idx2) and np.array_equal(e_kp[:ne].cpu().numpy(), idx2)
+    zz = np.stack([k2u["x"][idx2], k2u["y"][idx2]], 1).astype(np.float64)
+    ww = (np.float32(1.0) / k2u["size"][idx2] / k2u["size"][idx2]).astype(np.float64)
+    assert np.array_equal(e_z[:ne].cpu().numpy(), zz) and np.array_equal(e_w[:ne].cpu().numpy(), ww)
+    ref = ba.pose_optimize_batch(cam, np.eye(3)[None], np.zeros((1, 3)), np.array([0, ne], np.int32), Pw[idx1].astype(np.float64), zz, ww)
+    assert np.array_equal(R_out.cpu().numpy(), ref["pose_R"]) and np.array_equal(t_out.cpu().numpy(), ref["pose_t"])
+    assert int(n_inl[0]) == ref["n_inliers"][0] and np.array_equal(inl[:ne].cpu().numpy().astype(bool), ref["inlier"])
+    t_true = np.array([-dx * Z / fx, -dy * Z / fy, 0.0])
+    assert np.abs(t_out.cpu().numpy()[0] - t_true).max() < 0.02
