@@ -885,7 +885,11 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         if (!retry) { retry = true; thr = levels->min_th; }
         do ++cell; while (cell * ORBX_CELL < Ws && __builtin_amdgcn_readfirstlane(s_cellkeep[min(cell, FS_K - 1)]));
         if (cell * ORBX_CELL >= Ws) break;
-        lo = cell * ORBX_CELL; hi = min(lo + ORBX_CELL, Ws);
+        lo = cell * ORBX_CELL;
+        // a run of neighbouring cells without a keeper is one retry pass (the flags of the cells ahead are still the main
+        // pass's: a retry only ever sets the flags of its own cells)
+        while ((cell + 1) * ORBX_CELL < Ws && !__builtin_amdgcn_readfirstlane(s_cellkeep[min(cell + 1, FS_K - 1)])) ++cell;
+        hi = min((cell + 1) * ORBX_CELL, Ws);
     }
 }
 
