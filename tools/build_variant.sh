@@ -1,7 +1,10 @@
 #!/bin/bash
-# build liborbx variants with different -D flags into monoorbslam3_amd/lib/variants/<name>.so
+# build a liborbx variant with extra -D flags into monoorbslam3_amd/lib/variants/<name>:
+#   VARIANT_FILES="orbx_kernels" tools/build_variant.sh r16.so -DOCT_REG=16
+# recompiles the sources named in VARIANT_FILES with the flags and links them with the objects of the regular build
+# (build/obj, so run `make -C monoorbslam3_amd/csrc` first); tools/ab_libs.sh / ab_latency.sh then bench the variants
 set -e
-cd /root/repo/monoorbslam3_amd/csrc
+cd "$(dirname "$0")/../monoorbslam3_amd/csrc"
 mkdir -p ../lib/variants
 name=$1; shift
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-result --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1"
