@@ -1908,12 +1908,12 @@ static int projection_device(orbm_ctx *c, int mode, float nn_ratio, int check_or
                            d_cell_items, grid_cols, grid_rows, d_q_desc, d_q_xy, d_q_radius, d_lo, d_hi, d_q_ok, nq, 0, nullptr,
                            (int)std::min(pool_cap, (size_t)INT_MAX), d_counts, d_pool, d_total, d_offs);
     }
-    static bool configured = false;
-    if (!configured) {
+    static const bool configured = [] { // once per process, thread-safe (the matcher entry points are re-entrant)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_projection_resolve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_projection_resolve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        configured = true;
-    }
+        return true;
+    }();
+    (void)configured;
     if (mode == 0)
         hipLaunchKernelGGL(k_projection_resolve<0>, dim3(1), dim3(PR_T), lds, s, d_counts, d_offs, d_pool, (int)std::min(pool_cap, (size_t)INT_MAX),
                            d_total, nq, n2, (const orbx_kp *)d_kps2, d_q_angle, nn_ratio, check_orientation, d_frame_mp, d_result);

@@ -534,6 +534,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
 #ifndef FS_K
 #define FS_K 4                       // cells per strip (at most)
 #endif
+static_assert(FS_K >= 1 && FS_K <= 4, "a strip's tile row is 16 eight-byte items and its compass pass 32 lanes wide: at most 4 cells");
 #define FS_W (FS_K * ORBX_CELL)      // region columns of a full strip
 #define FS_G ((FS_W + 3) / 4)        // 4-pixel groups of a full strip
 #define FS_LG (FS_G <= 8 ? 8 : FS_G <= 16 ? 16 : 32) // lanes per tile row in the dense stage (a power of two >= FS_G)

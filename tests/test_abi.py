@@ -119,3 +119,23 @@ def test_every_handle_type_fails_loudly_without_a_gpu():
     with pytest.raises(OrbxError, match="no HIP device"):
         ba.pose_optimize_batch(args[0], np.eye(3)[None], np.zeros((1, 3)), np.array([0, 3], np.int32), np.ones((3, 3)),
                                np.zeros((3, 2)), np.ones(3))
+
+
+def test_issue_class_pricing_of_the_fast_floor():
+    """tools/isa_mix.py prices every VALU instruction of k_fast_strip by opcode AND operand form (bench.py reports the sum as
+    FAST's `limiter`): plain 32-bit logic / add / right shifts and v_bitop3 are the cheap class, a scalar-register operand
+    or any other encoding is not; LDS, scalar and memory instructions are counted apart."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_mix", os.path.join(ROOT, "tools", "isa_mix.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    kind = lambda line: m.classify(line)[0]  # noqa: E731
+    assert kind("v_and_b32_e32 v53, 0x3f3f3f3f, v53") == "valu_cheap"
+    assert kind("v_bitop3_b32 v48, v52, v49, v48 bitop3:0xc8") == "valu_cheap"
+    assert kind("v_lshrrev_b32_e32 v48, 2, v48") == "valu_cheap" and kind("v_lshlrev_b32_e32 v49, 2, v49") == "valu_slow"
+    assert kind("v_add_u32_e32 v49, s35, v28") == "valu_slow"            # the same opcode with a scalar operand
+    assert kind("v_alignbit_b32 v49, v49, v51, 26") == "valu_slow" and kind("v_cmp_ne_u32_e32 vcc, 0, v48") == "valu_slow"
+    assert kind("ds_read2_b32 v[48:49], v46 offset0:1 offset1:104") == "lds" and kind("s_bcnt1_i32_b64 s8, vcc") == "salu"
+    assert kind("global_load_dwordx2 v[2:3], v[0:1], off") == "vmem"
+    cheap, slow = m.classify("v_xor_b32_e32 v1, v2, v3")[1], m.classify("v_perm_b32 v1, v2, v3, v4")[1]
+    assert 700 < cheap < 1100 and 450 < slow < 650 and m.CHEAP > 1.4 * m.SLOW
