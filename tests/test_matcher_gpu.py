@@ -669,3 +669,52 @@ def test_search_by_projection_device_longest_displacement_chain(oracle_mod, mode
         assert res[2] >= n // 2
     else:
         assert tuple(res[4:7]) == tuple(want_cnt)
+
+
+@pytest.mark.parametrize("mode", ["frame", "points"])
+def test_search_by_projection_device_edge_cases(oracle_mod, mode):
+    """No queries; every query switched off; every slot of the frame already taken; a pool too small for the lists (reported,
+    nothing changed); a query set larger than the LDS budget (refused with ORBX_E_UNSUPPORTED, no launch)."""
+    import torch
+    from monoorbslam3_amd._lib import OrbxError
+    from monoorbslam3_amd.matcher import ORBMatcher
+    w, h = 752, 480
+    R = _device_record(w, h, 1000, seed=5)
+    dev, n, kps, desc = R["dev"], R["n"], R["kps"], R["desc"]
+    capk = R["d_un"].shape[1]
+    rng = np.random.RandomState(4)
+    nq = 300
+    pick = rng.randint(0, n, nq)
+    q_xy = np.stack([kps["x"][pick], kps["y"][pick]], 1).astype(np.float32)
+    q_r = np.full(nq, 12.0, np.float32)
+    q_level = kps["octave"][pick].astype(np.int32)
+    q_angle = kps["angle"][pick].astype(np.float32)
+    q_desc = desc[pick].copy()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    m = ORBMatcher(0.8, True)
+
+    def run(nq_, q_ok, mp0, cap=48):
+        d = dict(q_desc=t(q_desc), q_xy=t(q_xy), q_radius=t(q_r), q_level=t(q_level), q_angle=t(q_angle), q_ok=t(q_ok),
+                 kps2=R["d_un"], desc2=R["d_desc"], cell_start=R["d_start"], cell_items=R["d_items"], frame_mp=t(mp0),
+                 result=torch.full((8,), -3, dtype=torch.int32, device=dev))
+        m.SearchByProjectionDevice(mode, d, nq_, capk, R["cols"], R["rows"], list_cap=cap)
+        torch.cuda.synchronize()
+        return d["result"].cpu().numpy(), d["frame_mp"].cpu().numpy()
+    free = np.full(capk, -1, np.int32)
+    res, mp = run(0, np.ones(nq, np.uint8), free)                     # no queries
+    assert res[0] == 0 and res[1] == 0 and np.array_equal(mp, free)
+    res, mp = run(nq, np.zeros(nq, np.uint8), free)                    # all switched off
+    assert res[0] == 0 and res[3] == 0 and np.array_equal(mp, free) and (mode == "frame" or res[4] == nq)
+    taken = np.full(capk, 9, np.int32)
+    res, mp = run(nq, np.ones(nq, np.uint8), taken)                    # nothing free
+    assert res[0] == 0 and res[3] > 0 and np.array_equal(mp, taken) and (mode == "frame" or res[6] > 0)
+    big = q_r.copy()
+    q_r[:] = 300.0                                                     # windows of hundreds of key points: 300 * 1 entries is too few
+    res, mp = run(nq, np.ones(nq, np.uint8), free, cap=1)
+    assert res[1] == 1 and res[0] == 0 and np.array_equal(mp, free)
+    q_r[:] = big
+    with pytest.raises(OrbxError):                                     # nq + n2 above what one workgroup's LDS holds
+        d = dict(q_desc=t(q_desc), q_xy=t(q_xy), q_radius=t(q_r), q_level=t(q_level), q_angle=t(q_angle), q_ok=t(np.ones(nq, np.uint8)),
+                 kps2=R["d_un"], desc2=R["d_desc"], cell_start=R["d_start"], cell_items=R["d_items"], frame_mp=t(free),
+                 result=torch.zeros(8, dtype=torch.int32, device=dev))
+        m.SearchByProjectionDevice(mode, d, nq, 60000, R["cols"], R["rows"])
