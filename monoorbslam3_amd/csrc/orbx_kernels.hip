@@ -2442,6 +2442,13 @@ struct DescLv { // what k_orient_desc needs of one level: 32 bytes = ONE scalar 
     unsigned long long blur_off, pad2;
 };
 struct DescTab { int n_levels, kcap_total, pad[2]; DescLv lv[ORBX_MAX_LEVELS]; };
+// ROUNDS > 1 (ORBX_DESC_ROUNDS=2|4, an experiment that lost): a wave takes ROUNDS consecutive pairs of key points and, while it
+// samples pair i from LDS, has the patch loads of pair i + 1 in flight, to hide the staging's L2 round trip inside the wave --
+// the kernel issues VALU in only a tenth of its wave cycles.  Measured per 512 frames: 1.19 ms (2 rounds) and 1.50 ms (4)
+// against 0.62 for one round: every round's key-point records come through a chain of dependent scalar loads, and scalar
+// loads share the counter (lgkmcnt, waited to zero) with the LDS gathers of the round being sampled.  One round per wave,
+// written this way (no workgroup barrier, 50 VGPRs instead of 65), is what runs.
+template <int ROUNDS>
 __global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
                                                      orbx_kp *__restrict__ out_kp, uint8_t *__restrict__ out_desc,
                                                      int cap, int32_t *__restrict__ out_n, int per_frame, int n_frames)
@@ -2464,109 +2471,120 @@ __global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
     uint32_t pat[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) pat[j] = reinterpret_cast<const uint32_t *>(c_pattern)[lane + 64 * j];
+    constexpr int DP_ITEMS = DP_H * (DP_W / 16), DP_IT = (DP_ITEMS + 63) / 64;
+    struct Pair { // everything about one round's two key points (wave-uniform)
+        bool live[DP_K];
+        int level[DP_K], out_idx[DP_K];
+        uint2 rec[DP_K];
+        float4 ang[DP_K];
+    };
     // Everything about the wave's two keypoints is wave-uniform: the slot is forced into an SGPR so that the level table,
     // the per-level counts and the keypoint records come through the scalar cache instead of a chain of dependent vector
-    // loads, each with its own s_waitcnt.
-    const int slot0 = __builtin_amdgcn_readfirstlane((blk * 4 + wv) * DP_K);
-    bool live[DP_K];
-    int level[DP_K], out_idx[DP_K];
-    uint2 rec[DP_K];
-    float4 ang[DP_K];
-    const uint8_t *corner[DP_K];
-    int cpitch[DP_K];
+    // loads, each with its own s_waitcnt.  All six 128-bit loads of a lane (three per keypoint; the third covers items
+    // 128..147, clamped for the other lanes) are in flight together.
+    auto fetch = [&](int round, Pair &pr, uint4 (&stage)[DP_K][DP_IT]) {
+        const int slot0 = __builtin_amdgcn_readfirstlane(((blk * 4 + wv) * ROUNDS + round) * DP_K);
 #pragma unroll
-    for (int k = 0; k < DP_K; ++k) {
-        const int slot = slot0 + k;
-        live[k] = slot < tab.kcap_total;
-        // level of the slot from a per-geometry table, key points of the levels before from k_orient's prefix: a handful of
-        // scalar loads where two loops over the levels ran on the scalar unit (which this kernel kept as busy as the VALU)
-        const int lvl = live[k] ? b.slot_level[slot] : 0;
-        level[k] = lvl;
-        const DescLv lv = tab.lv[lvl]; // (a slot past the last one is given level 0; an empty slot of a level stages the corner of its own blurred level)
-        const int i = slot - lv.kp_off;
-        live[k] = live[k] && i < cnts[lvl];
-        const int oi = i + b.sel_prefix[frame * ORBX_MAX_LEVELS + lvl];
-        out_idx[k] = oi;
-        live[k] = live[k] && oi < cap;
-        rec[k] = make_uint2(0, 0);
-        ang[k] = make_float4(0.f, 1.f, 0.f, 0.f);
-        // a slot without a keypoint stages the top-left corner of its blurred level (valid memory, never sampled), so
-        // that the loads below need no branch
-        int x = 19, y = 18;
-        if (live[k]) {
-            rec[k] = b.sel[(size_t)frame * tab.kcap_total + slot];
-            ang[k] = b.kp_ang[(size_t)frame * tab.kcap_total + slot];
-            x = rec[k].x & 0xFFFF;
-            y = rec[k].x >> 16;
+        for (int k = 0; k < DP_K; ++k) {
+            const int slot = slot0 + k;
+            bool live = slot < tab.kcap_total;
+            // level of the slot from a per-geometry table, key points of the levels before from k_orient's prefix: a handful
+            // of scalar loads where two loops over the levels ran on the scalar unit
+            const int lvl = live ? b.slot_level[slot] : 0;
+            pr.level[k] = lvl;
+            const DescLv lv = tab.lv[lvl]; // (a slot past the last one is given level 0; an empty slot of a level stages the corner of its own blurred level)
+            const int i = slot - lv.kp_off;
+            live = live && i < cnts[lvl];
+            const int oi = i + b.sel_prefix[frame * ORBX_MAX_LEVELS + lvl];
+            pr.out_idx[k] = oi;
+            live = live && oi < cap;
+            pr.live[k] = live;
+            pr.rec[k] = make_uint2(0, 0);
+            pr.ang[k] = make_float4(0.f, 1.f, 0.f, 0.f);
+            // a slot without a keypoint stages the top-left corner of its blurred level (valid memory, never sampled), so
+            // that the loads below need no branch
+            int x = 19, y = 18;
+            if (live) {
+                pr.rec[k] = b.sel[(size_t)frame * tab.kcap_total + slot];
+                pr.ang[k] = b.kp_ang[(size_t)frame * tab.kcap_total + slot];
+                x = pr.rec[k].x & 0xFFFF;
+                y = pr.rec[k].x >> 16;
+            }
+            // arena rows are 64-byte aligned, so one shift (x-19)&15 serves the whole patch: the rows go to LDS
+            // as they are (148 aligned 128-bit loads per keypoint) and only the centre index moves
+            const uint8_t *corner = b.img_arena + (size_t)frame * b.img_frame_stride + lv.blur_off + (size_t)(y - 18) * lv.pitch + ((x - 19) & ~15);
+#pragma unroll
+            for (int it = 0; it < DP_IT; ++it) {
+                const int q = min(lane + 64 * it, DP_ITEMS - 1), r = q >> 2, dc = q & 3;
+                stage[k][it] = *reinterpret_cast<const uint4 *>(corner + (size_t)r * lv.pitch + 16 * dc);
+            }
         }
-        cpitch[k] = lv.pitch;
-        // arena rows are 64-byte aligned, so one shift (x-19)&15 serves the whole patch: the rows go to LDS
-        // as they are (148 aligned 128-bit loads per keypoint) and only the centre index moves
-        corner[k] = b.img_arena + (size_t)frame * b.img_frame_stride + lv.blur_off + (size_t)(y - 18) * lv.pitch + ((x - 19) & ~15);
-    }
-    // all six 128-bit loads of a lane (three per keypoint; the third covers items 128..147, clamped for the other lanes)
-    // are in flight together, then written to LDS
-    constexpr int DP_ITEMS = DP_H * (DP_W / 16), DP_IT = (DP_ITEMS + 63) / 64;
-    uint4 stage[DP_K][DP_IT];
-#pragma unroll
-    for (int k = 0; k < DP_K; ++k)
-#pragma unroll
-        for (int it = 0; it < DP_IT; ++it) {
-            const int q = min(lane + 64 * it, DP_ITEMS - 1), r = q >> 2, dc = q & 3;
-            stage[k][it] = *reinterpret_cast<const uint4 *>(corner[k] + (size_t)r * cpitch[k] + 16 * dc);
-        }
-#pragma unroll
-    for (int k = 0; k < DP_K; ++k)
-#pragma unroll
-        for (int it = 0; it < DP_IT; ++it) {
-            const int q = min(lane + 64 * it, DP_ITEMS - 1), r = q >> 2, dc = q & 3;
-            *reinterpret_cast<uint4 *>(&patch[wv][k][r * DP_W + 16 * dc]) = stage[k][it];
-        }
-    __syncthreads();
+    };
     float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         px0[j] = (float)(int8_t)(pat[j] & 255); py0[j] = (float)(int8_t)((pat[j] >> 8) & 255);
         px1[j] = (float)(int8_t)((pat[j] >> 16) & 255); py1[j] = (float)(int8_t)(pat[j] >> 24);
     }
+    Pair cur;
+    uint4 stage[DP_K][DP_IT];
+    fetch(0, cur, stage);
 #pragma unroll
-    for (int k = 0; k < DP_K; ++k) {
-        if (!live[k]) continue;
-        const float lscale = tab.lv[level[k]].scale;
-        const float a = ang[k].y, bb = ang[k].z;
-        // cvRound (ties to even) without v_rndne + v_cvt: adding 1.5 * 2^23 makes the float add itself round to the nearest
-        // integer (|value| <= 19 here), the integer is then the low mantissa bits.  The constant's bit pattern M is not
-        // subtracted per sample: (M + r) * 64 + (M + c) = r * 64 + c + 65 M, and 65 M is folded into the patch offset
-        // (unsigned arithmetic, wraps harmlessly).
-        static_assert(DP_W == 64, "row stride folded into a shift");
-        const float MAGIC = 12582912.f;
-        const uint32_t M = 0x4B400000u;
-        const uint8_t *pbytes = &patch[0][0][0];
-        const uint32_t centre = (uint32_t)((wv * DP_K + k) * (DP_H * DP_W) + 18 * DP_W + 19 + (((int)(rec[k].x & 0xFFFF) - 19) & 15)) -
-                                65u * M;
-        u64 bits[4];
+    for (int round = 0; round < ROUNDS; ++round) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t r0 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px0[j], bb), ORB_FMUL(py0[j], a)), MAGIC));
-            const uint32_t c0 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px0[j], a), ORB_FMUL(py0[j], bb)), MAGIC));
-            const uint32_t r1 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px1[j], bb), ORB_FMUL(py1[j], a)), MAGIC));
-            const uint32_t c1 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px1[j], a), ORB_FMUL(py1[j], bb)), MAGIC));
-            const int t0 = pbytes[(r0 << 6) + c0 + centre], t1 = pbytes[(r1 << 6) + c1 + centre];
-            bits[j] = __ballot(t0 < t1);
+        for (int k = 0; k < DP_K; ++k)
+#pragma unroll
+            for (int it = 0; it < DP_IT; ++it) {
+                const int q = min(lane + 64 * it, DP_ITEMS - 1), r = q >> 2, dc = q & 3;
+                *reinterpret_cast<uint4 *>(&patch[wv][k][r * DP_W + 16 * dc]) = stage[k][it];
+            }
+        // a wave stages and samples only its own two patches, and a wave's LDS instructions execute in issue order: all that
+        // is needed between the writes above and the gathers below (and between those and the next round's writes) is that
+        // the compiler keeps that order -- no workgroup barrier
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const Pair pr = cur;
+        if (round + 1 < ROUNDS) fetch(round + 1, cur, stage); // in flight while this round's pair is sampled
+#pragma unroll
+        for (int k = 0; k < DP_K; ++k) {
+            if (!pr.live[k]) continue;
+            const float lscale = tab.lv[pr.level[k]].scale;
+            const float a = pr.ang[k].y, bb = pr.ang[k].z;
+            // cvRound (ties to even) without v_rndne + v_cvt: adding 1.5 * 2^23 makes the float add itself round to the
+            // nearest integer (|value| <= 19 here), the integer is then the low mantissa bits.  The constant's bit pattern M
+            // is not subtracted per sample: (M + r) * 64 + (M + c) = r * 64 + c + 65 M, and 65 M is folded into the patch
+            // offset (unsigned arithmetic, wraps harmlessly).
+            static_assert(DP_W == 64, "row stride folded into a shift");
+            const float MAGIC = 12582912.f;
+            const uint32_t M = 0x4B400000u;
+            const uint8_t *pbytes = &patch[0][0][0];
+            const uint32_t centre = (uint32_t)((wv * DP_K + k) * (DP_H * DP_W) + 18 * DP_W + 19 + (((int)(pr.rec[k].x & 0xFFFF) - 19) & 15)) -
+                                    65u * M;
+            u64 bits[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t r0 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px0[j], bb), ORB_FMUL(py0[j], a)), MAGIC));
+                const uint32_t c0 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px0[j], a), ORB_FMUL(py0[j], bb)), MAGIC));
+                const uint32_t r1 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px1[j], bb), ORB_FMUL(py1[j], a)), MAGIC));
+                const uint32_t c1 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px1[j], a), ORB_FMUL(py1[j], bb)), MAGIC));
+                const int t0 = pbytes[(r0 << 6) + c0 + centre], t1 = pbytes[(r1 << 6) + c1 + centre];
+                bits[j] = __ballot(t0 < t1);
+            }
+            if (lane < 4) {
+                const u64 w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+                *reinterpret_cast<u64 *>(out_desc + ((size_t)frame * cap + pr.out_idx[k]) * 32 + 8 * lane) = w;
+            }
+            if (lane == 0) {
+                const int x = pr.rec[k].x & 0xFFFF, y = pr.rec[k].x >> 16;
+                orbx_kp kp;
+                float fx = (float)x, fy = (float)y;
+                if (pr.level[k] != 0) { fx = ORB_FMUL(fx, lscale); fy = ORB_FMUL(fy, lscale); }
+                kp.x = fx; kp.y = fy; kp.size = lscale; kp.angle = pr.ang[k].x; kp.response = (float)pr.rec[k].y;
+                kp.octave = pr.level[k]; kp.class_id = -1;
+                out_kp[(size_t)frame * cap + pr.out_idx[k]] = kp;
+            }
         }
-        if (lane < 4) {
-            const u64 w = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-            *reinterpret_cast<u64 *>(out_desc + ((size_t)frame * cap + out_idx[k]) * 32 + 8 * lane) = w;
-        }
-        if (lane == 0) {
-            const int x = rec[k].x & 0xFFFF, y = rec[k].x >> 16;
-            orbx_kp kp;
-            float fx = (float)x, fy = (float)y;
-            if (level[k] != 0) { fx = ORB_FMUL(fx, lscale); fy = ORB_FMUL(fy, lscale); }
-            kp.x = fx; kp.y = fy; kp.size = lscale; kp.angle = ang[k].x; kp.response = (float)rec[k].y;
-            kp.octave = level[k]; kp.class_id = -1;
-            out_kp[(size_t)frame * cap + out_idx[k]] = kp;
-        }
+        asm volatile("" ::: "memory"); // the next round's LDS writes stay behind this round's gathers
     }
 }
 
@@ -2574,7 +2592,7 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
                              uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done)
 {
-    const int pf_o = (levels.kcap_total + OR_KP - 1) / OR_KP, pf_d = (levels.kcap_total + 4 * DP_K - 1) / (4 * DP_K);
+    const int pf_o = (levels.kcap_total + OR_KP - 1) / OR_KP;
     OrientLevels tab;
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
         tab.kp_off[l] = l < levels.n_levels ? levels.lv[l].kp_off : 0;
@@ -2601,6 +2619,14 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
         dt.lv[l].pad = 0; dt.lv[l].pad2 = 0;
         dt.lv[l].blur_off = in ? (unsigned long long)levels.lv[l].blur_off : 0ull;
     }
-    hipLaunchKernelGGL(k_orient_desc, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, dt, b, out_kp,
-                       out_desc, cap, out_n, pf_d, n_frames);
+    static const int rounds_env = [] { const char *e = getenv("ORBX_DESC_ROUNDS"); return e ? atoi(e) : 0; }();
+    const int rounds = rounds_env ? rounds_env : 1;
+    const int per_wg = 4 * DP_K * (rounds >= 4 ? 4 : rounds >= 2 ? 2 : 1);
+    const int pf_d = (levels.kcap_total + per_wg - 1) / per_wg;
+    if (rounds >= 4)
+        hipLaunchKernelGGL(k_orient_desc<4>, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, dt, b, out_kp, out_desc, cap, out_n, pf_d, n_frames);
+    else if (rounds >= 2)
+        hipLaunchKernelGGL(k_orient_desc<2>, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, dt, b, out_kp, out_desc, cap, out_n, pf_d, n_frames);
+    else
+        hipLaunchKernelGGL(k_orient_desc<1>, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, dt, b, out_kp, out_desc, cap, out_n, pf_d, n_frames);
 }
