@@ -11,7 +11,12 @@
 #define ORBX_EDGE 19        // EDGE_THRESHOLD (reference modules/ORB/ORBExtractor.cpp:15)
 #define ORBX_CELL 30        // W              (reference modules/ORB/ORBExtractor.cpp:575)
 #define ORBX_HALF_PATCH 15  // HALF_PATCH_SIZE(reference modules/ORB/ORBExtractor.cpp:14)
-#define ORBX_OCT_THREADS 512
+#ifndef ORBX_OCT_THREADS
+#define ORBX_OCT_THREADS 512       // quadtree workgroup of a call with a few frames (at most 512: the block scans keep 8 wave totals)
+#endif
+#ifndef ORBX_OCT_THREADS_BATCH
+#define ORBX_OCT_THREADS_BATCH 256 // ... and of a resident batch (orbx_octree.h)
+#endif
 
 // Geometry of one pyramid level and where its buffers live inside the per-frame arenas.
 struct OrbxLevel {

@@ -9,7 +9,7 @@ import csv, glob
 f = glob.glob("/tmp/kt/**/*kernel_stats.csv", recursive=True)[0]
 print("%-16s %6s %12s %12s %7s" % ("kernel", "calls", "avg us", "min us", "%"))
 for r in csv.DictReader(open(f)):
-    name = r["Name"].split("(")[0].replace("void ", "")
+    name = r["Name"].split("(")[0].replace("void ", "").split("::")[-1]
     if name.startswith("k_"):
         print("%-16s %6s %12.1f %12.1f %7s" % (name, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, r["Percentage"]))
 PY

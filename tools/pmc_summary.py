@@ -9,7 +9,7 @@ root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+        name = row["Kernel_Name"].split("(")[0].replace("void ", "").split("::")[-1]
         acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for name, ctrs in sorted(acc.items()):
     if not name.startswith("k_"):

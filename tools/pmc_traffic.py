@@ -20,7 +20,7 @@ STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_fast_strip": "fas
 # per-step totals = sum over all dispatches of a kernel / number of steps in the run; a step has exactly one quadtree launch
 def kname(full):
     """'void k_blur_mfma<256>(FastSrc, ...)' -> 'k_blur_mfma'"""
-    return full.split("(")[0].replace("void ", "").split("<")[0].strip()
+    return full.split("(")[0].replace("void ", "").split("<")[0].strip().split("::")[-1]  # (oct_batch::k_octree_lds -> k_octree_lds)
 
 
 STEP_MARKER = "k_octree_lds"

@@ -16,7 +16,7 @@ STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_fast_strip": "fas
          "k_best2": "match_best2", "k_best2_mfma": "match_best2", "k_best2_fp4": "match_best2", "k_resize2": "resize"}
 def kname(full):
     """'void k_blur_mfma<256>(FastSrc, ...)' -> 'k_blur_mfma'"""
-    return full.split("(")[0].replace("void ", "").split("<")[0].strip()
+    return full.split("(")[0].replace("void ", "").split("<")[0].strip().split("::")[-1]  # (oct_batch::k_octree_lds -> k_octree_lds)
 
 
 STEP_MARKER = "k_octree_lds"  # exactly one launch per step: per-step totals = sum over all dispatches / its count
