@@ -48,6 +48,8 @@ struct orbx_ctx {
     OrbxLevels *d_levels;
     OrbxTap *d_xtap[ORBX_MAX_LEVELS], *d_ytap[ORBX_MAX_LEVELS];
     bool resize2_ok[ORBX_MAX_LEVELS]; // [l]: levels l and l + 1 can come out of one launch (k_resize2's patch fits)
+    bool resize_lds_ok[ORBX_MAX_LEVELS]; // [l]: level l can be made by k_resize_lds (its source tiles fit)
+    int resize_lds;                   // ORBX_RESIZE_LDS: 0 = never, 1 = resident batches (default), 2 = always
     int resize2;                      // ORBX_RESIZE2: 0 = never two levels per launch, 1 = calls with few frames (default), 2 = always
     int *d_umax, *d_taps;
     hipEvent_t ev_after_fast; bool after_fast_valid; // recorded behind the FAST launches of every call (orbx_stream_wait_fast)
@@ -378,6 +380,7 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
             HIP_TRY(hipMemcpy(c->d_ytap[l], ytaps.data(), ytaps.size() * sizeof(OrbxTap), hipMemcpyHostToDevice));
             // levels l - 1 and l from one launch (source: level l - 2): the patch of level l - 1 a tile of level l needs
             c->resize2_ok[l - 1] = l >= 2 && orbx_resize2_fits(taps.data(), ytaps.data(), s.w, s.h, d.w, d.h);
+            c->resize_lds_ok[l] = orbx_resize_lds_fits(taps.data(), ytaps.data(), s.w, s.h, d.w, d.h);
         }
     }
     // frame strides of the arenas are the allocated ones
@@ -438,7 +441,7 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
         const char *e = getenv("ORBX_SIDE_BLUR");
         c->side_blur = e ? atoi(e) : 1;
         const char *f = getenv("ORBX_EARLY_FAST");
-        c->early_fast = f ? atoi(f) : 1;
+        c->early_fast = f ? atoi(f) : -1; // -1: level 0's FAST beside the pyramid unless the pyramid is k_resize_lds's (see enqueue)
         const char *sp = getenv("ORBX_SPLIT_LEVEL0");
         c->split_level0 = sp ? atoi(sp) : 1;
         const char *fv = getenv("ORBX_FAST_VARIANT");
@@ -449,6 +452,10 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
     {
         const char *e = getenv("ORBX_RESIZE2"); // 0: one level per launch (k_resize only), the parity twin of k_resize2
         c->resize2 = e ? atoi(e) : 1;
+    }
+    {
+        const char *e = getenv("ORBX_RESIZE_LDS"); // 0: k_resize for every call, the parity twin of k_resize_lds
+        c->resize_lds = e ? atoi(e) : 1;
     }
     {
         const char *e = getenv("ORBX_STREAMS");
@@ -605,6 +612,12 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
                                 c->d_ytap[l + 1], n_frames, zero_counts);
             return l + 1;
         }
+        if ((c->resize_lds == 2 || (c->resize_lds == 1 && n_frames >= 24)) && c->resize_lds_ok[l]) {
+            orbx_launch_resize_lds(st, sp, sfs, spitch, LV.lv[l - 1].w, LV.lv[l - 1].h, l == 1 ? LV.lv[0].w : spitch,
+                                   b.img_arena + LV.lv[l].raw_off, b.img_frame_stride, LV.lv[l].pitch, LV.lv[l].w, LV.lv[l].h, c->d_xtap[l],
+                                   c->d_ytap[l], n_frames, zero_counts);
+            return l;
+        }
         orbx_launch_resize(st, sp, sfs, spitch, LV.lv[l - 1].w, LV.lv[l - 1].h, b.img_arena + LV.lv[l].raw_off, b.img_frame_stride,
                            LV.lv[l].pitch, LV.lv[l].w, LV.lv[l].h, c->d_xtap[l], c->d_ytap[l], n_frames, zero_counts);
         return l;
@@ -640,7 +653,12 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
             orbx_launch_blur(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames,
                              std::max(lb, lm), le);
     };
-    const bool early = side_ok && c->early_fast && L > 1 && n_cells0 > 0 && n_cells0 < n_units;
+    // Level 0 needs no pyramid, so its FAST can start on the side stream beside the resizes.  That pays next to k_resize (no LDS,
+    // 27 VGPRs: its waves fit between FAST's), not next to k_resize_lds, which wants the LDS that FAST's workgroups fill
+    // (512 frames, k_resize_lds with / without the early launch: 194.8 / 198.1 k frames/s; k_resize: 194.9 / 191.0).
+    const bool lds_pyramid = (c->resize_lds == 2 || (c->resize_lds == 1 && n_frames >= 24)) && L > 1 && c->resize_lds_ok[1];
+    const int early_fast = c->early_fast >= 0 ? c->early_fast : (lds_pyramid ? 0 : 1);
+    const bool early = side_ok && early_fast && L > 1 && n_cells0 > 0 && n_cells0 < n_units;
     // A call with a few frames is a chain of latency-bound kernels: level 0 (a third of the pixels, the longest quadtree)
     // then runs FAST -> quadtree on the side stream next to resize -> FAST -> quadtree of the other levels, and the blur
     // takes a stream of its own (slot 7 is free whenever the whole batch is on slot 8).
@@ -689,7 +707,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_start[slot], 0));
         launch_fast(c->side[slot], d_units, n_cells0);
         HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
-        if (c->early_fast > 1) // level 0 needs no pyramid for its blur either
+        if (early_fast > 1) // level 0 needs no pyramid for its blur either
             launch_blur(c->side[slot], 0, 1);
     }
     for (int l = 1; l < L;) l = launch_resize(s, l, nullptr) + 1;
@@ -698,7 +716,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     auto fork_blur = [&]() -> int { // the blur only needs the pyramid: side stream, joined before the descriptor kernel
         HIP_TRY(hipEventRecord(c->ev_pyr[bslot], s));
         HIP_TRY(hipStreamWaitEvent(c->side[bslot], c->ev_pyr[bslot], 0));
-        launch_blur(c->side[bslot], (early && c->early_fast > 1) ? 1 : 0, L);
+        launch_blur(c->side[bslot], (early && early_fast > 1) ? 1 : 0, L);
         HIP_TRY(hipEventRecord(c->ev_blur[bslot], c->side[bslot]));
         return ORBX_OK;
     };
@@ -713,12 +731,13 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     if (!c->ev_after_fast) HIP_TRY(hipEventCreateWithFlags(&c->ev_after_fast, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c->ev_after_fast, s)); // what follows (quadtree, orientation) leaves the vector ALUs mostly idle
     c->after_fast_valid = true;
-    if (side && c->side_blur != 1) { int rc = fork_blur(); if (rc) return rc; } // next to the quadtree and orientation
+    if (side && c->side_blur == 2) { int rc = fork_blur(); if (rc) return rc; } // next to the quadtree and orientation
     if (!side)
         launch_blur(s, 0, L);
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));
     orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, L);
     if (t) HIP_TRY(hipEventRecord(c->ev[4], s));
+    if (side && c->side_blur >= 3) { int rc = fork_blur(); if (rc) return rc; } // next to the orientation only
     orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames,
                             side ? c->ev_blur[bslot] : nullptr);
     if (t) { HIP_TRY(hipEventRecord(c->ev[5], s)); c->ev_valid = true; }

@@ -74,6 +74,12 @@ struct OrbxBuffers {
 void orbx_launch_resize(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh,
                         uint8_t *dst, size_t dst_fs, int dst_pitch, int dw, int dh,
                         const OrbxTap *xtap, const OrbxTap *ytap, int n_frames, int *zero_counts = nullptr);
+// the source tile staged through LDS (k_resize_lds, resident batches); usable when orbx_resize_lds_fits.  last_row_bytes: readable
+// bytes of the source's last row (its width for a caller's image, its pitch for an arena level)
+bool orbx_resize_lds_fits(const OrbxTap *xtap, const OrbxTap *ytap, int sw, int sh, int dw, int dh);
+void orbx_launch_resize_lds(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh, int last_row_bytes,
+                            uint8_t *dst, size_t dst_fs, int dst_pitch, int dw, int dh, const OrbxTap *xtap, const OrbxTap *ytap,
+                            int n_frames, int *zero_counts);
 // two levels per launch (k_resize2): src = level l, d1 = level l+1, d2 = level l+2; usable when orbx_resize2_fits
 bool orbx_resize2_fits(const OrbxTap *xtap2, const OrbxTap *ytap2, int w1, int h1, int w2, int h2);
 void orbx_launch_resize2(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh, uint8_t *d1, size_t d1_fs,

@@ -125,22 +125,6 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Two pyramid levels per launch.  Level l+2 is resampled from level l+1's ROUNDED pixels (ComputePyramid resizes from the
-// level before, :565), so the two steps cannot be merged arithmetically -- but a workgroup that owns a 64 x 16 tile of
-// level l+2 can compute the (<= 24 x 96) patch of level l+1 it needs from level l into LDS, write the part of that patch
-// it OWNS to memory, and resample its tile from LDS: level l+1 is written once and never read back, and the pyramid
-// takes four dependent launches instead of seven (what a single-frame call waits for).
-// Ownership: tile (bx, by) owns the level-(l+1) columns [cb(bx), cb(bx+1)) and rows [rb(by), rb(by+1)), cb = the first
-// source column of the tile's first pixel rounded down to 4 (dword stores), rb = the first source row of its first row;
-// the last tiles own up to the padded width / the height.  A patch always covers what its tile owns (scale < 2: the next
-// tile's first source column is at most two beyond this tile's last one), and about an eighth of level l+1 is computed
-// twice.  Same arithmetic as k_resize, pixel for pixel.
-// ---------------------------------------------------------------------------------------------
-#define R2_TW 64
-#define R2_TH 16
-#define R2_RW 104 // LDS pitch of the level-(l+1) patch: 4 * groups computed + 8 spare bytes, a multiple of 4
-#define R2_RH 24
 // 4 adjacent output pixels from two 8-byte source windows (w0 = row sy0, w1 = row sy1), k_resize's inner loop
 __device__ __forceinline__ uint32_t resize_quad(uint32_t w0l, uint32_t w0h, uint32_t w1l, uint32_t w1h, const uint32_t sel[4],
                                                 const uint32_t cc[4], int b0, int b1)
@@ -157,6 +141,128 @@ __device__ __forceinline__ uint32_t resize_quad(uint32_t w0l, uint32_t w0h, uint
     }
     return packed;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same resampling with the source tile staged through LDS (resident batches).  k_resize's 8-byte windows overlap
+// from lane to lane and start at any byte: every window costs the L1 two tag look-ups, 32 per wave instruction, and the
+// counters put the kernel at 0.6 look-ups per CU-cycle with 62 % of its wave cycles parked on memory
+// (profiles/r03_tcp_counters.txt, r03_sq_breakdown.txt; with the windows forced to aligned addresses -- wrong pixels, a
+// timing experiment -- the pyramid of 512 frames took 0.38 instead of 0.47 ms).  Here a workgroup's 256 x 32 output tile
+// first brings its (<= 352 x 42) source tile in with 16-byte loads, each byte once, a row per half-wave, and the windows
+// are read from LDS (three aligned dwords + two v_alignbit).  Same arithmetic as k_resize, pixel for pixel.
+// ---------------------------------------------------------------------------------------------
+#define RL_NC 22                // 16-byte chunks per staged row
+#define RL_LP (RL_NC * 16 + 16) // LDS pitch: a window's third dword may lie 12 bytes past the last needed column
+#define RL_NR 42                // staged rows
+#define RL_ROUNDS ((RL_NR + 7) / 8)
+__global__ __launch_bounds__(256) void k_resize_lds(const uint8_t *__restrict__ src, size_t src_fs, int src_pitch, int sw,
+                                                    int sh, int last_row_bytes, uint8_t *__restrict__ dst, size_t dst_fs,
+                                                    int dst_pitch, int dw, int dh, const OrbxTap *__restrict__ xtap,
+                                                    const OrbxTap *__restrict__ ytap, int gx, int gy, int n_frames,
+                                                    int *__restrict__ zero_counts)
+{
+    __shared__ __align__(16) uint8_t tile[RL_NR * RL_LP];
+    int frame, blk;
+    if (!xcd_remap(gx * gy, n_frames, &frame, &blk)) return;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if (zero_counts && blk == 0 && tid < ORBX_MAX_LEVELS) zero_counts[frame * ORBX_MAX_LEVELS + tid] = 0;
+    const int by = blk / gx, bx = blk - by * gx;
+    const int X0 = bx * 256, Y0 = by * 4 * RS_ROWS, Xl = min(X0 + 255, dw - 1), Yl = min(Y0 + 4 * RS_ROWS - 1, dh - 1);
+    // source tile: columns [colbase, colbase + 16 ncol), rows [r_lo, r_lo + nrow) -- the host checked that it fits
+    const int colbase = xtap[X0].ofs & ~15;
+    const int ncol = ((min(xtap[Xl].ofs + 1, sw - 1) - colbase) >> 4) + 1;
+    const int r_lo = min(max(ytap[Y0].ofs, 0), sh - 1);
+    const int nrow = min(max(ytap[Yl].ofs + 1, 0), sh - 1) - r_lo + 1;
+    const uint8_t *S = src + (size_t)frame * src_fs;
+    uint8_t *D = dst + (size_t)frame * dst_fs;
+    {
+        struct __attribute__((packed, aligned(1))) U128 { uint32_t w[4]; };
+        const int ch = tid & 31, rs = tid >> 5;
+        U128 v[RL_ROUNDS];
+        bool slow[RL_ROUNDS];
+#pragma unroll
+        for (int k = 0; k < RL_ROUNDS; ++k) {
+            const int row = rs + 8 * k, y = r_lo + row, c = colbase + 16 * ch;
+            const bool on = ch < ncol && row < nrow;
+            // the last row of a caller's image ends at its last pixel: a chunk that would pass it is fetched byte by byte
+            slow[k] = on && y == sh - 1 && c + 16 > last_row_bytes;
+            v[k].w[0] = v[k].w[1] = v[k].w[2] = v[k].w[3] = 0;
+            if (on && !slow[k]) v[k] = *reinterpret_cast<const U128 *>(S + (size_t)y * src_pitch + c);
+            if (slow[k])
+                for (int q = 0; q < 16; ++q)
+                    if (c + q < last_row_bytes) v[k].w[q >> 2] |= (uint32_t)S[(size_t)y * src_pitch + c + q] << (8 * (q & 3));
+        }
+#pragma unroll
+        for (int k = 0; k < RL_ROUNDS; ++k) {
+            const int row = rs + 8 * k;
+            if (ch < ncol && row < nrow)
+                *reinterpret_cast<uint4 *>(&tile[row * RL_LP + 16 * ch]) = make_uint4(v[k].w[0], v[k].w[1], v[k].w[2], v[k].w[3]);
+        }
+    }
+    __syncthreads();
+    const int dx0 = X0 + 4 * (int)threadIdx.x;
+    const int dy0 = Y0 + __builtin_amdgcn_readfirstlane((int)threadIdx.y) * RS_ROWS; // wave-uniform: row taps through the scalar cache
+    if (dx0 >= dw || dy0 >= dh) return;
+    const uint4 t01 = reinterpret_cast<const uint4 *>(xtap + dx0)[0], t23 = reinterpret_cast<const uint4 *>(xtap + dx0)[1];
+    const int ofs[4] = {(int)t01.x, (int)t01.z, (int)t23.x, (int)t23.z};
+    const uint32_t cc[4] = {t01.y, t01.w, t23.y, t23.w}; // c0 | c1 << 16
+    const int a = ofs[0] - colbase;
+    const uint32_t sh8 = (uint32_t)(a & 3) * 8u;
+    const uint8_t *tcol = tile + (a & ~3);
+    uint32_t sel[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sel[i] = (uint32_t)(ofs[i] - ofs[0]) * 0x00010001u + 0x0c010c00u; // bytes (o, o+1) -> 16-bit halves
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+        if (dy0 + r >= dh) break;
+        const OrbxTap ty = ytap[dy0 + r];
+        const int r0 = min(max(ty.ofs, 0), sh - 1) - r_lo, r1 = min(max(ty.ofs + 1, 0), sh - 1) - r_lo;
+        const uint32_t *p0 = reinterpret_cast<const uint32_t *>(tcol + r0 * RL_LP), *p1 = reinterpret_cast<const uint32_t *>(tcol + r1 * RL_LP);
+        const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], c0 = p1[0], c1 = p1[1], c2 = p1[2];
+        const uint32_t q = resize_quad(__builtin_amdgcn_alignbit(a1, a0, sh8), __builtin_amdgcn_alignbit(a2, a1, sh8),
+                                       __builtin_amdgcn_alignbit(c1, c0, sh8), __builtin_amdgcn_alignbit(c2, c1, sh8), sel, cc, ty.c0, ty.c1);
+        *reinterpret_cast<uint32_t *>(D + (size_t)(dy0 + r) * dst_pitch + dx0) = q; // rows of the arena are 64-byte aligned and padded
+    }
+}
+// whether every tile's source patch fits k_resize_lds's LDS array (host tap tables of the step)
+bool orbx_resize_lds_fits(const OrbxTap *xtap, const OrbxTap *ytap, int sw, int sh, int dw, int dh)
+{
+    for (int X0 = 0; X0 < dw; X0 += 256) {
+        const int Xl = std::min(X0 + 255, dw - 1), colbase = xtap[X0].ofs & ~15;
+        if (xtap[X0].ofs < 0 || ((std::min(xtap[Xl].ofs + 1, sw - 1) - colbase) >> 4) + 1 > RL_NC) return false;
+    }
+    for (int Y0 = 0; Y0 < dh; Y0 += 4 * RS_ROWS) {
+        const int Yl = std::min(Y0 + 4 * RS_ROWS - 1, dh - 1);
+        const int r_lo = std::min(std::max(ytap[Y0].ofs, 0), sh - 1);
+        if (std::min(std::max(ytap[Yl].ofs + 1, 0), sh - 1) - r_lo + 1 > RL_NR) return false;
+    }
+    return sw >= 16;
+}
+void orbx_launch_resize_lds(hipStream_t s, const uint8_t *src, size_t src_fs, int src_pitch, int sw, int sh, int last_row_bytes,
+                            uint8_t *dst, size_t dst_fs, int dst_pitch, int dw, int dh, const OrbxTap *xtap, const OrbxTap *ytap,
+                            int n_frames, int *zero_counts)
+{
+    const int gx = (dw + 255) / 256, gy = (dh + 4 * RS_ROWS - 1) / (4 * RS_ROWS);
+    hipLaunchKernelGGL(k_resize_lds, dim3(orbx_xcd_grid(gx * gy, n_frames)), dim3(64, 4), 0, s, src, src_fs, src_pitch, sw, sh,
+                       last_row_bytes, dst, dst_fs, dst_pitch, dw, dh, xtap, ytap, gx, gy, n_frames, zero_counts);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two pyramid levels per launch.  Level l+2 is resampled from level l+1's ROUNDED pixels (ComputePyramid resizes from the
+// level before, :565), so the two steps cannot be merged arithmetically -- but a workgroup that owns a 64 x 16 tile of
+// level l+2 can compute the (<= 24 x 96) patch of level l+1 it needs from level l into LDS, write the part of that patch
+// it OWNS to memory, and resample its tile from LDS: level l+1 is written once and never read back, and the pyramid
+// takes four dependent launches instead of seven (what a single-frame call waits for).
+// Ownership: tile (bx, by) owns the level-(l+1) columns [cb(bx), cb(bx+1)) and rows [rb(by), rb(by+1)), cb = the first
+// source column of the tile's first pixel rounded down to 4 (dword stores), rb = the first source row of its first row;
+// the last tiles own up to the padded width / the height.  A patch always covers what its tile owns (scale < 2: the next
+// tile's first source column is at most two beyond this tile's last one), and about an eighth of level l+1 is computed
+// twice.  Same arithmetic as k_resize, pixel for pixel.
+// ---------------------------------------------------------------------------------------------
+#define R2_TW 64
+#define R2_TH 16
+#define R2_RW 104 // LDS pitch of the level-(l+1) patch: 4 * groups computed + 8 spare bytes, a multiple of 4
+#define R2_RH 24
 struct Resize2Args { // level l (source), l+1 and l+2
     const uint8_t *src; size_t src_fs; int src_pitch, sw, sh;
     uint8_t *d1; size_t d1_fs; int d1_pitch, w1, h1; const OrbxTap *xtap1, *ytap1;
@@ -1655,7 +1761,9 @@ void launch_tap_sincos(const float *d_ang, int n, float2 *d_out, hipStream_t st)
 // ---------------------------------------------------------------------------------------------
 #define DP_W 64 // patch pitch: four ALIGNED 16-byte loads per row starting at floor16(x-19)
 #define DP_H 37
+#ifndef DP_K
 #define DP_K 2  // keypoints per wave: their record / patch loads are all issued before the first use
+#endif
 struct DescLv { // what k_orient_desc needs of one level: 32 bytes = ONE scalar load from the kernel-argument segment
     int kp_off, pitch;
     float scale;
@@ -1669,6 +1777,9 @@ struct DescTab { int n_levels, kcap_total, pad[2]; DescLv lv[ORBX_MAX_LEVELS]; }
 // against 0.62 for one round: every round's key-point records come through a chain of dependent scalar loads, and scalar
 // loads share the counter (lgkmcnt, waited to zero) with the LDS gathers of the round being sampled.  One round per wave,
 // written this way (no workgroup barrier, 50 VGPRs instead of 65), is what runs.
+// Also measured and dropped: the patch rows global -> LDS directly (global_load_lds_dwordx4; the layout is lane-linear, item q at
+// byte 16 q, so it fits: no staging registers, no ds_write_b128) -- bit-identical, 45 VGPRs, and 0.40 ms against 0.345; and
+// 1 / 3 / 4 key points per wave instead of 2 (-DDP_K): 0.41 / 0.38 / 0.41 ms.
 template <int ROUNDS>
 __global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
                                                      orbx_kp *__restrict__ out_kp, uint8_t *__restrict__ out_desc,

@@ -187,6 +187,29 @@ def test_pyramid_two_levels_per_launch(oracle_mod, monkeypatch, resize2, w, h, n
             _check_frame(ex, orc, imgs[f], out[f][0], out[f][1], frame=f, stages=True)
 
 
+@pytest.mark.parametrize("resize_lds", ["0", "2"])
+@pytest.mark.parametrize("w,h,nf,sf,levels,batch", [(1242, 375, 2000, 1.2, 8, 1), (333, 251, 300, 1.2, 8, 3), (641, 479, 700, 1.1, 9, 2),
+                                                    (800, 600, 900, 1.5, 5, 1), (1920, 1080, 2000, 1.2, 8, 1), (405, 607, 500, 1.3, 6, 26),
+                                                    (1000, 163, 400, 1.9, 3, 2), (64, 48, 50, 1.2, 2, 1)])
+def test_pyramid_source_tile_through_lds(oracle_mod, monkeypatch, resize_lds, w, h, nf, sf, levels, batch):
+    """ORBExtractor.cpp:559-570 through k_resize_lds (the source tile of a 256 x 32 output tile staged with 16-byte loads,
+    ORBX_RESIZE_LDS=2: forced, also for a single frame; what a resident batch runs by default) and through k_resize alone
+    (=0): every level bit-exact against the oracle either way.  Widths that are not multiples of 16 (the last row of the
+    caller's image ends inside a 16-byte chunk), scale factors up to 1.9 (tiles too wide for the LDS array fall back),
+    levels smaller than one tile.  ORBX_RESIZE2=0 so that the single-level kernels run for these small calls."""
+    monkeypatch.setenv("ORBX_RESIZE_LDS", resize_lds)  # read when the extractor is created
+    monkeypatch.setenv("ORBX_RESIZE2", "0")
+    ex, orc = _mk(oracle_mod, nf, w, h, n_levels=levels, sf=sf, batch=batch)
+    imgs = synth.make_frames(batch, w, h, seed=3 * w + 11 * h)
+    if batch == 1:
+        kps, desc = ex(imgs[0])
+        _check_frame(ex, orc, imgs[0], kps, desc, stages=True)
+    else:
+        out = ex.extract_batch(imgs)
+        for f in (0, batch - 1):
+            _check_frame(ex, orc, imgs[f], out[f][0], out[f][1], frame=f, stages=True)
+
+
 @pytest.mark.parametrize("nf,sf,levels,ini,mn", [(800, 1.5, 4, 30, 10), (1200, 1.1, 12, 12, 5), (600, 1.2, 8, 7, 20),
                                                  (500, 1.2, 1, 20, 7)])
 def test_other_constructor_arguments(oracle_mod, nf, sf, levels, ini, mn):
