@@ -443,6 +443,9 @@ __global__ __launch_bounds__(BF_WAVES * 64, 4) void k_best2_fp4(const uint8_t *_
     int frame = 0;
 
     // ---- staging: thread -> (candidate tid / 8 (+ 64 per round) of the stage, descriptor dword tid % 8) -> 16 unpacked bytes
+    // (Measured and dropped: the stage in two halves -- loads of stage s + 1 before the tiles of stage s, unpack + LDS writes after them.
+    // The two dwords that stay live across the tile loop push the kernel past its 128 registers (two spills, scratch set up for
+    // every wave): 0.33-0.35 ms per 512 problems against 0.305.)
     const int sr = tid >> 3, st = tid & 7;
     auto stage = [&](int step, int buf) {
         uint32_t w[BF_TC / (BF_WAVES * 8)];

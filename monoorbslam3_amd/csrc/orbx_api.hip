@@ -599,6 +599,9 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         if (l == 0) { *p = d_l0; *fs = l0_fs; *pitch = l0_pitch; }
         else { *p = b.img_arena + LV.lv[l].raw_off; *fs = b.img_frame_stride; *pitch = LV.lv[l].pitch; }
     };
+    // k_resize_lds pays once the batch is large (1242x375: the two kernels tie up to 192 frames -- 0.18 ms -- and part at 256: 0.206
+    // against 0.231, at 512: 0.35 against 0.46; 1920x1080 x 128: 0.37 against 0.52): from about 10^8 level-0 pixels per call
+    const bool lds_resize = c->resize_lds == 2 || (c->resize_lds == 1 && (size_t)n_frames * (size_t)LV.lv[0].w * (size_t)LV.lv[0].h >= (size_t)100000000);
     // level l from level l - 1 -- and level l + 1 with it when the two fit one launch (k_resize2): returns the last level made
     auto launch_resize = [&](hipStream_t st, int l, int *zero_counts) -> int {
         const uint8_t *sp; size_t sfs; int spitch;
@@ -612,7 +615,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
                                 c->d_ytap[l + 1], n_frames, zero_counts);
             return l + 1;
         }
-        if ((c->resize_lds == 2 || (c->resize_lds == 1 && n_frames >= 24)) && c->resize_lds_ok[l]) {
+        if (lds_resize && c->resize_lds_ok[l]) {
             orbx_launch_resize_lds(st, sp, sfs, spitch, LV.lv[l - 1].w, LV.lv[l - 1].h, l == 1 ? LV.lv[0].w : spitch,
                                    b.img_arena + LV.lv[l].raw_off, b.img_frame_stride, LV.lv[l].pitch, LV.lv[l].w, LV.lv[l].h, c->d_xtap[l],
                                    c->d_ytap[l], n_frames, zero_counts);
@@ -656,7 +659,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     // Level 0 needs no pyramid, so its FAST can start on the side stream beside the resizes.  That pays next to k_resize (no LDS,
     // 27 VGPRs: its waves fit between FAST's), not next to k_resize_lds, which wants the LDS that FAST's workgroups fill
     // (512 frames, k_resize_lds with / without the early launch: 194.8 / 198.1 k frames/s; k_resize: 194.9 / 191.0).
-    const bool lds_pyramid = (c->resize_lds == 2 || (c->resize_lds == 1 && n_frames >= 24)) && L > 1 && c->resize_lds_ok[1];
+    const bool lds_pyramid = lds_resize && L > 1 && c->resize_lds_ok[1];
     const int early_fast = c->early_fast >= 0 ? c->early_fast : (lds_pyramid ? 0 : 1);
     const bool early = side_ok && early_fast && L > 1 && n_cells0 > 0 && n_cells0 < n_units;
     // A call with a few frames is a chain of latency-bound kernels: level 0 (a third of the pixels, the longest quadtree)

@@ -15,6 +15,8 @@ cp $R/match_latency.txt profiles/${T}_match_latency.txt
 cp $R/octree_phases.txt profiles/${T}_octree_phases.txt
 cp $R/octree_phases_1080.txt profiles/${T}_octree_phases_1080.txt
 cp $R/tcp_counters.txt profiles/${T}_tcp_counters.txt
+cp $R/step_timeline.txt profiles/${T}_step_timeline.txt
+cp $R/fast_mix.json profiles/fast_mix.json
 cp $R/valu_ops3.txt profiles/${T}_valu_ops3.txt
 cp $R/fp4_hamming.txt profiles/${T}_fp4_hamming.txt
 cp $R/fast_mix.txt profiles/${T}_fast_mix.txt
