@@ -20,6 +20,7 @@ bash tools/lds_breakdown.sh > $O/lds.log 2>&1; cp gpurun_out/lds_breakdown.txt $
 bash tools/batch_sweep.sh > $O/batch_sweep.txt 2> $O/batch_sweep.err; echo "sweep done"
 { python3 tools/latency.py 1242 375 2000; python3 tools/latency.py 752 480 1000; python3 tools/latency.py 1920 1080 2000; bash tools/latency_c.sh; } 2>&1 | grep -v amdgpu.ids > $O/single_frame_latency.txt; echo "latency done"
 python3 tools/match_latency.py 2>&1 | grep -v amdgpu.ids > $O/match_latency.txt; echo "match latency done"
+python3 tools/ba_latency.py 2>&1 | grep -v amdgpu.ids > $O/ba_latency.txt; python3 tools/bow_timing.py 2>&1 | grep -v amdgpu.ids > $O/bow_timing.txt; echo "ba / bow done"
 python3 tools/octree_phases.py 1 2>&1 | grep -v amdgpu.ids > $O/octree_phases.txt || true
 python3 tools/octree_phases.py 1 1920 1080 2>&1 | grep -v amdgpu.ids > $O/octree_phases_1080.txt || true
 bash tools/ta_breakdown.sh > $O/tcp.log 2>&1; cp gpurun_out/ta_breakdown.txt $O/tcp_counters.txt; echo "tcp done"

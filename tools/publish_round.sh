@@ -12,6 +12,8 @@ cp $R/lds_breakdown.txt profiles/${T}_lds_breakdown.txt
 cp $R/batch_sweep.txt profiles/${T}_batch_sweep.txt
 cp $R/single_frame_latency.txt profiles/${T}_single_frame_latency.txt
 cp $R/match_latency.txt profiles/${T}_match_latency.txt
+cp $R/ba_latency.txt profiles/${T}_ba_latency.txt
+cp $R/bow_timing.txt profiles/${T}_bow_timing.txt
 cp $R/octree_phases.txt profiles/${T}_octree_phases.txt
 cp $R/octree_phases_1080.txt profiles/${T}_octree_phases_1080.txt
 cp $R/tcp_counters.txt profiles/${T}_tcp_counters.txt
