@@ -10,7 +10,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <string>
 #include <vector>
@@ -391,6 +393,101 @@ __global__ __launch_bounds__(256) void k_lm_schur(int n_free, int n_points, doub
 }
 
 // S (n x n, row-major, lower triangle used) -> L in place; x = S^-1 rhs.  *ok = 0 if a pivot is not positive.
+// The same solve with the system resident in LDS (n <= CH_MAX_N, i.e. up to 23 free key frames: (n + 1)^2 doubles).  The global-
+// memory kernel below pays three workgroup barriers and as many memory round trips per column (0.52 ms for n = 114, two thirds
+// of a local-BA iteration); here a column costs ONE barrier:
+//   * the right-hand side rides along as row n of the matrix, so the forward substitution L y = rhs falls out of the
+//     factorisation (row n of L is y^T);
+//   * step k reads the unscaled column k of the lower triangle, scales on the fly (every thread computes 1 / sqrt(d_k) itself)
+//     and writes the scaled column -- L's column k -- into ROW k of the upper triangle, which no step reads: nothing is read
+//     and written in one step (1 / L[k][k] goes to an array of its own: a slow thread may still be reading d_k);
+//   * thread (tr, tc) of a (CH_T / 16) x 16 grid owns the elements r = tr mod CH_T / 16, c = tc mod 16: no index division;
+//   * L^T x = y is solved by ONE wave without barriers (lane owns x[lane], x[lane + 64], x[lane + 128]; x[k] is broadcast
+//     with a lane read; the column of the step after is requested before the current one is used).
+// Operation order differs from LAPACK's (the oracle) at rounding level only; the LM tests compare at 1e-6.
+// Measured for n = 114 (tools/ba_kernel_stats.sh): 0.52 ms -> 0.13; of that 0.04 are the load, the barriers and the back
+// substitution, 0.09 the element updates.  Variants that lost: the next pivot's reciprocal square root on an extra wave
+// (0.14: the chain is 0.1 us of a step's 1.2), a step's operands of a row -- or of the whole step -- requested before the first
+// store (0.17 / 0.39: nine predicated accesses per row cost more than the two or three real ones they wait for).
+#ifndef CH_T
+#define CH_T 512
+#endif
+#define CH_MAX_N 140
+__global__ __launch_bounds__(CH_T) void k_lm_chol_solve_lds(int n, const double *__restrict__ S, const double *__restrict__ rhs,
+                                                            double *__restrict__ x, int *__restrict__ ok)
+{
+    extern __shared__ __align__(16) double A[]; // (n + 1) rows x P columns, then 1 / L[k][k] for every k
+    const int tid = threadIdx.x, P = n + 1;
+    double *dinv = A + (size_t)(n + 1) * P;
+    for (int i = tid; i < n * n; i += CH_T) {
+        const int r = i / n, c = i - r * n;
+        if (c <= r) A[r * P + c] = S[i];
+    }
+    for (int i = tid; i < n; i += CH_T) A[n * P + i] = rhs[i];
+    __syncthreads();
+    constexpr int TR = CH_T / 16;
+    const int tr = tid >> 4, tc = tid & 15;
+    bool bad = false;
+    for (int k = 0; k < n; ++k) {
+        const double d = A[k * P + k];
+        if (!(d > 0.0)) { bad = true; break; } // (every thread reads the same value: a uniform exit)
+        const double inv = 1.0 / sqrt(d);
+        // first row / column of this thread's residue class beyond k
+        const int r0 = k + 1 + ((tr - (k + 1)) & (TR - 1)), c0 = k + 1 + ((tc - (k + 1)) & 15);
+        for (int r = r0; r <= n; r += TR) {
+            const double lr = A[r * P + k] * inv;
+            const int cend = r < n ? r : n - 1;
+            for (int c = c0; c <= cend; c += 16) A[r * P + c] -= lr * (A[c * P + k] * inv);
+            if (tc == 0) A[k * P + r] = lr; // L[r][k]; r = n: y[k]
+        }
+        if (tid == 0) dinv[k] = inv;
+        __syncthreads();
+    }
+    if (bad) {
+        if (tid == 0) *ok = 0;
+        for (int i = tid; i < n; i += CH_T) x[i] = 0.0;
+        return;
+    }
+    if (tid >= 64) return;
+    // L^T x = y: L[k][r] (r < k) lies at A[r][k]; y[k] at A[k][n]
+    constexpr int SL = (CH_MAX_N + 63) / 64;
+    double y[SL], a[SL], an[SL];
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {
+        const int r = min(tid + 64 * q, n - 1);
+        y[q] = A[r * P + n];
+        an[q] = A[r * P + n - 1];
+    }
+    double di = dinv[n - 1];
+    for (int k = n - 1; k >= 0; --k) {
+        const double dk = di;
+#pragma unroll
+        for (int q = 0; q < SL; ++q) a[q] = an[q];
+        if (k > 0) { // the step after's operands: independent of this step's result
+            di = dinv[k - 1];
+#pragma unroll
+            for (int q = 0; q < SL; ++q) an[q] = A[min(tid + 64 * q, n - 1) * P + k - 1];
+        }
+        const int kq = k >> 6, kl = k & 63; // wave-uniform
+        double ysel = y[0];
+#pragma unroll
+        for (int q = 1; q < SL; ++q) ysel = q == kq ? y[q] : ysel;
+        const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(ysel) & 0xFFFFFFFFll), kl);
+        const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(ysel) >> 32), kl);
+        const double xk = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo) * dk;
+#pragma unroll
+        for (int q = 0; q < SL; ++q) {
+            const int r = tid + 64 * q;
+            if (r < k) y[q] -= a[q] * xk;
+            else if (r == k) y[q] = xk;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SL; ++q)
+        if (tid + 64 * q < n) x[tid + 64 * q] = y[q];
+    if (tid == 0) *ok = 1;
+}
+
 __global__ __launch_bounds__(256) void k_lm_chol_solve(int n, double *__restrict__ S, const double *__restrict__ rhs,
                                                        double *__restrict__ x, int *__restrict__ ok)
 {
@@ -679,8 +776,21 @@ extern "C" int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o,
             hipLaunchKernelGGL(k_lm_schur, dim3(NF * (NF + 1) / 2), dim3(256), 0, 0, NF, NL, lam, dfree.as<int>(), deo.as<int>(),
                                dHpp.as<double>(), dbp.as<double>(), dHlp.as<double>(), dinv.as<double>(), dtl.as<double>(),
                                dS.as<double>(), drhs.as<double>());
-            hipLaunchKernelGGL(k_lm_chol_solve, dim3(1), dim3(256), 0, 0, N, dS.as<double>(), drhs.as<double>(), dxp.as<double>(),
-                               dflag.as<int>());
+            const char *chol_env = getenv("ORBBA_CHOL"); // =global: the global-memory kernel, the parity twin (read per call)
+            const bool chol_global = chol_env && !strcmp(chol_env, "global");
+            if (N <= CH_MAX_N && !chol_global) {
+                const size_t lds = sizeof(double) * ((size_t)(N + 1) * (N + 1) + N);
+                static std::atomic<size_t> configured{0};
+                if (lds > configured.load()) { // (idempotent: racing threads set the same or a larger value)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lm_chol_solve_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    configured.store(lds);
+                }
+                hipLaunchKernelGGL(k_lm_chol_solve_lds, dim3(1), dim3(CH_T), lds, 0, N, dS.as<double>(), drhs.as<double>(), dxp.as<double>(),
+                                   dflag.as<int>());
+            } else {
+                hipLaunchKernelGGL(k_lm_chol_solve, dim3(1), dim3(256), 0, 0, N, dS.as<double>(), drhs.as<double>(), dxp.as<double>(),
+                                   dflag.as<int>());
+            }
             hipLaunchKernelGGL(k_lm_backsub, dim3(LB), dim3(256), 0, 0, NL, lam, dlo.as<int>(), dep.as<int>(), dslot.as<int>(),
                                dHlp.as<double>(), dxp.as<double>(), dbl.as<double>(), dinv.as<double>(), dxl.as<double>(),
                                dpart.as<double>() + EB);

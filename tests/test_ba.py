@@ -118,12 +118,16 @@ def test_oracle_se3_exp_is_a_rigid_motion():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_poses,n_points,huber", [(6, 200, True), (6, 200, False), (20, 3000, True)])
-def test_gpu_lm_matches_oracle(n_poses, n_points, huber):
+@pytest.mark.parametrize("chol", ["lds", "global"])
+@pytest.mark.parametrize("n_poses,n_points,huber", [(6, 200, True), (6, 200, False), (20, 3000, True), (25, 600, True), (26, 600, True)])
+def test_gpu_lm_matches_oracle(monkeypatch, chol, n_poses, n_points, huber):
     """Same LM decisions (iteration / trial counts), estimates within 1e-6 relative of the numpy restatement: the two
-    differ only in summation order and in the dense Cholesky."""
+    differ only in summation order and in the dense Cholesky -- through the LDS-resident solver (the reduced system of up to 23
+    free key frames; 25 poses = 23 free ones is its largest case) and through the global-memory one (ORBBA_CHOL=global, and
+    what 26 poses take either way)."""
     from oracle import ba_ref
     from monoorbslam3_amd import ba
+    monkeypatch.setenv("ORBBA_CHOL", chol)  # read per call
     pr, args = _perturbed(n_poses, n_points, 5)
     delta = ba.HUBER_MONO if huber else 0.0
     ref = ba_ref.lm_optimize(*args, delta, 6)
