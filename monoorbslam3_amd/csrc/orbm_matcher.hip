@@ -443,6 +443,11 @@ __global__ __launch_bounds__(BF_WAVES * 64, 4) void k_best2_fp4(const uint8_t *_
     int frame = 0;
 
     // ---- staging: thread -> (candidate tid / 8 (+ 64 per round) of the stage, descriptor dword tid % 8) -> 16 unpacked bytes
+    // (Measured and dropped: the tiles as a rolling pipeline inside the wave -- one query group's MFMA chain issued interleaved,
+    // one MFMA : eight v_med3 via sched_group_barrier, with the key update of the other group's finished accumulators --
+    // bit-identical, 0.33-0.34 ms against 0.305: per SIMD the kernel's matrix-pipe cycles (39 %) and VALU cycles (55 %) add up to
+    // the whole time either way, i.e. the three-operand v_med3 updates do not issue beside this MFMA, whichever wave they
+    // come from.)
     // (Measured and dropped: the stage in two halves -- loads of stage s + 1 before the tiles of stage s, unpack + LDS writes after them.
     // The two dwords that stay live across the tile loop push the kernel past its 128 registers (two spills, scratch set up for
     // every wave): 0.33-0.35 ms per 512 problems against 0.305.)
