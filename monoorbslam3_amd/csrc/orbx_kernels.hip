@@ -150,6 +150,9 @@ __device__ __forceinline__ uint32_t resize_quad(uint32_t w0l, uint32_t w0h, uint
 // timing experiment -- the pyramid of 512 frames took 0.38 instead of 0.47 ms).  Here a workgroup's 256 x 32 output tile
 // first brings its (<= 352 x 42) source tile in with 16-byte loads, each byte once, a row per half-wave, and the windows
 // are read from LDS (three aligned dwords + two v_alignbit).  Same arithmetic as k_resize, pixel for pixel.
+// (Built on top of it and dropped: two levels per launch -- a 128 x 32 tile of level l+2 from an LDS patch of level l+1 from an
+// LDS-staged piece of level l, k_resize2's ownership rule, bit-identical -- takes a quarter of the pyramid's HBM traffic away and
+// 0.47-0.48 ms per 512 frames against 0.35: three phases and two barriers per workgroup cost more than the bytes saved.)
 // ---------------------------------------------------------------------------------------------
 #define RL_NC 22                // 16-byte chunks per staged row
 #define RL_LP (RL_NC * 16 + 16) // LDS pitch: a window's third dword may lie 12 bytes past the last needed column
