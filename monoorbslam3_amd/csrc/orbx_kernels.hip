@@ -1331,10 +1331,20 @@ void orbx_launch_blur(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pit
 // ---------------------------------------------------------------------------------------------
 typedef int bl_v4i __attribute__((ext_vector_type(4)));
 typedef int bl_v16i __attribute__((ext_vector_type(16)));
-#define BM_COLS 128  // output columns of a workgroup: four waves, one 32-column MFMA tile each
-#define BM_SRC_W 160 // source bytes staged per row: 16 either side, in 16-byte chunks
-#define BM_SRC_P 176 // LDS pitch of a staged source row (conflict-free 16-byte operand reads)
-#define BM_OUT_P 132 // LDS pitch of a finished output row (33 dwords: conflict-free dword writes)
+#ifndef BM_COLS
+#define BM_COLS 128  // output columns of a workgroup: one wave and one 32-column MFMA tile per 32 columns.  (As a plain copy this access
+                     // pattern moves 4.2 TB/s -- the kernel's own rate -- and 5.3 TB/s in 256-column blocks, tools/microbench/colblock_copy.hip;
+                     // the kernel itself is no faster that way, 0.40 against 0.38 ms per 512 frames: eight-wave workgroups at 88 VGPRs
+                     // leave 16 waves per CU instead of 20, and the last block of a level idles more waves.)
+#endif
+#define BM_WAVES (BM_COLS / 32)
+#define BM_T (64 * BM_WAVES)           // threads
+#define BM_SRC_W (BM_COLS + 32)       // source bytes staged per row: 16 either side, in 16-byte chunks
+#define BM_CH (BM_SRC_W / 16)
+#define BM_SRC_P (BM_SRC_W + 16)      // LDS pitch of a staged source row (128 columns: 176, conflict-free 16-byte operand reads)
+#define BM_OUT_P (BM_COLS + 4)        // LDS pitch of a finished output row (an odd number of dwords: conflict-free dword writes)
+#define BM_OCH (BM_COLS / 16)         // 16-byte chunks of a finished row
+static_assert(32 * BM_CH <= 2 * BM_T && 32 * BM_OCH == BM_T, "a thread stages at most two chunks and stores one");
 struct __attribute__((aligned(4))) BlurBlock { uint16_t level, bx; };
 struct __attribute__((packed, aligned(1))) UnalignedV4 { bl_v4i v; };
 struct __attribute__((packed, aligned(1))) UnalignedU4 { uint32_t x, y, z, w; };
@@ -1345,12 +1355,12 @@ struct __attribute__((packed, aligned(1))) UnalignedU4 { uint32_t x, y, z, w; };
 __host__ __device__ __forceinline__ int blur_origin(int bx, int limit) { return min(max(BM_COLS * bx - 16, 0), limit - BM_SRC_W); }
 __host__ __device__ __forceinline__ int blur_window(int tx, int limit)
 {
-    const int xo = blur_origin(tx >> 2, limit);
+    const int xo = blur_origin(tx / BM_WAVES, limit);
     return min(max(32 * tx - 16, xo), xo + BM_SRC_W - 64);
 }
 
 template <int K_SUM> // the taps sum to 256 (default set), or to 257 (the plain-rounded set: two more operations per pixel)
-__global__ __launch_bounds__(256) void k_blur_mfma(FastSrc src, BlurMfmaLevels lv, const BlurBlock *__restrict__ blocks,
+__global__ __launch_bounds__(BM_T) void k_blur_mfma(FastSrc src, BlurMfmaLevels lv, const BlurBlock *__restrict__ blocks,
                                                    const uint4 *__restrict__ band_h, const uint4 *__restrict__ band_v,
                                                    uint8_t *__restrict__ arena, size_t arena_fs, int n_blocks, int n_frames)
 {
@@ -1367,7 +1377,7 @@ __global__ __launch_bounds__(256) void k_blur_mfma(FastSrc src, BlurMfmaLevels l
     const int w = lv.w[level], h = lv.h[level], pitch = src.pitch[level], n_ty = lv.n_ty[level], dpitch = lv.dst_pitch[level];
     const int limit = level == 0 ? w : pitch;
     const int xo = blur_origin(bk.bx, limit);
-    const int n_tx = (w + 31) >> 5, tx = min(4 * (int)bk.bx + wave, n_tx - 1); // a wave past the last tile repeats it (not stored)
+    const int n_tx = (w + 31) >> 5, tx = min(BM_WAVES * (int)bk.bx + wave, n_tx - 1); // a wave past the last tile repeats it (not stored)
     const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level];
     uint8_t *D = arena + (size_t)frame * arena_fs + lv.dst_off[level];
     // band of the H pass for this wave's tile column: two K-steps of 32 source columns
@@ -1375,19 +1385,20 @@ __global__ __launch_bounds__(256) void k_blur_mfma(FastSrc src, BlurMfmaLevels l
     const bl_v4i bh0 = __builtin_bit_cast(bl_v4i, bh[lane]), bh1 = __builtin_bit_cast(bl_v4i, bh[64 + lane]);
     const int a_off = n * BM_SRC_P + (blur_window(tx, limit) - xo) + 16 * hh; // this lane's 16 operand bytes of K-step 0
 
-    // staging: 32 rows x ten 16-byte chunks per H tile = 320 chunks, thread t takes chunk t and (t < 64) chunk 256 + t.
+    // staging: 32 rows x BM_CH 16-byte chunks per H tile (128 columns: 320 chunks), thread t takes chunk t and, the first ones, chunk BM_T + t.
     // H tile T = rows 32 T - 3 .. 32 T + 28 (rows outside the image are clamped: their coefficients are zero).
-    const int c0r = tid / 10, c0c = tid - 10 * c0r, c1r = (256 + tid) / 10, c1c = (256 + tid) - 10 * c1r;
+    const int c0r = tid / BM_CH, c0c = tid - BM_CH * c0r, c1r = (BM_T + tid) / BM_CH, c1c = (BM_T + tid) - BM_CH * c1r;
+    const bool second = tid < 32 * BM_CH - BM_T;
     auto g_load = [&](int T, uint4 *u0, uint4 *u1) {
         const int r0 = min(max(32 * T - 3 + c0r, 0), h - 1), r1 = min(max(32 * T - 3 + min(c1r, 31), 0), h - 1);
         const UnalignedU4 a = *reinterpret_cast<const UnalignedU4 *>(S + (size_t)r0 * pitch + xo + 16 * c0c);
-        const UnalignedU4 b2 = *reinterpret_cast<const UnalignedU4 *>(S + (size_t)r1 * pitch + xo + 16 * (tid < 64 ? c1c : 0));
+        const UnalignedU4 b2 = *reinterpret_cast<const UnalignedU4 *>(S + (size_t)r1 * pitch + xo + 16 * (second ? c1c : 0));
         *u0 = make_uint4(a.x, a.y, a.z, a.w);
         *u1 = make_uint4(b2.x, b2.y, b2.z, b2.w);
     };
     auto s_store = [&](int buf, const uint4 &u0, const uint4 &u1) {
         *reinterpret_cast<uint4 *>(&s_src[buf][c0r * BM_SRC_P + 16 * c0c]) = u0;
-        if (tid < 64) *reinterpret_cast<uint4 *>(&s_src[buf][c1r * BM_SRC_P + 16 * c1c]) = u1;
+        if (second) *reinterpret_cast<uint4 *>(&s_src[buf][c1r * BM_SRC_P + 16 * c1c]) = u1;
     };
     // the H tile staged in `buf`, turned into the two A operands of the V pass
     auto h_tile = [&](int buf, bl_v4i *hi, bl_v4i *lo) {
@@ -1423,7 +1434,7 @@ __global__ __launch_bounds__(256) void k_blur_mfma(FastSrc src, BlurMfmaLevels l
     h_tile(0, &hiP, &loP);
     __syncthreads(); // buffer 0 is free for tile 2
     const uint4 *bv = band_v + lv.bv_off[level];
-    const int orow = tid >> 3, ocol = 16 * (tid & 7); // this thread's 16 bytes of the finished 32 x 128 tile
+    const int orow = tid / BM_OCH, ocol = 16 * (tid % BM_OCH); // this thread's 16 bytes of the finished 32 x BM_COLS tile
     // One barrier per trip: trip ty reads source buffer (ty + 1) & 1, so buffer ty & 1 (last read in trip ty - 1) takes
     // tile ty + 2 at the top of the trip, from registers loaded during the trip before; the finished tiles alternate
     // between two output buffers.
@@ -1539,11 +1550,11 @@ void orbx_launch_blur_mfma(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l
     int K = 0;
     for (int i = 0; i < 7; ++i) K += taps[i];
     if (K == 256)
-        hipLaunchKernelGGL(k_blur_mfma<256>, dim3(orbx_xcd_grid(count, n_frames)), dim3(256), 0, s, src, tab,
+        hipLaunchKernelGGL(k_blur_mfma<256>, dim3(orbx_xcd_grid(count, n_frames)), dim3(BM_T), 0, s, src, tab,
                            reinterpret_cast<const BlurBlock *>(d_blocks) + first, reinterpret_cast<const uint4 *>(d_band_h),
                            reinterpret_cast<const uint4 *>(d_band_v), b.img_arena, b.img_frame_stride, count, n_frames);
     else // K == 257 (orbx_blur_mfma_levels() returns 0 for any other tap set)
-        hipLaunchKernelGGL(k_blur_mfma<257>, dim3(orbx_xcd_grid(count, n_frames)), dim3(256), 0, s, src, tab,
+        hipLaunchKernelGGL(k_blur_mfma<257>, dim3(orbx_xcd_grid(count, n_frames)), dim3(BM_T), 0, s, src, tab,
                            reinterpret_cast<const BlurBlock *>(d_blocks) + first, reinterpret_cast<const uint4 *>(d_band_h),
                            reinterpret_cast<const uint4 *>(d_band_v), b.img_arena, b.img_frame_stride, count, n_frames);
 }
