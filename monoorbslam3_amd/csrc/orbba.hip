@@ -990,7 +990,7 @@ __device__ __forceinline__ bool solve6(const double *h21, double lam, const doub
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, int iterations, const int *__restrict__ edge_off,
+__global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, int iterations, int cap, const int *__restrict__ edge_off,
                                                        const double *__restrict__ R0, const double *__restrict__ t0,
                                                        const double *__restrict__ Pw, const double *__restrict__ z,
                                                        const double *__restrict__ w, double *__restrict__ R_out,
@@ -998,32 +998,54 @@ __global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, in
                                                        int *__restrict__ n_inliers, double *__restrict__ chi2_out)
 {
     __shared__ double red[4][28];
+    // A frame's edges (map point, measurement, weight, inlier flag: 49 bytes each) are read in every one of up to 4 x 10 x 2 passes:
+    // up to `cap` of them are staged in LDS once (structure of arrays), so a pass costs LDS latency instead of an L2 round trip per
+    // operand.  Same operations in the same order as from global memory (a frame with more edges keeps reading it from there).
+    extern __shared__ __align__(16) double sm[];
     const int f = blockIdx.x, tid = threadIdx.x, e0 = edge_off[f], n = edge_off[f + 1] - e0;
+    const bool staged = n <= cap;
+    double *const sPx = sm, *const sPy = sPx + cap, *const sPz = sPy + cap, *const szu = sPz + cap, *const szv = szu + cap, *const sww = szv + cap;
+    uint8_t *const sin_ = reinterpret_cast<uint8_t *>(sww + cap);
     double Ri[9], ti[3], R[9], t[3];
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = Ri[k] = R0[(size_t)f * 9 + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) t[k] = ti[k] = t0[(size_t)f * 3 + k];
-    for (int e = tid; e < n; e += 256) inlier[e0 + e] = 1;
+    for (int e = tid; e < n; e += 256) {
+        inlier[e0 + e] = 1;
+        if (staged) {
+            sPx[e] = Pw[(size_t)(e0 + e) * 3]; sPy[e] = Pw[(size_t)(e0 + e) * 3 + 1]; sPz[e] = Pw[(size_t)(e0 + e) * 3 + 2];
+            szu[e] = z[(size_t)(e0 + e) * 2]; szv[e] = z[(size_t)(e0 + e) * 2 + 1]; sww[e] = w[e0 + e];
+            sin_[e] = 1;
+        }
+    }
+    __syncthreads();
+    auto is_in = [&](int e) -> bool { return staged ? sin_[e] != 0 : inlier[e0 + e] != 0; };
+    auto weight = [&](int e) -> double { return staged ? sww[e] : w[e0 + e]; };
     const double d2 = cam.delta * cam.delta;
 
     // residual of edge e at pose (R, t); returns chi2, optionally the pieces needed for the Jacobian
     auto edge_chi = [&](int e, const double *Rc, const double *tc, double *ex, double *ey, double *Pc) -> double {
-        const double *P = Pw + (size_t)(e0 + e) * 3;
+        double P[3], zu, zv;
+        if (staged) { P[0] = sPx[e]; P[1] = sPy[e]; P[2] = sPz[e]; zu = szu[e]; zv = szv[e]; }
+        else {
+            const double *Pg = Pw + (size_t)(e0 + e) * 3;
+            P[0] = Pg[0]; P[1] = Pg[1]; P[2] = Pg[2]; zu = z[(size_t)(e0 + e) * 2]; zv = z[(size_t)(e0 + e) * 2 + 1];
+        }
         const double X = Rc[0] * P[0] + Rc[1] * P[1] + Rc[2] * P[2] + tc[0];
         const double Y = Rc[3] * P[0] + Rc[4] * P[1] + Rc[5] * P[2] + tc[1];
         const double Z = Rc[6] * P[0] + Rc[7] * P[1] + Rc[8] * P[2] + tc[2];
         double u, v;
         ba_project(cam, X, Y, Z, &u, &v);
-        *ex = z[(size_t)(e0 + e) * 2] - u;
-        *ey = z[(size_t)(e0 + e) * 2 + 1] - v;
+        *ex = zu - u;
+        *ey = zv - v;
         Pc[0] = X; Pc[1] = Y; Pc[2] = Z;
-        return w[e0 + e] * (*ex * *ex + *ey * *ey);
+        return weight(e) * (*ex * *ex + *ey * *ey);
     };
     auto robust_sum = [&](const double *Rc, const double *tc) -> double { // activeRobustChi2
         double s[1] = {0.0};
         for (int e = tid; e < n; e += 256) {
-            if (!inlier[e0 + e]) continue;
+            if (!is_in(e)) continue;
             double ex, ey, Pc[3];
             double c = edge_chi(e, Rc, tc, &ex, &ey, Pc);
             if (cam.delta > 0.0 && c > d2) c = 2.0 * cam.delta * sqrt(c) - d2;
@@ -1040,7 +1062,7 @@ __global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, in
 #pragma unroll
             for (int k = 0; k < 3; ++k) t[k] = ti[k];
             double cnt[1] = {0.0};
-            for (int e = tid; e < n; e += 256) cnt[0] += inlier[e0 + e] ? 1.0 : 0.0;
+            for (int e = tid; e < n; e += 256) cnt[0] += is_in(e) ? 1.0 : 0.0;
             block_sum_vals<1>(cnt, red);
             double lam = 0.0, ni = 2.0;
             if (cnt[0] > 0.0) {
@@ -1050,12 +1072,12 @@ __global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, in
 #pragma unroll
                     for (int k = 0; k < 28; ++k) acc[k] = 0.0;
                     for (int e = tid; e < n; e += 256) {
-                        if (!inlier[e0 + e]) continue;
+                        if (!is_in(e)) continue;
                         double ex, ey, Pc[3];
                         const double c = edge_chi(e, R, t, &ex, &ey, Pc);
                         double rw = 1.0, rc = c;
                         if (cam.delta > 0.0 && c > d2) { rw = cam.delta / sqrt(c); rc = 2.0 * cam.delta * sqrt(c) - d2; }
-                        const double W = rw * w[e0 + e], X = Pc[0], Y = Pc[1], Z = Pc[2];
+                        const double W = rw * weight(e), X = Pc[0], Y = Pc[1], Z = Pc[2];
                         double Jp[6];
                         ba_proj_jacobian(cam, X, Y, Z, Jp);
                         double Jq[12];
@@ -1132,6 +1154,7 @@ __global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, in
                 double ex, ey, Pc[3];
                 const double c = edge_chi(e, R, t, &ex, &ey, Pc);
                 inlier[e0 + e] = !(c > 5.991);
+                if (staged) sin_[e] = !(c > 5.991);
             }
             __syncthreads();
         }
@@ -1141,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, in
         double ex, ey, Pc[3];
         const double c = edge_chi(e, R, t, &ex, &ey, Pc);
         if (chi2_out) chi2_out[e0 + e] = c;
-        cnt[0] += (n >= 3 && inlier[e0 + e]) ? 1.0 : 0.0;
+        cnt[0] += (n >= 3 && is_in(e)) ? 1.0 : 0.0;
     }
     block_sum_vals<1>(cnt, red);
     if (tid == 0) {
@@ -1153,6 +1176,22 @@ __global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, in
     }
 }
 
+// edges of a frame staged in LDS by k_pose_optimize (49 bytes each; 0: never -- ORBBA_POSE_LDS=0, the parity twin)
+static int pose_lds_cap()
+{
+    const char *e = getenv("ORBBA_POSE_LDS");
+    return e ? std::max(0, std::min(atoi(e), 3000)) : 3000;
+}
+static size_t pose_lds_bytes(int cap) { return ((size_t)cap * 49 + 15) / 16 * 16; }
+static void pose_lds_configure(int cap)
+{
+    static std::atomic<size_t> configured{0};
+    const size_t need = pose_lds_bytes(cap);
+    if (need > configured.load()) { // (idempotent)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pose_optimize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+        configured.store(need);
+    }
+}
 extern "C" int orbba_pose_optimize_batch(const orbba_pose_problem *p, orbba_pose_result *r, int device)
 {
     if (!p || !r) return orbx_set_error(ORBX_E_ARG, "null argument");
@@ -1183,8 +1222,12 @@ extern "C" int orbba_pose_optimize_batch(const orbba_pose_problem *p, orbba_pose
     hipEvent_t e0, e1;
     B_TRY(hipEventCreate(&e0)); B_TRY(hipEventCreate(&e1));
     B_TRY(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_pose_optimize, dim3(B), dim3(256), 0, 0, cam, p->rounds > 0 ? p->rounds : 4,
-                       p->iterations > 0 ? p->iterations : 10, doff.as<int>(), dR0.as<double>(), dt0.as<double>(), dP.as<double>(),
+    int max_n = 0;
+    for (int f = 0; f < B; ++f) max_n = std::max(max_n, p->edge_off[f + 1] - p->edge_off[f]);
+    const int cap = std::min(pose_lds_cap(), max_n); // (no more LDS than the largest frame needs: more workgroups per CU for a big batch)
+    pose_lds_configure(cap);
+    hipLaunchKernelGGL(k_pose_optimize, dim3(B), dim3(256), pose_lds_bytes(cap), 0, cam, p->rounds > 0 ? p->rounds : 4,
+                       p->iterations > 0 ? p->iterations : 10, cap, doff.as<int>(), dR0.as<double>(), dt0.as<double>(), dP.as<double>(),
                        dz.as<double>(), dw.as<double>(), dR.as<double>(), dt.as<double>(), din.as<uint8_t>(), dni.as<int>(),
                        dchi.as<double>());
     B_TRY(hipEventRecord(e1, 0));
@@ -1259,8 +1302,10 @@ extern "C" int orbba_pose_optimize_batch_device(const orbba_pose_problem *p, orb
         !r->pose_R || !r->pose_t || !r->n_inliers || !r->inlier || !r->chi2)
         return orbx_set_error(ORBX_E_ARG, "null array (every pointer is device memory here, chi2 included)");
     const BaCam cam = make_cam(p->fx, p->fy, p->cx, p->cy, p->huber_delta, p->camera_model, p->fisheye_k);
-    hipLaunchKernelGGL(k_pose_optimize, dim3(p->n_frames), dim3(256), 0, (hipStream_t)stream, cam, p->rounds > 0 ? p->rounds : 4,
-                       p->iterations > 0 ? p->iterations : 10, p->edge_off, p->pose_R, p->pose_t, p->points, p->edge_z,
+    const int cap = pose_lds_cap(); // (the edge counts are on the device: the full capacity, one workgroup per CU)
+    pose_lds_configure(cap);
+    hipLaunchKernelGGL(k_pose_optimize, dim3(p->n_frames), dim3(256), pose_lds_bytes(cap), (hipStream_t)stream, cam, p->rounds > 0 ? p->rounds : 4,
+                       p->iterations > 0 ? p->iterations : 10, cap, p->edge_off, p->pose_R, p->pose_t, p->points, p->edge_z,
                        p->edge_inv_sigma2, r->pose_R, r->pose_t, r->inlier, r->n_inliers, r->chi2);
     B_TRY(hipGetLastError());
     r->kernel_ms = 0.f;

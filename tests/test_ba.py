@@ -218,9 +218,13 @@ def test_oracle_pose_optimize_recovers_pose_and_flags_outliers():
 
 
 @pytest.mark.gpu
-def test_gpu_pose_optimize_batch_matches_oracle():
+@pytest.mark.parametrize("lds", ["3000", "1000", "0"])
+def test_gpu_pose_optimize_batch_matches_oracle(monkeypatch, lds):
+    """Optimize.cpp:447-540 for a batch of frames: edges staged in LDS (ORBBA_POSE_LDS = capacity in edges; 1000: the two larger
+    frames of the batch keep reading global memory beside the staged ones; 0: every frame does -- the parity twin)."""
     from oracle import ba_ref
     from monoorbslam3_amd import ba
+    monkeypatch.setenv("ORBBA_POSE_LDS", lds)  # read per call
     sizes = [300, 1500, 2, 0, 64, 257, 2000, 3]
     cam, R0, t0, off, P, Z, W = _pose_frames(sizes, 17)
     got = ba.pose_optimize_batch(cam, R0, t0, off, P, Z, W)
