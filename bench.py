@@ -116,6 +116,52 @@ def cpu_baseline(frames, n_features, threads, match):
             "one_thread": one_stats, "all_threads": allc}
 
 
+def self_launch(n):
+    """Start `n` ranks of this script under torch.distributed.run on this node (one per GPU, rendezvous on 127.0.0.1 and
+    a free port), pass their output through and return the launcher's exit status.  Called before any GPU call."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    return subprocess.call(cmd, env=env)
+
+
+def stub_run(args, rank, world):
+    """`--stub-step`: the contract's control flow (warm-up, barrier + timing of exactly K steps, MAX over ranks, one JSON
+    line on rank 0) with the step replaced by a sleep, over gloo -- what a CPU test can check of the N > 1 launcher path."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    for _ in range(args.warmup):
+        time.sleep(1e-3)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": baseline_metric(), "value": round(world * (args.batch or 1) * args.steps / dt, 2), "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "stub",
+                          "config": {"workload": "launcher rehearsal: the step is a 1 ms sleep, nothing is measured"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +189,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-device rehearses the N>1 control flow on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank computes on cuda:0")
+    ap.add_argument("--stub-step", action="store_true",
+                    help="launcher rehearsal without a GPU: every rank replaces the step by a 1 ms sleep and runs the barrier / "
+                         "max-over-ranks timing over gloo (tests/test_dist_cpu.py drives `bench.py --gpus 2 --stub-step`)")
     ap.add_argument("--gather", default="torch", choices=["torch", "c-abi"],
                     help="N > 1: the record gather through torch.distributed (default) or through the library's own RCCL "
                          "entry point orbd_gather_records (include/orbd.h)")
@@ -158,9 +207,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` from a plain shell: start the N ranks ourselves.  Nothing in this process has touched
+        # the GPU yet (importing torch does not initialise it), and the ranks are CHILD processes -- a process that has
+        # initialised the GPU is never replaced by another program.
+        sys.exit(self_launch(args.gpus))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        sys.exit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or from a plain shell"
+                 % (args.gpus, world, args.gpus))
+    if args.stub_step:
+        return stub_run(args, rank, world)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
     if args.share_device:

@@ -648,6 +648,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
 #define FS_K 4                       // cells per strip (at most)
 #endif
 static_assert(FS_K >= 1 && FS_K <= 4, "a strip's tile row is 16 eight-byte items and its compass pass 32 lanes wide: at most 4 cells");
+static_assert(4 * ((FS_K * ORBX_CELL + 3) / 4) + 3 < 128, "a pixel entry keeps the tile column in 7 bits (bit 7 is the polarity)");
 #define FS_W (FS_K * ORBX_CELL)      // region columns of a full strip
 #define FS_G ((FS_W + 3) / 4)        // 4-pixel groups of a full strip
 #define FS_LG (FS_G <= 8 ? 8 : FS_G <= 16 ? 16 : 32) // lanes per tile row in the dense stage (a power of two >= FS_G)
@@ -669,18 +670,23 @@ struct __attribute__((aligned(8))) FastStrip { // 8-byte aligned: one scalar loa
 // the same barrier, leaving a named comment in the ISA: tools/isa_mix.py counts the instructions between "name_begin" and "name_end"
 #define FS_MARK(name) asm volatile("; FSM " name ::: "memory")
 
-// bit 7 of every byte set <=> at least 9 contiguous (cyclic) of the 16 flags x[k] have bit 7 set in that byte
+// three-input logic in one instruction (v_bitop3_b32: result bit = table[(a << 2) | (b << 1) | c], cheap issue class)
+#define B3_AND3 0x80      // a & b & c
+#define B3_A_AND_BORC 0xE0 // a & (b | c)
+#define B3_A_OR_BANDC 0xF8 // a | (b & c)
+// bit 7 of every byte set <=> at least 9 contiguous (cyclic) of the 16 flags x[k] have bit 7 set in that byte.
+// A 9-run holds four whole aligned pairs (2s, 2s+1) .. (2s+6, 2s+7) and the flag before or after them: 32 three-input
+// operations (the 2 -> 4 -> 8 doubling on the pairs took 40).
 __device__ __forceinline__ uint32_t swar_arc9(const uint32_t x[16])
 {
-    uint32_t a[8], q[8], any = 0;
+    uint32_t a[8], any = 0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) a[s] = x[2 * s] & x[2 * s + 1];           // 2 from 2s
-#pragma unroll
-    for (int s = 0; s < 8; ++s) q[s] = a[s] & a[(s + 1) & 7];             // 4 from 2s
+    for (int s = 0; s < 8; ++s) a[s] = x[2 * s] & x[2 * s + 1];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const uint32_t o = q[s] & q[(s + 2) & 7];                         // 8 from 2s
-        any |= o & (x[(2 * s + 8) & 15] | x[(2 * s + 15) & 15]);          // ... plus the one after or the one before
+        const uint32_t b = __builtin_amdgcn_bitop3_b32(a[s], a[(s + 1) & 7], a[(s + 2) & 7], B3_AND3);
+        const uint32_t d = __builtin_amdgcn_bitop3_b32(a[(s + 3) & 7], x[(2 * s + 8) & 15], x[(2 * s + 15) & 15], B3_A_AND_BORC);
+        any = s == 0 ? (b & d) : __builtin_amdgcn_bitop3_b32(any, b, d, B3_A_OR_BANDC);
     }
     return any;
 }
@@ -697,6 +703,46 @@ __device__ __forceinline__ int wave_rank(u64 mk)
 __device__ __forceinline__ int wave_rank_from(u64 mk, int base)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, (uint32_t)base));
+}
+
+// ballot of "byte J of v is not zero" in ONE instruction (the byte select rides on the compare: SDWA), result in a scalar pair
+template <int J> __device__ __forceinline__ u64 ballot_byte_nz(uint32_t v)
+{
+    u64 mk;
+    if (J == 0) asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD" : "=s"(mk) : "v"(v), "s"(0));
+    if (J == 1) asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_1 src1_sel:DWORD" : "=s"(mk) : "v"(v), "s"(0));
+    if (J == 2) asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD" : "=s"(mk) : "v"(v), "s"(0));
+    if (J == 3) asm volatile("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:DWORD" : "=s"(mk) : "v"(v), "s"(0));
+    return mk;
+}
+// (byte J of a, zero-extended) | b in one instruction
+template <int J> __device__ __forceinline__ uint32_t or_byte(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    if (J == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(a), "v"(b));
+    if (J == 1) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(a), "v"(b));
+    if (J == 2) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(a), "v"(b));
+    if (J == 3) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// 16-bit LDS store by the lanes of `mk` only: the ballot IS the execution mask, so the predicate is not evaluated a second time
+// (written as a branch the compiler compares again for the mask).  `addr` = byte address inside LDS.
+__device__ __forceinline__ void lds_store_u16_masked(u64 mk, uint32_t addr, uint32_t val)
+{
+    u64 save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(mk), "v"(addr), "v"(val) : "memory");
+}
+// (a << 1) + b in one instruction, b from a scalar register
+__device__ __forceinline__ uint32_t shl1_add(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
 
 #ifdef OCT_PROF
@@ -779,10 +825,12 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         const bool live = lane < n;
         const int e = cq[(cq_head + min(lane, n - 1)) & (FS_CQ - 1)];
         cq_head += n;
-        // bit 15: the arc test passed the pixel as a BRIGHT corner candidate.  A corner at T >= 0 is dark or bright, never
+        // bit 7: the arc test passed the pixel as a BRIGHT corner candidate.  A corner at T >= 0 is dark or bright, never
         // both (two 9-arcs of a 16-ring share two pixels), and its strength is its own polarity's arc measure; with
         // every byte complemented the bright measure is the dark one, so one window pass serves either polarity.
-        const int r = (e >> 8) & 31, tc = e & 127, F = (e & 0x8000) ? 255 : 0;
+        const int r = (e >> 8) & 31, tc = e & 127;
+        int F = (e & 0x80) ? 255 : 0;
+        asm("" : "+v"(F)); // kept as one vector register: folded into the 17 exclusive-ors it would make each a three-input operation with a scalar operand (slow class)
         const uint8_t *t = &tile[r * FS_TP + tc - 3]; // ring pixel (dx, dy) at t[(dy + 3) * FS_TP + dx + 3]
 #define FS_PX(dx, dy) ((int)t[((dy) + 3) * FS_TP + (dx) + 3] ^ F)
         int p[16];
@@ -843,26 +891,26 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         for (int k = 0; k < 16; ++k) x[k] = Vb + R[k];   // bit 7: brighter (superset)
         const uint32_t mb = swar_arc9(x) & mc;
         const uint32_t m = md | mb;
-        // pixel entry: row << 8 | tile column, bit 15 = candidate of a BRIGHT corner (the exact stage then evaluates that
+        // pixel entry: row << 8 | tile column, bit 7 = candidate of a BRIGHT corner (the exact stage then evaluates that
         // polarity only).  With t6 >= 1 no pixel passes both; at thresholds 0..2 (t6 = 0) the dark entry is queued too.
+        // Byte j of `mbj` is the entry's low byte less the column base: 0x80 for bright, + j.
         const uint32_t ent = (uint32_t)(r << 8) | (uint32_t)(4 * g + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool hit = (m >> (8 * j + 7)) & 1u;
-            const u64 mk = __ballot(hit);
-            const uint32_t tag = (j == 0 ? (mb << 8) : (mb >> (8 * j - 8))) & 0x8000u;
-            if (hit) cq[wave_rank_from(mk, cq_tail) & (FS_CQ - 1)] = (uint16_t)((ent + j) | tag);
-            cq_tail += (int)__popcll(mk);
+        const uint32_t mbj = mb | 0x03020100u;
+        const uint32_t cq_base = lds_addr(cq);
+#define FS_QUEUE_PIXEL(j, flags, tagsrc)                                                                         \
+        {                                                                                                        \
+            const u64 mk = ballot_byte_nz<j>(flags);                                                             \
+            const uint32_t pos = (uint32_t)wave_rank_from(mk, cq_tail);                                          \
+            lds_store_u16_masked(mk, shl1_add(pos & (FS_CQ - 1), cq_base), or_byte<j>(tagsrc, ent));                  \
+            cq_tail += (int)__popcll(mk);                                                                        \
         }
+        FS_QUEUE_PIXEL(0, m, mbj) FS_QUEUE_PIXEL(1, m, mbj) FS_QUEUE_PIXEL(2, m, mbj) FS_QUEUE_PIXEL(3, m, mbj)
         if (both_possible) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool hit = ((md & mb) >> (8 * j + 7)) & 1u;
-                const u64 mk = __ballot(hit);
-                if (hit) cq[wave_rank_from(mk, cq_tail) & (FS_CQ - 1)] = (uint16_t)(ent + j);
-                cq_tail += (int)__popcll(mk);
-            }
+            const uint32_t both = md & mb;
+            FS_QUEUE_PIXEL(0, both, 0x03020100u) FS_QUEUE_PIXEL(1, both, 0x03020100u) FS_QUEUE_PIXEL(2, both, 0x03020100u)
+            FS_QUEUE_PIXEL(3, both, 0x03020100u)
         }
+#undef FS_QUEUE_PIXEL
         FS_MARK("arc_end");
     };
 
@@ -1465,7 +1513,11 @@ __global__ __launch_bounds__(BM_T) void k_blur_mfma(FastSrc src, BlurMfmaLevels 
         __syncthreads(); // the finished tile and the source of the next trip are complete
         {
             const int y = 32 * ty + orow, x = BM_COLS * (int)bk.bx + ocol;
+#ifdef BM_PROBE_NOSTORE // timing probe only (tools/build_variant.sh): the blur without its HBM writes
+            if (y < h && x < dpitch && frame < 0) {
+#else
             if (y < h && x < dpitch) { // columns between the width and the padded pitch take whatever the last tile holds
+#endif
                 const uint32_t *o = reinterpret_cast<const uint32_t *>(&so[orow * BM_OUT_P + ocol]);
                 *reinterpret_cast<uint4 *>(D + (size_t)y * dpitch + x) = make_uint4(o[0], o[1], o[2], o[3]);
             }

@@ -140,3 +140,27 @@ def test_c_abi_exchange_fails_loudly_without_a_gpu():
         D.RecordExchange.unique_id()
     with pytest.raises(OrbxError, match="no HIP device"):
         D.RecordExchange(0, 1, bytes(128))
+
+
+def test_bench_launches_its_own_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts the two ranks itself (children of the
+    launcher, before any GPU call), passes rank 0's JSON line through and returns the children's status.  The step is the
+    `--stub-step` sleep: what is checked is the launcher and the barrier / max-over-ranks control flow over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-step", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["data"] == "stub"
+    assert out["ms_per_step"] >= 1.0  # four 1 ms sleeps between the barriers, the slower rank counts
+    # a mismatch between --gpus and an existing WORLD_SIZE is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-step"], capture_output=True, text=True,
+                        timeout=120, env=env2)
+    assert r2.returncode != 0 and "WORLD_SIZE" in r2.stderr
