@@ -192,6 +192,10 @@ def main():
     ap.add_argument("--stub-step", action="store_true",
                     help="launcher rehearsal without a GPU: every rank replaces the step by a 1 ms sleep and runs the barrier / "
                          "max-over-ranks timing over gloo (tests/test_dist_cpu.py drives `bench.py --gpus 2 --stub-step`)")
+    ap.add_argument("--variant", action="append", default=[], metavar="NAME=VALUE",
+                    help="kernel-choice switch of the extractor handle (orbx_set_variant; names in monoorbslam3_amd/extractor.py "
+                         "VARIANTS, e.g. --variant side_blur=2 --variant desc=separate); repeatable")
+    ap.add_argument("--best2", default="fp4", choices=["fp4", "i8", "valu"], help="dense best / second-best kernel (orbm_set_variant)")
     ap.add_argument("--gather", default="torch", choices=["torch", "c-abi"],
                     help="N > 1: the record gather through torch.distributed (default) or through the library's own RCCL "
                          "entry point orbd_gather_records (include/orbd.h)")
@@ -250,7 +254,11 @@ def main():
         noise = torch.randint(-2, 3, frames.shape, generator=g, dtype=torch.int16).to(dev)
         noise[:n_distinct] = 0
         frames = (frames.to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8).contiguous()
-    ex = ORBExtractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
+    variants = {}
+    for kv in args.variant:
+        k, _, v = kv.partition("=")
+        variants[k] = int(v) if v.lstrip("-").isdigit() else v
+    ex = ORBExtractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank, variants=variants)
     cap = ex.max_keypoints(W, H)
     # two output sets: the best-2 match of batch k runs on its own stream while batch k+1 is being extracted
     NBUF = 2
@@ -261,6 +269,7 @@ def main():
     d_bd = [torch.zeros((B, cap), dtype=torch.int16, device=dev) for _ in range(NBUF)]
     d_sd = [torch.zeros((B, cap), dtype=torch.int16, device=dev) for _ in range(NBUF)]
     mh = MatcherHandle(device=local_rank)
+    mh.set_variant("best2", args.best2)
     ML = _mlib()
     rec = None
     if args.records:  # SURVEY 8f rows 2 and 3 chained behind the extraction, all on device buffers
@@ -574,7 +583,7 @@ def main():
     if match_ms > 0:
         tops = pairs * 512 / (match_ms * 1e-3) / 1e12
         mfma = {"pairs_per_step": int(pairs), "gpairs_per_s": round(pairs / (match_ms * 1e-3) / 1e9, 2),
-                "pipe": "v_mfma_f32_32x32x64_f8f6f4 (FP4 operands)" if os.environ.get("ORBM_BEST2", "fp4") == "fp4" else os.environ.get("ORBM_BEST2"),
+                "pipe": "v_mfma_f32_32x32x64_f8f6f4 (FP4 operands)" if args.best2 == "fp4" else args.best2,
                 "achieved_TOPS": round(tops, 1), "peak_TOPS": MFMA_FP4_PEAK_TOPS, "frac_of_dense_fp4_peak": round(tops / MFMA_FP4_PEAK_TOPS, 3),
                 "note": "2 x 256 operations per 256-bit pair; peak = 4096 operations per cycle per SIMD x 1024 SIMDs x 2.4 GHz "
                         "(32 cycles per 32x32x64 instruction, measured by tools/microbench/fp4_hamming.hip)"}

@@ -131,10 +131,19 @@ int orbba_pose_optimize_batch_device(const orbba_pose_problem *p, orbba_pose_res
  * d_q_points[3q..] (float, mp->getPos()), the measurement kp.pt of d_kps[i] (orbx_kp records, undistorted) and
  * invSigma2 = 1.f / kp.size / kp.size (:479).  d_edge_off receives {0, n_edges} (one frame); d_points / d_edge_z /
  * d_edge_inv_sigma2 need room for n2 edges; d_edge_kp (may be NULL) receives i per edge -- the vecIndices of :464 that the
- * caller uses to drop the outliers from the frame (:531-537).  Enqueued on `stream`. */
+ * caller uses to drop the outliers from the frame (:531-537).  Enqueued on `stream`.
+ * d_frame_mp must hold indices of ONE query set: when two searches filled it (Tracking.cpp:289-336 runs frame -> frame and then
+ * map points -> frame on the same frame_mp), give both searches one shared index space -- concatenated query arrays with
+ * q_ok masks selecting each search's part -- and pass the concatenated d_q_points here. */
 int orbba_pose_edges_device(int n2, int nq, const int32_t *d_frame_mp, const void *d_kps, const float *d_q_points,
                             int32_t *d_edge_off, double *d_points, double *d_edge_z, double *d_edge_inv_sigma2,
                             int32_t *d_edge_kp, void *stream);
+
+/* Kernel-choice switches (parity twins; no reference counterpart).  The BA entry points take no handle, so a switch holds
+ * for the process and is read per call.  Unknown switch / value out of range: ORBX_E_ARG. */
+#define ORBBA_VAR_CHOL 0      /* reduced pose system: 0 solved in LDS when it fits (default), 1 the global-memory kernel */
+#define ORBBA_VAR_POSE_LDS 1  /* poseOptimize: edges of a frame staged in LDS, 0 .. 3000 (default 3000; 0 = never) */
+int orbba_set_variant(int which, int value);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,11 @@ typedef struct orbm_ctx orbm_t;
 
 int orbm_create(int device, orbm_t **out);
 void orbm_destroy(orbm_t *h);
+/* Kernel-choice switches per handle (parity twins; no reference counterpart).  They replace the ORBM_BEST2 / ORBM_WINDOW
+ * environment variables of earlier builds.  Unknown switch / value out of range: ORBX_E_ARG. */
+#define ORBM_VAR_BEST2 0   /* dense best / second-best: 0 FP4 matrix path k_best2_fp4 (default), 1 i8 matrix path k_best2_mfma, 2 VALU k_best2 */
+#define ORBM_VAR_WINDOW 1  /* window searches of the host entry points: 0 grid and lists on the device (default), 1 host grid */
+int orbm_set_variant(orbm_t *h, int which, int value);
 
 /* DBoW2::FeatureVector (thirdParty/DBoW2/DBoW2/FeatureVector.h) flattened to CSR:
  * node ids ascending, indices of a node in insertion (ascending feature) order. */
@@ -58,9 +63,9 @@ int orbm_hamming_matrix_device(orbm_t *h, const uint8_t *d_a, int na, const uint
  * (may be NULL) are byte masks: skipped queries return (-1,256,256); masked candidates
  * are not considered.  `n_pairs` independent (A,B) problems are processed in one launch:
  * problem p uses a + p*a_stride ... (strides in descriptors/elements).  Device pointers.
- * Which kernel runs: problems without a candidate mask (d_col_ok == NULL) and nb_max <= 8160 take the matrix-pipe
- * kernel (k_best2_mfma); a candidate mask, more candidates, or ORBM_BEST2=valu in the environment take the VALU
- * kernel (k_best2).  Both give the same outputs; only the speed differs. */
+ * Which kernel runs: problems without a candidate mask (d_col_ok == NULL) and nb_max <= 8160 take a matrix-pipe
+ * kernel (k_best2_fp4, or k_best2_mfma with ORBM_VAR_BEST2 = 1); a candidate mask, more candidates, or ORBM_VAR_BEST2 = 2
+ * take the VALU kernel (k_best2).  All three give the same outputs; only the speed differs. */
 int orbm_best2_device(orbm_t *h, int n_pairs, const uint8_t *d_a, size_t a_stride, const int32_t *d_na, int na_max,
                       const uint8_t *d_b, size_t b_stride, const int32_t *d_nb, int nb_max,
                       const uint8_t *d_row_ok, const uint8_t *d_col_ok, int32_t *d_best_idx, uint16_t *d_best,

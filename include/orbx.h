@@ -125,6 +125,26 @@ int orbx_tap_level_counts(orbx_t *h, int frame, int32_t *counts);
  * i.e. glibc cosf / sinf of angle_deg * (float)(CV_PI / 180.f)) on n host angles; cos_sin receives n (cos, sin) pairs */
 int orbx_tap_sincos(orbx_t *h, const float *angles_deg, int n, float *cos_sin);
 
+/* ---- kernel-choice switches (no reference counterpart) ----
+ * Every stage has one default kernel per call size and at least one parity twin that produces the same bytes; these
+ * select them per handle (tests run every twin, tools measure them).  They replace the environment variables earlier
+ * builds read: an exported variable in a user's shell can no longer change which kernel Tracking runs.  A new value
+ * applies from the next extract call; an unknown switch or a value outside its range is ORBX_E_ARG. */
+#define ORBX_VAR_FAST 0         /* 0 by call size (default: strips of cells from 24 frames), 1 one wave per cell, 2 strips */
+#define ORBX_VAR_BLUR 1         /* 1 by call size (default: matrix pipe from 8 frames, levels >= 160 px), 0 VALU kernels, 2 matrix pipe */
+#define ORBX_VAR_RESIZE_LDS 2   /* 1 by call size (default: source tile through LDS for resident batches), 0 never, 2 always */
+#define ORBX_VAR_RESIZE2 3      /* 1 by call size (default: two levels per launch below 24 frames), 0 never, 2 always */
+#define ORBX_VAR_SIDE_BLUR 4    /* blur pass on a side stream: 1 beside FAST (default), 2 beside the quadtree, 3 beside the orientation, 0 in line */
+#define ORBX_VAR_EARLY_FAST 5   /* level 0's FAST beside the pyramid: -1 by pyramid kernel (default), 0 no, 1 yes, 2 and its blur */
+#define ORBX_VAR_SPLIT_LEVEL0 6 /* synchronous calls with a few frames: first level of the main chain (default 1), 0 = one chain */
+#define ORBX_VAR_STREAMS 7      /* frame ranges of a batch on 1..8 internal streams (default 1) */
+#define ORBX_VAR_ZERO_COPY 8    /* 1 small calls write their records into pinned host memory (default), 0 copy them back */
+#define ORBX_VAR_DESC 9         /* 0 by call size (default), 1 separate blur pass + k_orient_desc, 2 k_blur_desc (blur and
+                                 * descriptors in one pass over the raw level, no blurred level in memory) */
+#define ORBX_N_VARIANTS 10
+int orbx_set_variant(orbx_t *h, int which, int value);
+int orbx_get_variant(const orbx_t *h, int which, int *value);
+
 /* ---- per-kernel timing (HIP events on the handle's stream) ---- */
 #define ORBX_STAGE_RESIZE 0
 #define ORBX_STAGE_FAST 1

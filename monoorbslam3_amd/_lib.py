@@ -59,6 +59,8 @@ def lib():
         "orbx_tap_candidates": (i32, [vp, i32, i32, vp, vp, vp, i32, C.POINTER(i32)]),
         "orbx_tap_level_counts": (i32, [vp, i32, vp]),
         "orbx_tap_sincos": (i32, [vp, vp, i32, vp]),
+        "orbx_set_variant": (i32, [vp, i32, i32]),
+        "orbx_get_variant": (i32, [vp, i32, C.POINTER(i32)]),
         "orbx_set_stage_timing": (i32, [vp, i32]),
         "orbx_fast_times_in_step_ms": (i32, [vp, C.POINTER(f32), C.POINTER(i32)]),
         "orbx_stage_times_ms": (i32, [vp, vp]),

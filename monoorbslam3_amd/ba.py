@@ -11,6 +11,15 @@ import numpy as np
 from . import _lib
 
 
+def set_variant(name, value):
+    """orbba_set_variant (per process): "chol" = "lds" | "global", "pose_lds" = edges of a frame staged in LDS (0 .. 3000)."""
+    L = _lib.lib()
+    L.orbba_set_variant.restype = C.c_int
+    L.orbba_set_variant.argtypes = [C.c_int, C.c_int]
+    which = {"chol": 0, "pose_lds": 1}[name]
+    _lib.check(L.orbba_set_variant(which, int({"lds": 0, "global": 1}.get(value, value))))
+
+
 class _Problem(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("huber_delta", C.c_double), ("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),

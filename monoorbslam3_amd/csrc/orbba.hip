@@ -21,12 +21,24 @@
 #include "../../include/orbx.h"
 
 int orbx_set_error(int code, const std::string &msg);
+hipError_t orbx_lds_opt_in(const void *kernel, size_t bytes); // orbx_api.hip: dynamic LDS above 64 KB, per kernel and per device
 #define B_TRY(expr)                                                                                    \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
         if (e_ != hipSuccess)                                                                          \
             return orbx_set_error(ORBX_E_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// kernel-choice switches of the BA entry points (include/orbba.h: orbba_set_variant); the entry points take no handle, so the
+// switches are per process and read per call
+static std::atomic<int> g_ba_chol{0};        // ORBBA_VAR_CHOL: 0 = reduced system in LDS when it fits, 1 = global-memory kernel
+static std::atomic<int> g_ba_pose_lds{3000}; // ORBBA_VAR_POSE_LDS: edges of a frame k_pose_optimize stages in LDS (0 .. 3000)
+extern "C" int orbba_set_variant(int which, int value)
+{
+    if (which == ORBBA_VAR_CHOL && (value == 0 || value == 1)) { g_ba_chol.store(value); return ORBX_OK; }
+    if (which == ORBBA_VAR_POSE_LDS && value >= 0 && value <= 3000) { g_ba_pose_lds.store(value); return ORBX_OK; }
+    return orbx_set_error(ORBX_E_ARG, "unknown BA variant switch or value out of range");
+}
 
 struct BaCam { double fx, fy, cx, cy, delta; int model; double k[4]; };
 static BaCam make_cam(double fx, double fy, double cx, double cy, double delta, int model, const double *k)
@@ -776,20 +788,23 @@ extern "C" int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o,
             hipLaunchKernelGGL(k_lm_schur, dim3(NF * (NF + 1) / 2), dim3(256), 0, 0, NF, NL, lam, dfree.as<int>(), deo.as<int>(),
                                dHpp.as<double>(), dbp.as<double>(), dHlp.as<double>(), dinv.as<double>(), dtl.as<double>(),
                                dS.as<double>(), drhs.as<double>());
-            const char *chol_env = getenv("ORBBA_CHOL"); // =global: the global-memory kernel, the parity twin (read per call)
-            const bool chol_global = chol_env && !strcmp(chol_env, "global");
-            if (N <= CH_MAX_N && !chol_global) {
+            // ORBBA_VAR_CHOL = 1: the global-memory kernel, the parity twin (read per call)
+            bool in_lds = N <= CH_MAX_N && g_ba_chol.load() == 0;
+            if (in_lds) {
                 const size_t lds = sizeof(double) * ((size_t)(N + 1) * (N + 1) + N);
-                static std::atomic<size_t> configured{0};
-                if (lds > configured.load()) { // (idempotent: racing threads set the same or a larger value)
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lm_chol_solve_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    configured.store(lds);
+                // per device; when the opt-in or the launch is refused the global-memory kernel solves the system instead --
+                // a launch that did not happen would leave the previous iteration's step in dxp / dflag
+                in_lds = orbx_lds_opt_in(reinterpret_cast<const void *>(k_lm_chol_solve_lds), lds) == hipSuccess;
+                if (in_lds) {
+                    hipLaunchKernelGGL(k_lm_chol_solve_lds, dim3(1), dim3(CH_T), lds, 0, N, dS.as<double>(), drhs.as<double>(), dxp.as<double>(),
+                                       dflag.as<int>());
+                    in_lds = hipGetLastError() == hipSuccess;
                 }
-                hipLaunchKernelGGL(k_lm_chol_solve_lds, dim3(1), dim3(CH_T), lds, 0, N, dS.as<double>(), drhs.as<double>(), dxp.as<double>(),
-                                   dflag.as<int>());
-            } else {
+            }
+            if (!in_lds) {
                 hipLaunchKernelGGL(k_lm_chol_solve, dim3(1), dim3(256), 0, 0, N, dS.as<double>(), drhs.as<double>(), dxp.as<double>(),
                                    dflag.as<int>());
+                B_TRY(hipGetLastError());
             }
             hipLaunchKernelGGL(k_lm_backsub, dim3(LB), dim3(256), 0, 0, NL, lam, dlo.as<int>(), dep.as<int>(), dslot.as<int>(),
                                dHlp.as<double>(), dxp.as<double>(), dbl.as<double>(), dinv.as<double>(), dxl.as<double>(),
@@ -1176,21 +1191,12 @@ __global__ __launch_bounds__(256) void k_pose_optimize(BaCam cam, int rounds, in
     }
 }
 
-// edges of a frame staged in LDS by k_pose_optimize (49 bytes each; 0: never -- ORBBA_POSE_LDS=0, the parity twin)
-static int pose_lds_cap()
-{
-    const char *e = getenv("ORBBA_POSE_LDS");
-    return e ? std::max(0, std::min(atoi(e), 3000)) : 3000;
-}
+// edges of a frame staged in LDS by k_pose_optimize (49 bytes each; ORBBA_VAR_POSE_LDS = 0: never, the parity twin)
+static int pose_lds_cap() { return g_ba_pose_lds.load(); }
 static size_t pose_lds_bytes(int cap) { return ((size_t)cap * 49 + 15) / 16 * 16; }
-static void pose_lds_configure(int cap)
+static hipError_t pose_lds_configure(int cap)
 {
-    static std::atomic<size_t> configured{0};
-    const size_t need = pose_lds_bytes(cap);
-    if (need > configured.load()) { // (idempotent)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pose_optimize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-        configured.store(need);
-    }
+    return orbx_lds_opt_in(reinterpret_cast<const void *>(k_pose_optimize), pose_lds_bytes(cap)); // per device, largest size wins
 }
 extern "C" int orbba_pose_optimize_batch(const orbba_pose_problem *p, orbba_pose_result *r, int device)
 {
@@ -1225,7 +1231,7 @@ extern "C" int orbba_pose_optimize_batch(const orbba_pose_problem *p, orbba_pose
     int max_n = 0;
     for (int f = 0; f < B; ++f) max_n = std::max(max_n, p->edge_off[f + 1] - p->edge_off[f]);
     const int cap = std::min(pose_lds_cap(), max_n); // (no more LDS than the largest frame needs: more workgroups per CU for a big batch)
-    pose_lds_configure(cap);
+    B_TRY(pose_lds_configure(cap));
     hipLaunchKernelGGL(k_pose_optimize, dim3(B), dim3(256), pose_lds_bytes(cap), 0, cam, p->rounds > 0 ? p->rounds : 4,
                        p->iterations > 0 ? p->iterations : 10, cap, doff.as<int>(), dR0.as<double>(), dt0.as<double>(), dP.as<double>(),
                        dz.as<double>(), dw.as<double>(), dR.as<double>(), dt.as<double>(), din.as<uint8_t>(), dni.as<int>(),
@@ -1303,7 +1309,7 @@ extern "C" int orbba_pose_optimize_batch_device(const orbba_pose_problem *p, orb
         return orbx_set_error(ORBX_E_ARG, "null array (every pointer is device memory here, chi2 included)");
     const BaCam cam = make_cam(p->fx, p->fy, p->cx, p->cy, p->huber_delta, p->camera_model, p->fisheye_k);
     const int cap = pose_lds_cap(); // (the edge counts are on the device: the full capacity, one workgroup per CU)
-    pose_lds_configure(cap);
+    B_TRY(pose_lds_configure(cap));
     hipLaunchKernelGGL(k_pose_optimize, dim3(p->n_frames), dim3(256), pose_lds_bytes(cap), (hipStream_t)stream, cam, p->rounds > 0 ? p->rounds : 4,
                        p->iterations > 0 ? p->iterations : 10, cap, p->edge_off, p->pose_R, p->pose_t, p->points, p->edge_z,
                        p->edge_inv_sigma2, r->pose_R, r->pose_t, r->inlier, r->n_inliers, r->chi2);

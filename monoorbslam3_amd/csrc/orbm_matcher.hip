@@ -27,6 +27,7 @@ typedef unsigned long long u64;
 extern "C" const char *orbx_last_error(void);
 // error text is shared with the extractor (orbx_api.hip owns the thread-local string)
 int orbx_set_error(int code, const std::string &msg);
+hipError_t orbx_lds_opt_in(const void *kernel, size_t bytes); // orbx_api.hip: dynamic LDS above 64 KB, per kernel and per device
 #define M_TRY(expr)                                                                                    \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
@@ -970,7 +971,8 @@ struct orbm_ctx {
     DevBuf a, b, out, q_idx, c_begin, c_len, out_begin, c_idx, row_ok, col_ok, bidx, bbest, bsecond;
     DevBuf w_in, w_out, w_grid; // window searches: staged inputs, lists, CSR grid + scratch
     PinBuf h_in, h_out;
-    int window_on_device = 1;   // ORBM_WINDOW=host keeps the host grid (the parity twin of the device lists)
+    int window_on_device = 1;   // ORBM_VAR_WINDOW = 1 keeps the host grid (the parity twin of the device lists)
+    int best2_variant = 0;      // ORBM_VAR_BEST2: 0 = fp4, 1 = i8, 2 = valu
     size_t window_last_total = 0; // candidates the previous window search returned (sizes the first copy-out)
 };
 
@@ -989,12 +991,16 @@ extern "C" int orbm_create(int device, orbm_t **out)
         delete c;
         return orbx_set_error(ORBX_E_NO_DEVICE, "stream creation failed");
     }
-    {
-        const char *e = getenv("ORBM_WINDOW");
-        c->window_on_device = !(e && strcmp(e, "host") == 0);
-    }
     *out = c;
     return ORBX_OK;
+}
+
+extern "C" int orbm_set_variant(orbm_t *c, int which, int value)
+{
+    if (!c) return orbx_set_error(ORBX_E_ARG, "null handle");
+    if (which == ORBM_VAR_BEST2 && value >= 0 && value <= 2) { c->best2_variant = value; return ORBX_OK; }
+    if (which == ORBM_VAR_WINDOW && (value == 0 || value == 1)) { c->window_on_device = !value; return ORBX_OK; }
+    return orbx_set_error(ORBX_E_ARG, "unknown matcher variant switch or value out of range");
 }
 
 extern "C" void orbm_destroy(orbm_t *c)
@@ -1052,11 +1058,8 @@ extern "C" int orbm_best2_device(orbm_t *c, int n_pairs, const uint8_t *d_a, siz
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     // the matrix-pipe kernel takes every problem without a candidate mask and at most BM_MAX_CAND (8160) candidates --
     // 16 * tile + register must stay below the 4096 free low bits of its keys; anything else runs k_best2;
-    // ORBM_BEST2=valu keeps everything on the VALU kernel (its parity twin)
-    static const int variant = [] { // ORBM_BEST2 = fp4 (default) | i8 | valu
-        const char *e = getenv("ORBM_BEST2");
-        return !e ? 2 : strcmp(e, "valu") == 0 ? 0 : strcmp(e, "i8") == 0 ? 1 : 2;
-    }();
+    // ORBM_VAR_BEST2 = 2 keeps everything on the VALU kernel (the parity twin), 1 takes the i8 matrix kernel
+    const int variant = c->best2_variant == 0 ? 2 : c->best2_variant == 1 ? 1 : 0; // 2 = fp4, 1 = i8, 0 = valu
     const bool use_mfma = variant != 0;
     if (variant == 2 && !d_col_ok && nb_max <= BM_MAX_CAND) {
         dim3 grid((na_max + BF_WAVES * 64 - 1) / (BF_WAVES * 64), n_pairs);
@@ -1580,7 +1583,7 @@ struct WindowQueries {
 // q.e[q.c_begin[k] .. + q.c_len[k]) (distance << 22 | index) in the reference's getFeaturesInArea order.  On the device
 // path q.e is the pinned copy-out buffer of the context, read in place (valid until the context's next call).
 //   device path (default): ONE pinned staging copy in, grid build + one wave per query on the device, ONE copy out;
-//   host path (ORBM_WINDOW=host, or a window longer than `cap`): FrameGrid::area on the host + k_hamming_lists.
+//   host path (ORBM_VAR_WINDOW = 1, or a window longer than `cap`): FrameGrid::area on the host + k_hamming_lists.
 
 static int window_candidates(orbm_ctx *c, bool strict, const float *sigma2, int n_sigma, int cap, const uint8_t *q_desc,
                              const float *q_xy, const float *q_radius, const int32_t *q_min, const int32_t *q_max,
@@ -1916,12 +1919,9 @@ static int projection_device(orbm_ctx *c, int mode, float nn_ratio, int check_or
                            d_cell_items, grid_cols, grid_rows, d_q_desc, d_q_xy, d_q_radius, d_lo, d_hi, d_q_ok, nq, 0, nullptr,
                            (int)std::min(pool_cap, (size_t)INT_MAX), d_counts, d_pool, d_total, d_offs);
     }
-    static const bool configured = [] { // once per process, thread-safe (the matcher entry points are re-entrant)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_projection_resolve<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_projection_resolve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        return true;
-    }();
-    (void)configured;
+    // once per device, thread-safe (the matcher entry points are re-entrant)
+    M_TRY(orbx_lds_opt_in(reinterpret_cast<const void *>(k_projection_resolve<0>), 150 * 1024));
+    M_TRY(orbx_lds_opt_in(reinterpret_cast<const void *>(k_projection_resolve<1>), 150 * 1024));
     if (mode == 0)
         hipLaunchKernelGGL(k_projection_resolve<0>, dim3(1), dim3(PR_T), lds, s, d_counts, d_offs, d_pool, (int)std::min(pool_cap, (size_t)INT_MAX),
                            d_total, nq, n2, (const orbx_kp *)d_kps2, d_q_angle, nn_ratio, check_orientation, d_frame_mp, d_result);

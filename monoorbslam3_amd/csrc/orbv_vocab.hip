@@ -23,6 +23,7 @@
 #include "orb_math.h"
 
 int orbx_set_error(int code, const std::string &msg);
+hipError_t orbx_lds_opt_in(const void *kernel, size_t bytes); // orbx_api.hip: dynamic LDS above 64 KB, per kernel and per device
 
 #define V_TRY(expr)                                                                                                    \
     do {                                                                                                               \
@@ -55,7 +56,6 @@ struct orbv_ctx {
     void *h_desc = nullptr, *h_bow_ids = nullptr, *h_bow_vals = nullptr, *h_fv_nodes = nullptr, *h_fv_off = nullptr,
          *h_fv_idx = nullptr, *h_counts = nullptr;
     size_t h_cap = 0;
-    bool lds_attr_set = false;
 };
 
 __device__ __forceinline__ int ham256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1)
@@ -486,11 +486,8 @@ extern "C" int orbv_transform_device(orbv_t *c, int n_frames, const uint8_t *d_d
     int p_max = 256;
     while (p_max < std::min(cap, ORBV_MAX_FEATURES)) p_max <<= 1;
     const size_t lds = (size_t)p_max * 16;
-    if (!c->lds_attr_set) { // more than 64 KB of dynamic LDS has to be requested once per device
-        V_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_voc_group), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  ORBV_MAX_FEATURES * 16));
-        c->lds_attr_set = true;
-    }
+    // more than 64 KB of dynamic LDS has to be requested once per device
+    V_TRY(orbx_lds_opt_in(reinterpret_cast<const void *>(k_voc_group), (size_t)ORBV_MAX_FEATURES * 16));
     hipLaunchKernelGGL(k_voc_group, dim3(n_frames), dim3(256), lds, s, c->dev, d_n, cap, p_max, c->s_word, c->s_node, c->s_w,
                        d_bow_ids, d_bow_vals, d_n_words, d_fv_nodes, d_fv_off, d_fv_idx, d_n_fv);
     V_TRY(hipGetLastError());

@@ -10,6 +10,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
 #include <chrono>
 #include <vector>
@@ -27,6 +29,21 @@ int orbx_set_error(int code, const std::string &msg) { return fail(code, msg); }
         if (e_ != hipSuccess)                                                                 \
             return fail(ORBX_E_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+hipError_t orbx_lds_opt_in(const void *kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> configured;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu); // read, set and store as one step: a smaller size can never overwrite a larger one
+    size_t &have = configured[std::make_pair(kernel, dev)];
+    if (bytes <= have) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 
 struct orbx_ctx {
     orbx_cfg cfg;
@@ -49,19 +66,21 @@ struct orbx_ctx {
     OrbxTap *d_xtap[ORBX_MAX_LEVELS], *d_ytap[ORBX_MAX_LEVELS];
     bool resize2_ok[ORBX_MAX_LEVELS]; // [l]: levels l and l + 1 can come out of one launch (k_resize2's patch fits)
     bool resize_lds_ok[ORBX_MAX_LEVELS]; // [l]: level l can be made by k_resize_lds (its source tiles fit)
-    int resize_lds;                   // ORBX_RESIZE_LDS: 0 = never, 1 = resident batches (default), 2 = always
-    int resize2;                      // ORBX_RESIZE2: 0 = never two levels per launch, 1 = calls with few frames (default), 2 = always
+    int resize_lds;                   // ORBX_VAR_RESIZE_LDS: 0 = never, 1 = resident batches (default), 2 = always
+    int resize2;                      // ORBX_VAR_RESIZE2: 0 = never two levels per launch, 1 = calls with few frames (default), 2 = always
     int *d_umax, *d_taps;
     hipEvent_t ev_after_fast; bool after_fast_valid; // recorded behind the FAST launches of every call (orbx_stream_wait_fast)
     hipEvent_t ev_fast_t[4]; int fast_t_n; // timing mode 2: events around the (up to two) FAST launches of a step
     uint16_t *d_fast_cells; int n_fast_cells;
     uint16_t *d_fast_strips; int n_fast_strips, n_fast_strips0; // strips of all levels / of level 0
-    int fast_variant;                                           // 2 = strips (default), 1 = one wave per cell
+    int fast_variant;                                           // ORBX_VAR_FAST: 0 = by call size (default), 1 = one wave per cell, 2 = strips
+    int zero_copy;                                              // ORBX_VAR_ZERO_COPY
+    int desc_variant;                                           // ORBX_VAR_DESC: 0 = by call size, 1 = blur pass + k_orient_desc, 2 = k_blur_desc (fused)
     uint16_t *d_blur_tiles; int n_blur_tiles;
     // the Gaussian on the matrix pipe: strip list, band tables, per-level record; levels [0, blur_mfma_levels)
     uint16_t *d_blur_strips; uint8_t *d_band_h, *d_band_v;
     BlurMfmaLevels blur_tab; int blur_strips_before[ORBX_MAX_LEVELS + 1]; int blur_mfma_levels;
-    int blur_mfma;                                              // ORBX_BLUR=valu switches it off
+    int blur_mfma;                                              // ORBX_VAR_BLUR: 1 = by call size (default), 0 = VALU kernels, 2 = matrix pipe for any batch
     uint8_t *d_l0_stage; size_t l0_stage_fs;
     int *d_slot_level;                                          // level of every key-point slot of the current geometry
     // host-API output staging, one device block: [counts, 256 B aligned][key points][descriptors]; `h_out_block` is its
@@ -310,10 +329,9 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
         c->h_out_dev = nullptr;
         if (c->out_block_bytes <= (size_t)4 << 20) {
             HIP_TRY(hipHostMalloc((void **)&c->h_out_block, c->out_block_bytes, hipHostMallocMapped));
-            // the descriptor kernel writes a small call's records straight into this block (no copy back); ORBX_ZERO_COPY=0
-            // keeps them in HBM and copies
-            const char *z = getenv("ORBX_ZERO_COPY");
-            if (!(z && atoi(z) == 0)) HIP_TRY(hipHostGetDevicePointer((void **)&c->h_out_dev, c->h_out_block, 0));
+            // the descriptor kernel writes a small call's records straight into this block (no copy back);
+            // ORBX_VAR_ZERO_COPY = 0 keeps them in HBM and copies
+            HIP_TRY(hipHostGetDevicePointer((void **)&c->h_out_dev, c->h_out_block, 0));
         }
         c->alloc_out_cap = cap;
     }
@@ -437,33 +455,20 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
             hipEventCreateWithFlags(&c->ev_start[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_fast0[i], hipEventDisableTiming) != hipSuccess)
             return cleanup(fail(ORBX_E_NO_DEVICE, "side-stream creation failed"));
-    {
-        const char *e = getenv("ORBX_SIDE_BLUR");
-        c->side_blur = e ? atoi(e) : 1;
-        const char *f = getenv("ORBX_EARLY_FAST");
-        c->early_fast = f ? atoi(f) : -1; // -1: level 0's FAST beside the pyramid unless the pyramid is k_resize_lds's (see enqueue)
-        const char *sp = getenv("ORBX_SPLIT_LEVEL0");
-        c->split_level0 = sp ? atoi(sp) : 1;
-        const char *fv = getenv("ORBX_FAST_VARIANT");
-        c->fast_variant = fv ? atoi(fv) : 2;
-        const char *bl = getenv("ORBX_BLUR");
-        c->blur_mfma = bl ? (strcmp(bl, "valu") == 0 ? 0 : strcmp(bl, "mfma") == 0 ? 2 : 1) : 1;
-    }
-    {
-        const char *e = getenv("ORBX_RESIZE2"); // 0: one level per launch (k_resize only), the parity twin of k_resize2
-        c->resize2 = e ? atoi(e) : 1;
-    }
-    {
-        const char *e = getenv("ORBX_RESIZE_LDS"); // 0: k_resize for every call, the parity twin of k_resize_lds
-        c->resize_lds = e ? atoi(e) : 1;
-    }
-    {
-        const char *e = getenv("ORBX_STREAMS");
-        // Default 1: with the blur already on a side stream, splitting the batch into frame ranges on more streams loses
-        // (tools/overlap_sweep.sh: 103.6 k frames/s with 1, 95.7 k with 2, 94.8 k with 4 at the runtime's default of four
-        // hardware queues; more streams than queues alias and serialise).  The knob stays for experiments.
-        c->n_sub = e ? std::min(std::max(atoi(e), 1), 8) : 1;
-    }
+    // kernel-choice switches: defaults here, orbx_set_variant() changes them per handle (include/orbx.h)
+    c->side_blur = 1;      // the blur on a side stream next to FAST
+    c->early_fast = -1;    // level 0's FAST beside the pyramid unless the pyramid is k_resize_lds's (see enqueue)
+    c->split_level0 = 1;
+    c->fast_variant = 0;   // strips for batches, one wave per cell for a few frames
+    c->blur_mfma = 1;      // matrix pipe for batches and levels that are large enough
+    c->resize2 = 1;        // two levels per launch for calls with a few frames
+    c->resize_lds = 1;     // source tile through LDS for resident batches
+    // Sub-batch streams, default 1: with the blur already on a side stream, splitting the batch into frame ranges on more
+    // streams loses (tools/overlap_sweep.sh: 103.6 k frames/s with 1, 95.7 k with 2, 94.8 k with 4 at the runtime's default of
+    // four hardware queues; more streams than queues alias and serialise).  The knob stays for experiments.
+    c->n_sub = 1;
+    c->zero_copy = 1;
+    c->desc_variant = 0;
     if (hipMalloc((void **)&c->d_levels, sizeof(OrbxLevels)) != hipSuccess ||
         hipMalloc((void **)&c->d_umax, sizeof(int) * 16) != hipSuccess ||
         hipMalloc((void **)&c->d_taps, sizeof(int) * 8) != hipSuccess)
@@ -481,13 +486,20 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
 
 extern "C" int orbx_create(const orbx_cfg *cfg, orbx_t **out) { return create_common(cfg, nullptr, out); }
 
+
 extern "C" int orbx_create_requota(const orbx_t *other, int n_features, orbx_t **out)
 {
     // reference ORBExtractor.cpp:477-493: same pyramid and thresholds, new quotas
     if (!other) return fail(ORBX_E_ARG, "null argument");
     orbx_cfg cfg = other->cfg;
     cfg.n_features = n_features;
-    return create_common(&cfg, nullptr, out);
+    int rc = create_common(&cfg, nullptr, out);
+    if (rc) return rc;
+    for (int which = 0; which < ORBX_N_VARIANTS; ++which) { // the twin keeps the kernel choices of the handle it was made from
+        int v = 0;
+        if (orbx_get_variant(other, which, &v) == ORBX_OK) (void)orbx_set_variant(*out, which, v);
+    }
+    return ORBX_OK;
 }
 
 extern "C" void orbx_destroy(orbx_t *c)
@@ -607,7 +619,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         const uint8_t *sp; size_t sfs; int spitch;
         raw(l - 1, &sp, &sfs, &spitch);
         // (small calls only: per 512 frames the pyramid takes 0.71 ms this way against 0.47 -- a workgroup's two phases run one
-        // after the other -- while a single 1242x375 frame is back 20 us sooner, 157 -> 138 us; ORBX_RESIZE2=2 forces it)
+        // after the other -- while a single 1242x375 frame is back 20 us sooner, 157 -> 138 us; ORBX_VAR_RESIZE2 = 2 forces it)
         if ((c->resize2 == 2 || (c->resize2 == 1 && n_frames < 24)) && l + 1 < L && c->resize2_ok[l]) {
             orbx_launch_resize2(st, sp, sfs, spitch, LV.lv[l - 1].w, LV.lv[l - 1].h, b.img_arena + LV.lv[l].raw_off, b.img_frame_stride,
                                 LV.lv[l].pitch, LV.lv[l].w, LV.lv[l].h, c->d_xtap[l], c->d_ytap[l], b.img_arena + LV.lv[l + 1].raw_off,
@@ -626,11 +638,11 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         return l;
     };
     const bool side_ok = !t && c->side_blur && slot >= 0;
-    // FAST work units (strips of cells, or single cells for ORBX_FAST_VARIANT=1); both lists are level-major
+    // FAST work units (strips of cells, or single cells); both lists are level-major
     // Strips need a few thousand waves in flight to pay (two cells per wave, a long rolling pipeline); a call with a
     // handful of frames is bounded by the longest wave instead, where one short wave per cell finishes sooner
-    // (single 1242x375 frame: 31 us against 50; 16 frames: 63 against 69; 32 frames: 110 against 97).  Same candidates either way (tests).  ORBX_FAST_VARIANT=1 / 3 force one.
-    const bool strips = c->fast_variant == 3 || (c->fast_variant != 1 && n_frames >= 24);
+    // (single 1242x375 frame: 31 us against 50; 16 frames: 63 against 69; 32 frames: 110 against 97).  Same candidates either way (tests).  ORBX_VAR_FAST = 1 / 2 force one.
+    const bool strips = c->fast_variant == 2 || (c->fast_variant == 0 && n_frames >= 24);
     const uint16_t *d_units = strips ? c->d_fast_strips : c->d_fast_cells;
     const int n_units = strips ? c->n_fast_strips : c->n_fast_cells;
     const int n_cells0 = strips ? c->n_fast_strips0 : LV.lv[0].n_cols * LV.lv[0].n_rows;
@@ -646,7 +658,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         ++fast_launch_no;
     };
     // 7x7 Gaussian of levels [lb, le): on the matrix pipe for the levels that are large enough when the call is a batch
-    // (ORBX_BLUR=mfma forces it for any batch, =valu switches it off), the VALU kernels for the rest
+    // (ORBX_VAR_BLUR = 2 forces it for any batch, 0 switches it off), the VALU kernels for the rest
     auto launch_blur = [&](hipStream_t st, int lb, int le) {
         const int lm = (c->blur_mfma == 2 || (c->blur_mfma == 1 && n_frames >= 8)) ? std::min(c->blur_mfma_levels, le) : 0;
         if (lm > lb)
@@ -678,7 +690,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         // side stream as soon as level G-1 exists, beside the resizes -- and then the FAST and quadtree -- of the small
         // levels.  (A stream of its own for levels 1 .. G-1 was measured: with a fourth stream the call takes 200 us, not
         // 160 -- the runtime maps streams onto four hardware queues.)
-        const int G = std::min(std::max(c->split_level0, 1), L - 1); // first level of the main chain's FAST / quadtree (ORBX_SPLIT_LEVEL0, default 1: level 0 alone; 4 is 3 us better at 1242x375 and 17 us worse at 1920x1080)
+        const int G = std::min(std::max(c->split_level0, 1), L - 1); // first level of the main chain's FAST / quadtree (ORBX_VAR_SPLIT_LEVEL0, default 1: level 0 alone; 4 is 3 us better at 1242x375 and 17 us worse at 1920x1080)
         int cells_before[ORBX_MAX_LEVELS + 1];
         cells_before[0] = 0;
         for (int l = 0; l < L; ++l) cells_before[l + 1] = cells_before[l] + LV.lv[l].n_cols * LV.lv[l].n_rows;
@@ -731,9 +743,11 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         launch_fast(s, d_units, n_units);
     }
     if (t) HIP_TRY(hipEventRecord(c->ev[2], s));
-    if (!c->ev_after_fast) HIP_TRY(hipEventCreateWithFlags(&c->ev_after_fast, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(c->ev_after_fast, s)); // what follows (quadtree, orientation) leaves the vector ALUs mostly idle
-    c->after_fast_valid = true;
+    if (slot == 8) { // (a batch split over sub-streams records the event once, behind the join of all of them: enqueue_batch)
+        if (!c->ev_after_fast) HIP_TRY(hipEventCreateWithFlags(&c->ev_after_fast, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_after_fast, s)); // what follows (quadtree, orientation) leaves the vector ALUs mostly idle
+        c->after_fast_valid = true;
+    }
     if (side && c->side_blur == 2) { int rc = fork_blur(); if (rc) return rc; } // next to the quadtree and orientation
     if (!side)
         launch_blur(s, 0, L);
@@ -765,6 +779,11 @@ static int enqueue_batch(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t
         HIP_TRY(hipEventRecord(c->ev_join[i], c->sub[i]));
         HIP_TRY(hipStreamWaitEvent(s, c->ev_join[i], 0));
     }
+    // orbx_stream_wait_fast must cover EVERY frame range: with the batch split, the event sits behind the join of all
+    // sub-streams (conservative: the whole extraction, not only its FAST stages)
+    if (!c->ev_after_fast) HIP_TRY(hipEventCreateWithFlags(&c->ev_after_fast, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_after_fast, s));
+    c->after_fast_valid = true;
     return ORBX_OK;
 }
 
@@ -846,7 +865,7 @@ extern "C" int orbx_extract_batch(orbx_t *c, const uint8_t *imgs, int n_frames, 
     };
     // (Replaying the call as one captured hipGraph -- kernels on three streams plus the record copy -- was measured and is
     // not used: 295 us per 1242x375 frame against 218 us for the eager launches, ROCm 7.2.)
-    if (c->h_out_dev) { // the last kernel writes the records into the pinned block itself
+    if (c->h_out_dev && c->zero_copy) { // the last kernel writes the records into the pinned block itself
         rc = enqueue_batch(c, s, c->d_l0_stage, l0_fs, l0_pitch, n_frames, reinterpret_cast<orbx_kp *>(c->h_out_dev + c->out_kp_off),
                            c->h_out_dev + c->out_desc_off, scap, reinterpret_cast<int32_t *>(c->h_out_dev), true);
         if (rc) return rc;
@@ -1024,6 +1043,44 @@ extern "C" int orbx_stage_times_ms(orbx_t *c, float *ms)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(c->ev[ORBX_N_STAGES]));
     for (int i = 0; i < ORBX_N_STAGES; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    return ORBX_OK;
+}
+
+static int *variant_field(orbx_ctx *c, int which, int *lo, int *hi)
+{
+    switch (which) {
+    case ORBX_VAR_FAST: *lo = 0; *hi = 2; return &c->fast_variant;
+    case ORBX_VAR_BLUR: *lo = 0; *hi = 2; return &c->blur_mfma;
+    case ORBX_VAR_RESIZE_LDS: *lo = 0; *hi = 2; return &c->resize_lds;
+    case ORBX_VAR_RESIZE2: *lo = 0; *hi = 2; return &c->resize2;
+    case ORBX_VAR_SIDE_BLUR: *lo = 0; *hi = 3; return &c->side_blur;
+    case ORBX_VAR_EARLY_FAST: *lo = -1; *hi = 2; return &c->early_fast;
+    case ORBX_VAR_SPLIT_LEVEL0: *lo = 0; *hi = ORBX_MAX_LEVELS; return &c->split_level0;
+    case ORBX_VAR_STREAMS: *lo = 1; *hi = 8; return &c->n_sub;
+    case ORBX_VAR_ZERO_COPY: *lo = 0; *hi = 1; return &c->zero_copy;
+    case ORBX_VAR_DESC: *lo = 0; *hi = 2; return &c->desc_variant;
+    default: return nullptr;
+    }
+}
+
+extern "C" int orbx_set_variant(orbx_t *c, int which, int value)
+{
+    if (!c) return fail(ORBX_E_ARG, "null handle");
+    int lo, hi;
+    int *f = variant_field(c, which, &lo, &hi);
+    if (!f) return fail(ORBX_E_ARG, "unknown variant switch");
+    if (value < lo || value > hi) return fail(ORBX_E_ARG, "variant value out of range");
+    *f = value;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_get_variant(const orbx_t *c, int which, int *value)
+{
+    if (!c || !value) return fail(ORBX_E_ARG, "null argument");
+    int lo, hi;
+    int *f = variant_field(const_cast<orbx_ctx *>(c), which, &lo, &hi);
+    if (!f) return fail(ORBX_E_ARG, "unknown variant switch");
+    *value = *f;
     return ORBX_OK;
 }
 

@@ -18,6 +18,12 @@
 #define ORBX_OCT_THREADS_BATCH 256 // ... and of a resident batch (orbx_octree.h)
 #endif
 
+// More than 64 KB of dynamic LDS has to be requested per kernel AND per device (the attribute belongs to the device's code
+// object).  orbx_lds_opt_in keeps the largest size configured so far per (kernel, device of the calling thread) under a mutex,
+// raises it when `bytes` is larger, and returns the runtime's answer -- a handle on a second GPU of the process gets its
+// own opt-in, and a failed one is reported instead of being found out by a launch error later.
+hipError_t orbx_lds_opt_in(const void *kernel, size_t bytes);
+
 // Geometry of one pyramid level and where its buffers live inside the per-frame arenas.
 struct OrbxLevel {
     int w, h;           // level size

@@ -1664,12 +1664,8 @@ void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLev
     // a resident batch has more workgroups than the chip holds at once: narrower workgroups, more of them per CU
     const bool batch = (size_t)n_frames * (size_t)levels.n_levels > 512;
     if (lds_bytes <= 160 * 1024 - 256 && small_nodes) {
-        static std::atomic<size_t> configured[2];
         const void *fn = batch ? reinterpret_cast<const void *>(oct_batch::k_octree_lds) : reinterpret_cast<const void *>(oct_wide::k_octree_lds);
-        if (lds_bytes > configured[batch].load()) { // (idempotent: two threads racing here set the same or a larger value)
-            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            configured[batch].store(lds_bytes);
-        }
+        (void)orbx_lds_opt_in(fn, lds_bytes); // per device; a refusal shows as the launch error the caller checks
         if (batch)
             hipLaunchKernelGGL(oct_batch::k_octree_lds, grid, dim3(ORBX_OCT_THREADS_BATCH), lds_bytes, s, d_levels, b, level_begin);
         else
@@ -1840,7 +1836,7 @@ struct DescLv { // what k_orient_desc needs of one level: 32 bytes = ONE scalar 
     unsigned long long blur_off, pad2;
 };
 struct DescTab { int n_levels, kcap_total, pad[2]; DescLv lv[ORBX_MAX_LEVELS]; };
-// ROUNDS > 1 (ORBX_DESC_ROUNDS=2|4, an experiment that lost): a wave takes ROUNDS consecutive pairs of key points and, while it
+// ROUNDS > 1 (an experiment that lost, no longer instantiated): a wave takes ROUNDS consecutive pairs of key points and, while it
 // samples pair i from LDS, has the patch loads of pair i + 1 in flight, to hide the staging's L2 round trip inside the wave --
 // the kernel issues VALU in only a tenth of its wave cycles.  Measured per 512 frames: 1.19 ms (2 rounds) and 1.50 ms (4)
 // against 0.62 for one round: every round's key-point records come through a chain of dependent scalar loads, and scalar
@@ -2020,14 +2016,329 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
         dt.lv[l].pad = 0; dt.lv[l].pad2 = 0;
         dt.lv[l].blur_off = in ? (unsigned long long)levels.lv[l].blur_off : 0ull;
     }
-    static const int rounds_env = [] { const char *e = getenv("ORBX_DESC_ROUNDS"); return e ? atoi(e) : 0; }();
-    const int rounds = rounds_env ? rounds_env : 1;
-    const int per_wg = 4 * DP_K * (rounds >= 4 ? 4 : rounds >= 2 ? 2 : 1);
+    const int per_wg = 4 * DP_K; // (the instantiations with 2 / 4 rounds per wave lost -- see the kernel -- and are not built)
     const int pf_d = (levels.kcap_total + per_wg - 1) / per_wg;
-    if (rounds >= 4)
-        hipLaunchKernelGGL(k_orient_desc<4>, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, dt, b, out_kp, out_desc, cap, out_n, pf_d, n_frames);
-    else if (rounds >= 2)
-        hipLaunchKernelGGL(k_orient_desc<2>, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, dt, b, out_kp, out_desc, cap, out_n, pf_d, n_frames);
-    else
         hipLaunchKernelGGL(k_orient_desc<1>, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, dt, b, out_kp, out_desc, cap, out_n, pf_d, n_frames);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_blur_desc: the 7x7 Gaussian and the rBRIEF descriptors in ONE pass over the raw level.
+//
+// The reference blurs a copy of every level only to sample descriptors from it (ORBExtractor.cpp:527-532: the blurred Mat
+// has no other reader).  As two kernels that is a full extra pass -- the blurred pyramid written to HBM and read back, one
+// 37 x 64-byte patch per key point.  Here a workgroup walks DOWN a block of BD_COLS blurred columns the way k_blur_mfma does
+// (same matrix products, same band tables for the rows) but keeps the blurred rows in an LDS ring of four 32-row trips
+// instead of storing them: after trip ty the ring holds rows 32 ty - 96 .. 32 ty + 31, and every key point of the block whose
+// window ends inside trip ty (y + 18 <= 32 ty + 31, rows from 32 ty - 36 on) is sampled from the ring right there.  Nothing
+// blurred ever reaches memory, no patch is staged, and the raw level is read once (plus the 36 / 128 column overlap of the
+// blocks: a block serves the key points of its middle BD_CW = 92 columns).  Key points come bucketed by (block, trip) from
+// k_desc_bins, one 32-byte record each (position, output slot, angle, cos, sin, response) through the scalar cache.
+// Same arithmetic as k_blur_mfma + k_orient_desc, bit for bit (tests: both paths against the oracle, and against each other).
+// ---------------------------------------------------------------------------------------------
+#define BD_WAVES BM_WAVES
+#define BD_COLS BM_COLS                  // blurred columns of a workgroup
+#define BD_HALO 18                       // a rotated pattern point lies within +-18 px of its key point (ORBX_EDGE - 1)
+#define BD_CW (BD_COLS - 2 * BD_HALO)    // key-point columns a workgroup serves
+#define BD_RING 128                      // blurred rows held in LDS: four trips
+#define BD_RP (BD_COLS + 4)              // ring pitch (an odd number of dwords: the 32 rows of a tile column land in different banks)
+static_assert(BD_RING == 128 && BD_HALO + 1 == ORBX_EDGE, "ring rows are addressed with & 127; the halo is the descriptor's reach");
+struct __attribute__((aligned(4))) BdBlock { uint16_t level, bi; };
+struct __attribute__((aligned(32))) BdItem { // one key point as k_blur_desc takes it: 32 bytes = one scalar load
+    uint32_t xy;      // x | y << 16, level coordinates
+    int32_t out_idx;  // record index inside the frame's output (-1: beyond the caller's capacity)
+    float angle, cs, sn, response;
+    int32_t pad[2];
+};
+// first blurred column of block bi, the block of a key-point column, the trip that completes a key point's window
+__host__ __device__ __forceinline__ int bd_first_col(int bi) { return bi * BD_CW; }
+__host__ __device__ __forceinline__ int bd_block_of(int x) { return (x - BD_HALO) / BD_CW; }
+__host__ __device__ __forceinline__ int bd_trip_of(int y) { return (y + BD_HALO) >> 5; }
+
+// Buckets the selected key points of one (frame, level) by (block, trip) -- a counting sort in LDS -- and writes their item
+// records; also the frame's total count (what k_orient_desc's first workgroup does on the two-kernel path).
+__global__ __launch_bounds__(256) void k_desc_bins(const OrbxLevels *__restrict__ levels, BdLevels lv, OrbxBuffers b,
+                                                   int *__restrict__ bk_start, int bk_stride, BdItem *__restrict__ items, int cap,
+                                                   int32_t *__restrict__ out_n)
+{
+    extern __shared__ int s_bins[]; // [nb + 1] starts, [nb] cursors
+    __shared__ int s_part[256];
+    const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const int kc = levels->kcap_total, L = levels->n_levels;
+    const int *cnts = b.sel_count + frame * ORBX_MAX_LEVELS;
+    if (level == 0 && tid == 0) {
+        int tot = 0;
+        for (int l = 0; l < L; ++l) tot += cnts[l];
+        out_n[frame] = tot;
+    }
+    const int n_ty = lv.n_ty[level], nb = lv.n_bx[level] * n_ty, kp_off = levels->lv[level].kp_off;
+    const int n = min(cnts[level], levels->lv[level].kcap);
+    int *start = s_bins, *cursor = s_bins + nb + 1;
+    for (int i = tid; i < nb; i += 256) cursor[i] = 0;
+    __syncthreads();
+    const uint2 *sel = b.sel + (size_t)frame * kc + kp_off;
+    for (int i = tid; i < n; i += 256) {
+        const uint32_t xy = sel[i].x;
+        atomicAdd(&cursor[bd_block_of((int)(xy & 0xFFFF)) * n_ty + bd_trip_of((int)(xy >> 16))], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the nb counts: a contiguous run per thread, then the 256 run totals
+    const int per = (nb + 255) / 256;
+    int s = 0;
+    for (int k = 0; k < per; ++k) { const int i = tid * per + k; if (i < nb) s += cursor[i]; }
+    s_part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int base = s_part[tid] - s;
+    for (int k = 0; k < per; ++k) {
+        const int i = tid * per + k;
+        if (i < nb) { const int c = cursor[i]; start[i] = base; base += c; }
+    }
+    __syncthreads();
+    int *gs = bk_start + (size_t)frame * bk_stride + lv.bucket_base[level];
+    for (int i = tid; i < nb; i += 256) { gs[i] = kp_off + start[i]; cursor[i] = start[i]; }
+    if (tid == 0) gs[nb] = kp_off + n;
+    __syncthreads();
+    const int before = b.sel_prefix[frame * ORBX_MAX_LEVELS + level];
+    for (int i = tid; i < n; i += 256) {
+        const uint2 rec = sel[i];
+        const float4 ang = b.kp_ang[(size_t)frame * kc + kp_off + i];
+        const int pos = atomicAdd(&cursor[bd_block_of((int)(rec.x & 0xFFFF)) * n_ty + bd_trip_of((int)(rec.x >> 16))], 1);
+        BdItem it;
+        it.xy = rec.x; it.out_idx = before + i < cap ? before + i : -1;
+        it.angle = ang.x; it.cs = ang.y; it.sn = ang.z; it.response = (float)rec.y; it.pad[0] = it.pad[1] = 0;
+        items[(size_t)frame * kc + kp_off + pos] = it;
+    }
+}
+
+template <int K_SUM>
+__global__ __launch_bounds__(BM_T) void k_blur_desc(FastSrc src, BdLevels lv, const BdBlock *__restrict__ blocks,
+                                                   const uint4 *__restrict__ band_h, const uint4 *__restrict__ band_v,
+                                                   const int *__restrict__ bk_start, int bk_stride, const BdItem *__restrict__ items,
+                                                   int kcap_total, orbx_kp *__restrict__ out_kp, uint8_t *__restrict__ out_desc, int cap,
+                                                   int n_blocks, int n_frames)
+{
+    constexpr int hbias = 128 * K_SUM - 32768;
+    constexpr uint32_t vbias = 128u * K_SUM * 257u + 32768u;
+    constexpr bool clamp255 = K_SUM != 256;
+    __shared__ __align__(16) uint8_t s_src[2][32 * BM_SRC_P];
+    __shared__ __align__(16) uint8_t s_ring[BD_RING * BD_RP];
+    int frame, bid;
+    if (!xcd_remap(n_blocks, n_frames, &frame, &bid)) return;
+    const BdBlock bk = blocks[bid];
+    const int level = bk.level, tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = lv.w[level], h = lv.h[level], pitch = src.pitch[level], n_ty = lv.n_ty[level];
+    const int limit = level == 0 ? w : pitch;
+    const int B0 = bd_first_col((int)bk.bi);
+    const int xo = min(max(B0 - 16, 0), limit - BM_SRC_W);
+    const int cw = min(max(B0 + 32 * wave - 16, xo), xo + BM_SRC_W - 64); // this wave's 64-column source window (two K-steps)
+    (void)w;
+    const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level];
+    const uint4 *bh = band_h + lv.bh_off[level] + (size_t)((int)bk.bi * BD_WAVES + wave) * 128;
+    const bl_v4i bh0 = __builtin_bit_cast(bl_v4i, bh[lane]), bh1 = __builtin_bit_cast(bl_v4i, bh[64 + lane]);
+    const int a_off = n * BM_SRC_P + (cw - xo) + 16 * hh;
+    // this lane's four sampling pairs (the same for every key point)
+    float px0[4], py0[4], px1[4], py1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t pat = reinterpret_cast<const uint32_t *>(c_pattern)[lane + 64 * j];
+        px0[j] = (float)(int8_t)(pat & 255); py0[j] = (float)(int8_t)((pat >> 8) & 255);
+        px1[j] = (float)(int8_t)((pat >> 16) & 255); py1[j] = (float)(int8_t)(pat >> 24);
+    }
+    const float lscale = lv.scale[level];
+    const int *bks = bk_start + (size_t)frame * bk_stride + lv.bucket_base[level] + (int)bk.bi * n_ty;
+    const BdItem *its = items + (size_t)frame * kcap_total;
+
+    const int c0r = tid / BM_CH, c0c = tid - BM_CH * c0r, c1r = (BM_T + tid) / BM_CH, c1c = (BM_T + tid) - BM_CH * c1r;
+    const bool second = tid < 32 * BM_CH - BM_T;
+    auto g_load = [&](int T, uint4 *u0, uint4 *u1) {
+        const int r0 = min(max(32 * T - 3 + c0r, 0), h - 1), r1 = min(max(32 * T - 3 + min(c1r, 31), 0), h - 1);
+        const UnalignedU4 a = *reinterpret_cast<const UnalignedU4 *>(S + (size_t)r0 * pitch + xo + 16 * c0c);
+        const UnalignedU4 b2 = *reinterpret_cast<const UnalignedU4 *>(S + (size_t)r1 * pitch + xo + 16 * (second ? c1c : 0));
+        *u0 = make_uint4(a.x, a.y, a.z, a.w);
+        *u1 = make_uint4(b2.x, b2.y, b2.z, b2.w);
+    };
+    auto s_store = [&](int buf, const uint4 &u0, const uint4 &u1) {
+        *reinterpret_cast<uint4 *>(&s_src[buf][c0r * BM_SRC_P + 16 * c0c]) = u0;
+        if (second) *reinterpret_cast<uint4 *>(&s_src[buf][c1r * BM_SRC_P + 16 * c1c]) = u1;
+    };
+    auto h_tile = [&](int buf, bl_v4i *hi, bl_v4i *lo) { // as in k_blur_mfma
+        bl_v4i a0 = reinterpret_cast<const UnalignedV4 *>(&s_src[buf][a_off])->v;
+        bl_v4i a1 = reinterpret_cast<const UnalignedV4 *>(&s_src[buf][a_off + 32])->v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a0[k] ^= (int)0x80808080u; a1[k] ^= (int)0x80808080u; }
+        const bl_v16i zero = {};
+        bl_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bh0, zero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bh1, acc, 0, 0, 0);
+        if (hbias) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] += hbias;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t p = (uint32_t)acc[4 * k], q = (uint32_t)acc[4 * k + 1], r2 = (uint32_t)acc[4 * k + 2], t = (uint32_t)acc[4 * k + 3];
+            const uint32_t pq1 = __builtin_amdgcn_perm(q, p, 0x0c0c0501u), rt1 = __builtin_amdgcn_perm(t, r2, 0x0c0c0501u);
+            const uint32_t pq0 = __builtin_amdgcn_perm(q, p, 0x0c0c0400u), rt0 = __builtin_amdgcn_perm(t, r2, 0x0c0c0400u);
+            (*hi)[k] = (int)__builtin_amdgcn_perm(rt1, pq1, 0x05040100u);
+            (*lo)[k] = (int)(__builtin_amdgcn_perm(rt0, pq0, 0x05040100u) ^ 0x80808080u);
+        }
+    };
+    // one key point: 512 rotated samples from the ring, four ballots -> 32 bytes, and its output record (reference :50-97, :537-546)
+    auto describe = [&](const BdItem &it) {
+        if (it.out_idx < 0) return;
+        const int x = (int)(it.xy & 0xFFFF), y = (int)(it.xy >> 16);
+        const float a = it.cs, bb = it.sn;
+        // cvRound through the float adder as in k_orient_desc: bits(v + 1.5 * 2^23) = M + round(v); M's low bits are zero, so
+        // the ring row is (M + dr + y) & 127, and M is taken out of the column once per key point
+        const float MAGIC = 12582912.f;
+        const uint32_t M = 0x4B400000u;
+        uint32_t yv = (uint32_t)y, colbase = (uint32_t)(x - B0) - M;
+        asm("" : "+v"(yv), "+v"(colbase)); // vector registers: a scalar operand halves the issue rate of the adds below
+        u64 bits[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t r0 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px0[j], bb), ORB_FMUL(py0[j], a)), MAGIC));
+            const uint32_t c0 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px0[j], a), ORB_FMUL(py0[j], bb)), MAGIC));
+            const uint32_t r1 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px1[j], bb), ORB_FMUL(py1[j], a)), MAGIC));
+            const uint32_t c1 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px1[j], a), ORB_FMUL(py1[j], bb)), MAGIC));
+            const int t0 = s_ring[((r0 + yv) & (BD_RING - 1)) * BD_RP + c0 + colbase];
+            const int t1 = s_ring[((r1 + yv) & (BD_RING - 1)) * BD_RP + c1 + colbase];
+            bits[j] = __ballot(t0 < t1);
+        }
+        if (lane < 4) {
+            const u64 wd = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+            *reinterpret_cast<u64 *>(out_desc + ((size_t)frame * cap + it.out_idx) * 32 + 8 * lane) = wd;
+        }
+        if (lane == 0) {
+            orbx_kp kp;
+            float fx = (float)x, fy = (float)y;
+            if (level != 0) { fx = ORB_FMUL(fx, lscale); fy = ORB_FMUL(fy, lscale); }
+            kp.x = fx; kp.y = fy; kp.size = lscale; kp.angle = it.angle; kp.response = it.response;
+            kp.octave = level; kp.class_id = -1;
+            out_kp[(size_t)frame * cap + it.out_idx] = kp;
+        }
+    };
+
+    uint4 u0, u1;
+    g_load(0, &u0, &u1);
+    s_store(0, u0, u1);
+    g_load(1, &u0, &u1);
+    s_store(1, u0, u1);
+    g_load(2, &u0, &u1);
+    __syncthreads();
+    bl_v4i hiP, loP, hiN, loN;
+    h_tile(0, &hiP, &loP);
+    __syncthreads();
+    const uint4 *bv = band_v + lv.bv_off[level];
+    for (int ty = 0; ty < n_ty; ++ty, bv += 128) {
+        // this trip's bucket: the wave takes items wave, wave + BD_WAVES, ...; the first record is requested now and used
+        // after the barrier, under the trip's arithmetic
+        const int it_begin = bks[ty] + wave, it_end = bks[ty + 1];
+        BdItem first;
+        first.out_idx = -1;
+        if (it_begin < it_end) first = its[it_begin];
+        const bl_v4i bv0 = __builtin_bit_cast(bl_v4i, bv[lane]), bv1 = __builtin_bit_cast(bl_v4i, bv[64 + lane]);
+        s_store(ty & 1, u0, u1);
+        g_load(ty + 3, &u0, &u1);
+        h_tile((ty + 1) & 1, &hiN, &loN);
+        const bl_v16i zero = {};
+        bl_v16i ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(hiP, bv0, zero, 0, 0, 0);
+        ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(hiN, bv1, ah, 0, 0, 0);
+        bl_v16i al = __builtin_amdgcn_mfma_i32_32x32x32_i8(loP, bv0, zero, 0, 0, 0);
+        al = __builtin_amdgcn_mfma_i32_32x32x32_i8(loN, bv1, al, 0, 0, 0);
+        // blurred rows 32 ty .. 32 ty + 31 take ring rows ((ty & 3) << 5) ..: written by this trip, read by this trip's and the
+        // next trip's key points, overwritten four trips on -- behind two barriers
+        uint8_t *so = &s_ring[((ty & 3) << 5) * BD_RP];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = (uint32_t)(ah[4 * g + k] * 256 + al[4 * g + k]) + vbias;
+                if (clamp255) v[k] = min(v[k], 0x00FFFFFFu);
+            }
+            const uint32_t a = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), b2 = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);
+            *reinterpret_cast<uint32_t *>(&so[n * BD_RP + 32 * wave + 8 * g + 4 * hh]) = __builtin_amdgcn_perm(b2, a, 0x05040100u);
+        }
+        __syncthreads(); // the trip's blurred rows and the source of the next trip are complete
+        if (it_begin < it_end) {
+            describe(first);
+            for (int k = it_begin + BD_WAVES; k < it_end; k += BD_WAVES) describe(its[k]);
+        }
+        hiP = hiN; loP = loN;
+    }
+}
+
+// Block list, H-band tables and bucket layout of k_blur_desc for the levels k_blur_mfma could take (the V bands are shared
+// with it).  Host side of the plan; `taps` as for orbx_build_blur_mfma.
+void orbx_build_blur_desc(const OrbxLevels &levels, const int taps[7], const BlurMfmaLevels &mf, std::vector<uint16_t> &blocks,
+                          std::vector<uint8_t> &band_h, BdLevels &out, int *n_fused_levels, int *bk_stride)
+{
+    blocks.clear(); band_h.clear();
+    memset(&out, 0, sizeof out);
+    const int n_lv = orbx_blur_mfma_levels(levels);
+    int buckets = 0;
+    for (int l = 0; l < n_lv; ++l) {
+        const OrbxLevel &v = levels.lv[l];
+        const int w = v.w, h = v.h, limit = l == 0 ? w : v.pitch;
+        out.w[l] = w; out.h[l] = h; out.n_ty[l] = (h + 31) / 32; out.scale[l] = v.scale;
+        out.bv_off[l] = mf.bv_off[l];
+        out.bh_off[l] = (int)(band_h.size() / 16);
+        // key-point columns are [19, w - 19): the last one decides how many blocks there are
+        const int n_bx = w - ORBX_EDGE - 1 >= ORBX_EDGE ? bd_block_of(w - ORBX_EDGE - 1) + 1 : 0;
+        out.n_bx[l] = n_bx;
+        out.bucket_base[l] = buckets;
+        buckets += n_bx * out.n_ty[l] + 1;
+        for (int bi = 0; bi < n_bx; ++bi) {
+            blocks.push_back((uint16_t)l); blocks.push_back((uint16_t)bi);
+            const int B0 = bd_first_col(bi), xo = std::min(std::max(B0 - 16, 0), limit - BM_SRC_W);
+            for (int k = 0; k < BD_WAVES; ++k) {
+                int B[64][32] = {};
+                const int x0 = B0 + 32 * k, cwin = std::min(std::max(x0 - 16, xo), xo + BM_SRC_W - 64);
+                for (int n = 0; n < 32 && x0 + n < w; ++n)
+                    for (int i = 0; i < 7; ++i) B[reflect101_host(x0 + n + i - 3, w) - cwin][n] += taps[i];
+                for (int s = 0; s < 2; ++s)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 16; ++j) band_h.push_back((uint8_t)(int8_t)B[32 * s + 16 * (lane >> 5) + j][lane & 31]);
+            }
+        }
+    }
+    *n_fused_levels = n_lv;
+    *bk_stride = std::max(buckets, 1);
+}
+
+void orbx_launch_desc_fused(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
+                            const OrbxLevels &levels, const OrbxBuffers &b, const BdLevels &tab, int n_fused_levels, const void *d_blocks,
+                            int n_blocks, const void *d_band_h, const void *d_band_v, int *d_bk_start, int bk_stride, void *d_items,
+                            const int taps[7], orbx_kp *out_kp, uint8_t *out_desc, int cap, int32_t *out_n, int n_frames)
+{
+    if (n_fused_levels <= 0) return;
+    int max_nb = 1;
+    for (int l = 0; l < n_fused_levels; ++l) max_nb = std::max(max_nb, tab.n_bx[l] * tab.n_ty[l]);
+    hipLaunchKernelGGL(k_desc_bins, dim3(n_fused_levels, n_frames), dim3(256), sizeof(int) * (2 * (size_t)max_nb + 1), s, d_levels, tab, b,
+                       d_bk_start, bk_stride, reinterpret_cast<BdItem *>(d_items), cap, out_n);
+    if (n_blocks <= 0) return;
+    FastSrc src;
+    for (int l = 0; l < levels.n_levels; ++l) {
+        src.base[l] = l == 0 ? l0 : b.img_arena + levels.lv[l].raw_off;
+        src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
+        src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
+    }
+    int K = 0;
+    for (int i = 0; i < 7; ++i) K += taps[i];
+    if (K == 256)
+        hipLaunchKernelGGL(k_blur_desc<256>, dim3(orbx_xcd_grid(n_blocks, n_frames)), dim3(BM_T), 0, s, src, tab,
+                           reinterpret_cast<const BdBlock *>(d_blocks), reinterpret_cast<const uint4 *>(d_band_h),
+                           reinterpret_cast<const uint4 *>(d_band_v), d_bk_start, bk_stride, reinterpret_cast<const BdItem *>(d_items),
+                           levels.kcap_total, out_kp, out_desc, cap, n_blocks, n_frames);
+    else
+        hipLaunchKernelGGL(k_blur_desc<257>, dim3(orbx_xcd_grid(n_blocks, n_frames)), dim3(BM_T), 0, s, src, tab,
+                           reinterpret_cast<const BdBlock *>(d_blocks), reinterpret_cast<const uint4 *>(d_band_h),
+                           reinterpret_cast<const uint4 *>(d_band_v), d_bk_start, bk_stride, reinterpret_cast<const BdItem *>(d_items),
+                           levels.kcap_total, out_kp, out_desc, cap, n_blocks, n_frames);
 }

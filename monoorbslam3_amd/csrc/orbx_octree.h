@@ -6,6 +6,9 @@
 #ifndef OCT_NT
 #error "define OCT_NT (threads per workgroup, a multiple of 64, at most 512: the block scans keep 8 wave totals)"
 #endif
+// The block scans below hold one running total per wave in an 8-entry LDS array: a 1024-thread build (-DORBX_OCT_THREADS=1024,
+// tried in round 3) wrote past it and faulted.  Refuse such a build instead of relying on a comment.
+static_assert(OCT_NT % 64 == 0 && OCT_NT >= 64 && OCT_NT <= 512, "quadtree workgroups are whole waves, at most 8 of them (the block scans keep 8 wave totals)");
 
 // ---------------------------------------------------------------------------------------------
 // DistributeOctree, one workgroup per (frame, level).

@@ -16,6 +16,19 @@ from . import _lib
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
 STAGES = ("resize", "fast", "blur", "octree", "orient_desc")
+# kernel-choice switches of include/orbx.h (ORBX_VAR_*): name -> (index, named values)
+VARIANTS = {
+    "fast": (0, {"auto": 0, "cells": 1, "strips": 2}),
+    "blur": (1, {"valu": 0, "auto": 1, "mfma": 2}),
+    "resize_lds": (2, {"never": 0, "auto": 1, "always": 2}),
+    "resize2": (3, {"never": 0, "auto": 1, "always": 2}),
+    "side_blur": (4, {}),
+    "early_fast": (5, {"auto": -1}),
+    "split_level0": (6, {}),
+    "streams": (7, {}),
+    "zero_copy": (8, {}),
+    "desc": (9, {"auto": 0, "separate": 1, "fused": 2}),
+}
 
 
 def _vp(a):
@@ -27,7 +40,7 @@ class ORBExtractor:
     (reference modules/ORB/ORBExtractor.h:29-30)."""
 
     def __init__(self, nFeatures=1000, scaleFactor=1.2, nLevels=8, iniThFast=20, minThFast=10, *, max_width=0,
-                 max_height=0, max_batch=1, blur_variant=0, device=-1, _requota_of=None):
+                 max_height=0, max_batch=1, blur_variant=0, device=-1, variants=None, _requota_of=None):
         self._L = _lib.lib()
         self._h = C.c_void_p()
         if _requota_of is not None:
@@ -49,6 +62,18 @@ class ORBExtractor:
         self.n_levels = n.value
         self.n_features = nFeatures
         self._lsf = lsf.value
+        for k, v in (variants or {}).items():
+            self.set_variant(k, v)
+
+    def set_variant(self, name, value):
+        """orbx_set_variant: pick a kernel / stream layout per handle (see VARIANTS; a value is an int or one of the names)."""
+        idx, names = VARIANTS[name]
+        _lib.check(self._L.orbx_set_variant(self._h, idx, names.get(value, value) if isinstance(value, str) else int(value)))
+
+    def get_variant(self, name):
+        v = C.c_int()
+        _lib.check(self._L.orbx_get_variant(self._h, VARIANTS[name][0], C.byref(v)))
+        return v.value
 
     @classmethod
     def requota(cls, nFeatures, other):

@@ -35,6 +35,7 @@ def _mlib():
         sigs = {
             "orbm_create": (i32, [i32, C.POINTER(vp)]),
             "orbm_destroy": (None, [vp]),
+            "orbm_set_variant": (i32, [vp, i32, i32]),
             "orbm_hamming_matrix": (i32, [vp, vp, i32, vp, i32, vp]),
             "orbm_hamming_matrix_device": (i32, [vp, vp, i32, vp, i32, vp, vp]),
             "orbm_best2_device": (i32, [vp, i32, vp, sz, vp, i32, vp, sz, vp, i32, vp, vp, vp, vp, vp, vp]),
@@ -95,6 +96,12 @@ class MatcherHandle:
         self._L = _mlib()
         self._h = C.c_void_p()
         _lib.check(self._L.orbm_create(device, C.byref(self._h)))
+
+    def set_variant(self, name, value):
+        """orbm_set_variant: "best2" = "fp4" | "i8" | "valu" (dense best / second-best kernel), "window" = "device" | "host"."""
+        which = {"best2": 0, "window": 1}[name]
+        val = {"fp4": 0, "i8": 1, "valu": 2, "device": 0, "host": 1}.get(value, value)
+        _lib.check(self._L.orbm_set_variant(self._h, which, int(val)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -120,14 +120,14 @@ def test_oracle_se3_exp_is_a_rigid_motion():
 @pytest.mark.gpu
 @pytest.mark.parametrize("chol", ["lds", "global"])
 @pytest.mark.parametrize("n_poses,n_points,huber", [(6, 200, True), (6, 200, False), (20, 3000, True), (25, 600, True), (26, 600, True)])
-def test_gpu_lm_matches_oracle(monkeypatch, chol, n_poses, n_points, huber):
+def test_gpu_lm_matches_oracle(chol, n_poses, n_points, huber):
     """Same LM decisions (iteration / trial counts), estimates within 1e-6 relative of the numpy restatement: the two
     differ only in summation order and in the dense Cholesky -- through the LDS-resident solver (the reduced system of up to 23
-    free key frames; 25 poses = 23 free ones is its largest case) and through the global-memory one (ORBBA_CHOL=global, and
+    free key frames; 25 poses = 23 free ones is its largest case) and through the global-memory one (ORBBA_VAR_CHOL = 1, and
     what 26 poses take either way)."""
     from oracle import ba_ref
     from monoorbslam3_amd import ba
-    monkeypatch.setenv("ORBBA_CHOL", chol)  # read per call
+    ba.set_variant("chol", chol)  # read per call
     pr, args = _perturbed(n_poses, n_points, 5)
     delta = ba.HUBER_MONO if huber else 0.0
     ref = ba_ref.lm_optimize(*args, delta, 6)
@@ -143,6 +143,7 @@ def test_gpu_lm_matches_oracle(monkeypatch, chol, n_poses, n_points, huber):
     if n_points == 3000:
         print("BA LM: %d edges, %d iterations / %d solves, %.2f ms on device" %
               (len(pr["edge_pose"]), got["iterations"], got["trials"], got["device_ms"]))
+    ba.set_variant("chol", "lds")
 
 
 @pytest.mark.gpu
@@ -218,13 +219,13 @@ def test_oracle_pose_optimize_recovers_pose_and_flags_outliers():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lds", ["3000", "1000", "0"])
-def test_gpu_pose_optimize_batch_matches_oracle(monkeypatch, lds):
-    """Optimize.cpp:447-540 for a batch of frames: edges staged in LDS (ORBBA_POSE_LDS = capacity in edges; 1000: the two larger
+@pytest.mark.parametrize("lds", [3000, 1000, 0])
+def test_gpu_pose_optimize_batch_matches_oracle(lds):
+    """Optimize.cpp:447-540 for a batch of frames: edges staged in LDS (ORBBA_VAR_POSE_LDS = capacity in edges; 1000: the two larger
     frames of the batch keep reading global memory beside the staged ones; 0: every frame does -- the parity twin)."""
     from oracle import ba_ref
     from monoorbslam3_amd import ba
-    monkeypatch.setenv("ORBBA_POSE_LDS", lds)  # read per call
+    ba.set_variant("pose_lds", lds)  # read per call
     sizes = [300, 1500, 2, 0, 64, 257, 2000, 3]
     cam, R0, t0, off, P, Z, W = _pose_frames(sizes, 17)
     got = ba.pose_optimize_batch(cam, R0, t0, off, P, Z, W)
@@ -244,6 +245,7 @@ def test_gpu_pose_optimize_batch_matches_oracle(monkeypatch, lds):
     big = ba.pose_optimize_batch(cam, R0, t0, off, P, Z, W)
     assert (big["n_inliers"] > 800).all()
     print("poseOptimize: 256 frames x 1000 edges in %.3f ms (%.1f us/frame)" % (big["kernel_ms"], big["kernel_ms"] * 1e3 / 256))
+    ba.set_variant("pose_lds", 3000)
 
 
 def test_oracle_lm_reaches_the_same_minimum_as_scipy():

@@ -13,9 +13,9 @@ from monoorbslam3_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _mk(oracle_mod, n_features, w, h, ini=20, mn=7, n_levels=8, sf=1.2, batch=1):
+def _mk(oracle_mod, n_features, w, h, ini=20, mn=7, n_levels=8, sf=1.2, batch=1, variants=None):
     from monoorbslam3_amd.extractor import ORBExtractor
-    ex = ORBExtractor(n_features, sf, n_levels, ini, mn, max_width=w, max_height=h, max_batch=batch)
+    ex = ORBExtractor(n_features, sf, n_levels, ini, mn, max_width=w, max_height=h, max_batch=batch, variants=variants)
     orc = oracle_mod.Oracle(n_features, sf, n_levels, ini, mn)
     return ex, orc
 
@@ -48,10 +48,10 @@ def _check_frame(ex, orc, img, kps, desc, frame=0, stages=True):
 # 6000 features: per-level quotas too large for the LDS-resident quadtree -> global-scratch kernel
 @pytest.mark.parametrize("w,h,nf", [(1242, 375, 2000), (752, 480, 1000), (640, 200, 500), (1242, 375, 6000),
                                     (1242, 375, 4000)])
-@pytest.mark.parametrize("variant", ["3", "1"])
-def test_single_frame_all_stages(oracle_mod, monkeypatch, w, h, nf, variant):
-    monkeypatch.setenv("ORBX_FAST_VARIANT", variant)  # both FAST kernels: per strip (batches) and per cell (few frames)
-    ex, orc = _mk(oracle_mod, nf, w, h)
+@pytest.mark.parametrize("variant", ["strips", "cells"])
+def test_single_frame_all_stages(oracle_mod, w, h, nf, variant):
+    # both FAST kernels: per strip (batches) and per cell (few frames)
+    ex, orc = _mk(oracle_mod, nf, w, h, variants={"fast": variant})
     img = synth.make_frames(1, w, h, seed=synth.DEFAULT_SEED + w)[0]
     kps, desc = ex(img)
     assert len(kps) > nf // 2
@@ -167,16 +167,15 @@ def test_odd_sizes_and_strides(oracle_mod):
         _check_frame(ex, orc, img, kps, desc, stages=True)
 
 
-@pytest.mark.parametrize("resize2", ["0", "2"])
+@pytest.mark.parametrize("resize2", ["never", "always"])
 @pytest.mark.parametrize("w,h,nf,sf,levels,batch", [(1242, 375, 2000, 1.2, 8, 1), (333, 251, 300, 1.2, 8, 3), (641, 479, 700, 1.1, 9, 2),
                                                     (800, 600, 900, 1.5, 5, 1), (1920, 1080, 2000, 1.2, 8, 1), (405, 607, 500, 1.3, 6, 26)])
-def test_pyramid_two_levels_per_launch(oracle_mod, monkeypatch, resize2, w, h, nf, sf, levels, batch):
-    """ORBExtractor.cpp:559-570 through k_resize2 (levels l+1 and l+2 from one launch, ORBX_RESIZE2=2: forced, also for a
-    batch) and through k_resize alone (=0): every level bit-exact against the oracle either way -- widths that are not
+def test_pyramid_two_levels_per_launch(oracle_mod, resize2, w, h, nf, sf, levels, batch):
+    """ORBExtractor.cpp:559-570 through k_resize2 (levels l+1 and l+2 from one launch, ORBX_VAR_RESIZE2 = 2: forced, also for a
+    batch) and through k_resize alone (= 0): every level bit-exact against the oracle either way -- widths that are not
     multiples of 4, an odd number of levels (the last one on its own), scale factors whose patches are wider (1.5: the
     launch falls back to single levels where a patch would not fit)."""
-    monkeypatch.setenv("ORBX_RESIZE2", resize2)  # read when the extractor is created
-    ex, orc = _mk(oracle_mod, nf, w, h, n_levels=levels, sf=sf, batch=batch)
+    ex, orc = _mk(oracle_mod, nf, w, h, n_levels=levels, sf=sf, batch=batch, variants={"resize2": resize2})
     imgs = synth.make_frames(batch, w, h, seed=w + 7 * h)
     if batch == 1:
         kps, desc = ex(imgs[0])
@@ -187,19 +186,17 @@ def test_pyramid_two_levels_per_launch(oracle_mod, monkeypatch, resize2, w, h, n
             _check_frame(ex, orc, imgs[f], out[f][0], out[f][1], frame=f, stages=True)
 
 
-@pytest.mark.parametrize("resize_lds", ["0", "2"])
+@pytest.mark.parametrize("resize_lds", ["never", "always"])
 @pytest.mark.parametrize("w,h,nf,sf,levels,batch", [(1242, 375, 2000, 1.2, 8, 1), (333, 251, 300, 1.2, 8, 3), (641, 479, 700, 1.1, 9, 2),
                                                     (800, 600, 900, 1.5, 5, 1), (1920, 1080, 2000, 1.2, 8, 1), (405, 607, 500, 1.3, 6, 26),
                                                     (1000, 163, 400, 1.9, 3, 2), (64, 48, 50, 1.2, 2, 1)])
-def test_pyramid_source_tile_through_lds(oracle_mod, monkeypatch, resize_lds, w, h, nf, sf, levels, batch):
+def test_pyramid_source_tile_through_lds(oracle_mod, resize_lds, w, h, nf, sf, levels, batch):
     """ORBExtractor.cpp:559-570 through k_resize_lds (the source tile of a 256 x 32 output tile staged with 16-byte loads,
-    ORBX_RESIZE_LDS=2: forced, also for a single frame; what a resident batch runs by default) and through k_resize alone
-    (=0): every level bit-exact against the oracle either way.  Widths that are not multiples of 16 (the last row of the
+    ORBX_VAR_RESIZE_LDS = 2: forced, also for a single frame; what a resident batch runs by default) and through k_resize alone
+    (= 0): every level bit-exact against the oracle either way.  Widths that are not multiples of 16 (the last row of the
     caller's image ends inside a 16-byte chunk), scale factors up to 1.9 (tiles too wide for the LDS array fall back),
-    levels smaller than one tile.  ORBX_RESIZE2=0 so that the single-level kernels run for these small calls."""
-    monkeypatch.setenv("ORBX_RESIZE_LDS", resize_lds)  # read when the extractor is created
-    monkeypatch.setenv("ORBX_RESIZE2", "0")
-    ex, orc = _mk(oracle_mod, nf, w, h, n_levels=levels, sf=sf, batch=batch)
+    levels smaller than one tile.  ORBX_VAR_RESIZE2 = 0 so that the single-level kernels run for these small calls."""
+    ex, orc = _mk(oracle_mod, nf, w, h, n_levels=levels, sf=sf, batch=batch, variants={"resize_lds": resize_lds, "resize2": "never"})
     imgs = synth.make_frames(batch, w, h, seed=3 * w + 11 * h)
     if batch == 1:
         kps, desc = ex(imgs[0])
@@ -238,14 +235,13 @@ def test_batch_path_with_other_arguments(oracle_mod, nf, sf, levels, ini, mn, w,
 
 @pytest.mark.parametrize("ini,mn,kind", [(5, 2, "noise"), (2, 1, "noise"), (2, 1, "scene"), (3, 3, "noise"), (40, 1, "scene"),
                                          (254, 200, "noise")])
-@pytest.mark.parametrize("variant", ["3", "1"])  # 3 = one wave per strip of cells (batches), 1 = one wave per cell (few frames)
-def test_fast_dense_corners_and_tiny_thresholds(oracle_mod, monkeypatch, ini, mn, kind, variant):
+@pytest.mark.parametrize("variant", ["strips", "cells"])  # one wave per strip of cells (batches) / one wave per cell (few frames)
+def test_fast_dense_corners_and_tiny_thresholds(oracle_mod, ini, mn, kind, variant):
     """The FAST kernel's rare paths: i.i.d. noise at low thresholds makes nearly every pixel a corner (more corners per
     strip than its LDS list holds -> the NMS sweeps the score map), thresholds 0..2 make the 6-bit arc test pass pixels
     in both polarities, thresholds near 255 pass nothing.  Candidates, key points and descriptors stay the oracle's."""
     w, h, nf = 500, 300, 1500
-    monkeypatch.setenv("ORBX_FAST_VARIANT", variant)  # read when the extractor is created
-    ex, orc = _mk(oracle_mod, nf, w, h, ini=ini, mn=mn)
+    ex, orc = _mk(oracle_mod, nf, w, h, ini=ini, mn=mn, variants={"fast": variant})
     if kind == "noise":
         img = np.random.RandomState(ini * 31 + mn).randint(0, 256, (h, w)).astype(np.uint8)
     else:
@@ -268,13 +264,12 @@ def test_blur_tap_variant_and_handle_reuse(oracle_mod):
 
 @pytest.mark.parametrize("w,h", [(1242, 375), (752, 480), (1920, 1080), (331, 77), (161, 40), (640, 9 * 4)])
 @pytest.mark.parametrize("blur_variant", [0, 1])
-def test_gaussian_on_the_matrix_pipe(oracle_mod, monkeypatch, w, h, blur_variant):
+def test_gaussian_on_the_matrix_pipe(oracle_mod, w, h, blur_variant):
     """k_blur_mfma (the batch path's 7x7 Gaussian: banded i8 matrix products) forced for a single frame: every blurred
     level byte-identical to the oracle, for both tap sets (sum 256 and the plain-rounded sum 257 with its clamp), widths
     that are not multiples of the 128-column block or the 32-column tile, and levels too small for it (VALU kernels)."""
     from monoorbslam3_amd.extractor import ORBExtractor
-    monkeypatch.setenv("ORBX_BLUR", "mfma")  # read when the extractor is created
-    ex = ORBExtractor(800, 1.2, 8, 20, 7, blur_variant=blur_variant)
+    ex = ORBExtractor(800, 1.2, 8, 20, 7, blur_variant=blur_variant, variants={"blur": "mfma"})
     orc = oracle_mod.Oracle(800, 1.2, 8, 20, 7, blur_variant=blur_variant)
     img = synth.make_frames(1, w, h, seed=7 * w + h)[0]
     if blur_variant == 1:
@@ -364,22 +359,22 @@ def test_golden_fixtures_through_the_c_abi(oracle_mod):
 
 
 def test_stream_layout_variants_give_identical_results(tmp_path):
-    """The internal stream layouts (ORBX_STREAMS / ORBX_SIDE_BLUR / ORBX_EARLY_FAST, read at handle creation) only change
-    what overlaps with what: every variant must return the default layout's bytes."""
+    """The internal stream layouts (ORBX_VAR_STREAMS / _SIDE_BLUR / _EARLY_FAST / _DESC) only change what overlaps with what
+    and which twin of a kernel runs: every variant must return the default layout's bytes."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "variant.py"
     script.write_text(
-        "import sys, hashlib\n"
+        "import sys, hashlib, json\n"
         "sys.path.insert(0, %r)\n"
         "import torch\n"
         "from monoorbslam3_amd import synth\n"
         "from monoorbslam3_amd.extractor import ORBExtractor\n"
         "B, W, H = 24, 640, 360\n"
         "fr = torch.from_numpy(synth.make_frames(B, W, H, seed=5)).cuda()\n"
-        "ex = ORBExtractor(800, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)\n"
+        "ex = ORBExtractor(800, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, variants=json.loads(sys.argv[1]))\n"
         "cap = ex.max_keypoints(W, H)\n"
         "kp = torch.zeros((B, cap, 28), dtype=torch.uint8, device='cuda')\n"
         "de = torch.zeros((B, cap, 32), dtype=torch.uint8, device='cuda')\n"
@@ -394,12 +389,12 @@ def test_stream_layout_variants_give_identical_results(tmp_path):
         "    h.update(kp[f, :nn[f]].cpu().numpy().tobytes()); h.update(de[f, :nn[f]].cpu().numpy().tobytes())\n"
         "print(int(nn.sum()), h.hexdigest())\n" % root)
     results = {}
-    for name, env in (("default", {}), ("streams3", {"ORBX_STREAMS": "3"}), ("no_side", {"ORBX_SIDE_BLUR": "0"}),
-                      ("blur_after_fast", {"ORBX_SIDE_BLUR": "2"}), ("no_early_fast", {"ORBX_EARLY_FAST": "0"}),
-                      ("early_blur", {"ORBX_EARLY_FAST": "2"})):
-        e = dict(os.environ)
-        e.update(env)
-        results[name] = subprocess.check_output([sys.executable, str(script)], env=e, text=True).strip().splitlines()[-1]
+    import json
+    for name, var in (("default", {}), ("streams3", {"streams": 3}), ("no_side", {"side_blur": 0}),
+                      ("blur_after_fast", {"side_blur": 2}), ("blur_beside_orientation", {"side_blur": 3}),
+                      ("no_early_fast", {"early_fast": 0}), ("early_blur", {"early_fast": 2}), ("desc_separate", {"desc": "separate"}),
+                      ("desc_fused", {"desc": "fused"}), ("copy_back", {"zero_copy": 0})):
+        results[name] = subprocess.check_output([sys.executable, str(script), json.dumps(var)], text=True).strip().splitlines()[-1]
     assert len(set(results.values())) == 1, results
     assert int(results["default"].split()[0]) > 24 * 500
 

@@ -266,10 +266,13 @@ def test_distinctive_descriptors(oracle_mod):
         ORBMatcher.ComputeDistinctiveDescriptors(np.zeros((1025, 32), np.uint8), np.array([0, 1025], np.int32))
 
 
-def test_best2_device_many_problems(oracle_mod):
+@pytest.mark.parametrize("variant", ["fp4", "i8", "valu"])
+def test_best2_device_many_problems(oracle_mod, variant):
     """orbm_best2_device the way bench.py drives it: several (A, B) problems in one launch, per-problem counts below
-    the strides, device pointers.  Every row equals the oracle's sequential strict-'<' scan (ORBMatcher.cpp:148-162);
-    includes a query whose only candidates are at distance 256, empty problems and masked rows / candidates."""
+    the strides, device pointers, through each of the three kernels that ship (ORBM_VAR_BEST2: the FP4 matrix path, the i8
+    matrix path, the VALU twin; a fresh handle per variant).  Every row equals the oracle's sequential strict-'<' scan
+    (ORBMatcher.cpp:148-162); includes a query whose only candidates are at distance 256, empty problems, masked rows and
+    candidates, and a row mask WITHOUT a candidate mask (the matrix kernels' own masked-row path)."""
     import torch
     from monoorbslam3_amd import _lib
     from monoorbslam3_amd.matcher import MatcherHandle, _mlib
@@ -296,20 +299,21 @@ def test_best2_device_many_problems(oracle_mod):
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
     dA, dB, dna, dnb, drow, dcol = t(A), t(B), t(na), t(nb), t(row_ok), t(col_ok)
     mh = MatcherHandle(device=0)
+    mh.set_variant("best2", variant)
     L = _mlib()
-    for masks in (False, True):
+    for masks in (False, True, "rows"):
         d_bi = torch.full((n_pairs, a_stride), -7, dtype=torch.int32, device=dev)
         d_bd = torch.full((n_pairs, a_stride), -7, dtype=torch.int16, device=dev)
         d_sd = torch.full((n_pairs, a_stride), -7, dtype=torch.int16, device=dev)
         st = torch.cuda.current_stream().cuda_stream
         _lib.check(L.orbm_best2_device(mh._h, n_pairs, dA.data_ptr(), a_stride, dna.data_ptr(), a_stride, dB.data_ptr(),
                                        b_stride, dnb.data_ptr(), b_stride, drow.data_ptr() if masks else None,
-                                       dcol.data_ptr() if masks else None, d_bi.data_ptr(), d_bd.data_ptr(),
+                                       dcol.data_ptr() if masks is True else None, d_bi.data_ptr(), d_bd.data_ptr(),
                                        d_sd.data_ptr(), st))
         torch.cuda.synchronize()
         bi, bd, sd = d_bi.cpu().numpy(), d_bd.cpu().numpy().view(np.uint16), d_sd.cpu().numpy().view(np.uint16)
         for p in range(n_pairs):
-            cand = np.arange(nb[p]) if not masks else np.nonzero(col_ok[p, :nb[p]])[0]
+            cand = np.arange(nb[p]) if masks is not True else np.nonzero(col_ok[p, :nb[p]])[0]
             r_bi, r_bd, r_sd = oracle_mod.best2(A[p, :na[p]], B[p][cand])
             r_bi = np.where(r_bi >= 0, cand[np.maximum(r_bi, 0)] if len(cand) else -1, -1)
             if masks:
@@ -321,6 +325,20 @@ def test_best2_device_many_problems(oracle_mod):
             # rows between the count and the stride are written as "no candidate", never left stale
             assert (bi[p, na[p]:] == -1).all() and (bd[p, na[p]:] == 256).all() and (sd[p, na[p]:] == 256).all()
     assert bi[1, 0] == -1 and bd[1, 0] == 256  # a 256-distance candidate never beats the initial 256
+
+
+@pytest.mark.parametrize("variant", ["fp4", "i8", "valu"])
+def test_best2_dense_2000x2000_every_kernel(oracle_mod, variant):
+    """BASELINE config 3's shape (2000 x 2000 256-bit descriptors, no masks) through each dense best / second-best kernel:
+    index, best and second distance of every row equal the oracle's scan."""
+    from monoorbslam3_amd.matcher import MatcherHandle, ORBMatcher
+    a, b, _ = synth.make_descriptor_pair(2000, seed=77)
+    b[1234] = b[77]  # a duplicate candidate: the first index wins
+    mh = MatcherHandle()
+    mh.set_variant("best2", variant)
+    bi, bd, sd = ORBMatcher.best2(a, b, handle=mh)
+    r_bi, r_bd, r_sd = oracle_mod.best2(a, b)
+    assert np.array_equal(bi, r_bi) and np.array_equal(bd, r_bd) and np.array_equal(sd, r_sd)
 
 
 @pytest.mark.parametrize("check_ori", [True, False])
@@ -472,17 +490,16 @@ def test_window_lists_on_a_device_resident_frame_record(oracle_mod):
     assert cnt[6] == 0 and cnt[7] == 0
 
 
-def test_window_searches_device_lists_equal_the_host_twin(oracle_mod, monkeypatch):
+def test_window_searches_device_lists_equal_the_host_twin(oracle_mod):
     """The four window searches with their candidate lists built on the device (default) and on the host
-    (ORBM_WINDOW=host): identical results, both equal to the oracle's."""
+    (ORBM_VAR_WINDOW = 1): identical results, both equal to the oracle's."""
     from monoorbslam3_amd.matcher import MatcherHandle, ORBMatcher
     w, h, k1, d1, k2, d2 = _two_views()
     rng = np.random.RandomState(21)
     n1, n2 = len(k1), len(k2)
     dev_h = MatcherHandle()
-    monkeypatch.setenv("ORBM_WINDOW", "host")
     host_h = MatcherHandle()
-    monkeypatch.delenv("ORBM_WINDOW")
+    host_h.set_variant("window", "host")
     q_xy = np.stack([k1["x"] - 6.0 + rng.normal(0, 1.5, n1), k1["y"] - 4.0 + rng.normal(0, 1.5, n1)], axis=1).astype(np.float32)
     q_ok = (rng.uniform(size=n1) > 0.3).astype(np.uint8)
     mp0 = np.where(rng.uniform(size=n2) > 0.95, 12345, -1).astype(np.int32)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-kernel average / minimum duration of one bench run under rocprofv3 --kernel-trace --stats (timed steps overlap
 # their streams, so the averages include contention; the minimum is close to the isolated time).
-cd /tmp && export TMPDIR=/tmp ORBX_STREAMS=1
+cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end "$@" > /dev/null 2>/tmp/kt.err
 python3 - <<'PY'

@@ -3,7 +3,7 @@
 # kernels wait for.  Output: gpurun_out/ta_breakdown.txt
 set -e -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-cd /tmp && export TMPDIR=/tmp ORBX_STREAMS=1
+cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tab
 # (a first pass with GRBM_GUI_ACTIVE + TA_TA_BUSY / TA_ADDR_STALLED_BY_TC / TA_DATA_STALLED_BY_TC hung rocprofv3 on this pool in
 # round 2 and was killed after 7 minutes of silence with an empty log -- profiles/README.md; that set is not collected any more)
