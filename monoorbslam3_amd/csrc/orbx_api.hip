@@ -80,6 +80,12 @@ struct orbx_ctx {
     // the Gaussian on the matrix pipe: strip list, band tables, per-level record; levels [0, blur_mfma_levels)
     uint16_t *d_blur_strips; uint8_t *d_band_h, *d_band_v;
     BlurMfmaLevels blur_tab; int blur_strips_before[ORBX_MAX_LEVELS + 1]; int blur_mfma_levels;
+    // blur + descriptors in one pass (k_blur_desc): block list, H bands, bucket layout; levels [0, bd_levels)
+    uint16_t *d_bd_blocks; uint8_t *d_bd_band_h; int n_bd_blocks, bd_levels, bd_bk_stride;
+    BdLevels bd_tab;
+    int *d_bd_bk_start; uint8_t *d_bd_items;                    // per frame: bucket starts, 32-byte key-point records
+    int alloc_bd_batch, alloc_bd_kcap, alloc_bd_stride;
+    int last_fused_levels;                                      // levels of the last call whose blurred copy was never written
     int blur_mfma;                                              // ORBX_VAR_BLUR: 1 = by call size (default), 0 = VALU kernels, 2 = matrix pipe for any batch
     uint8_t *d_l0_stage; size_t l0_stage_fs;
     int *d_slot_level;                                          // level of every key-point slot of the current geometry
@@ -193,6 +199,13 @@ static void linear_taps(int dn, int sn, bool clamp_ofs, std::vector<OrbxTap> &ou
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// ORBX_VAR_DESC = 0: calls with at least this many level-0 pixels take k_blur_desc.  A workgroup of that kernel walks down a whole
+// level, so a small call is bounded by its longest walk, and the blur pass it replaces hides beside FAST on a side stream:
+// measured at 1242x375 (tools/desc_crossover.sh) the one-pass kernel loses up to 96 frames (161 k against 165 k frames/s) and
+// wins from 128 (174.5 k against 168.4 k; 512 frames: 207 k against 197 k).
+#ifndef ORBX_FUSED_DESC_MIN_PIXELS
+#define ORBX_FUSED_DESC_MIN_PIXELS 55000000ull
+#endif
 
 struct Geometry {
     OrbxLevels levels;
@@ -385,6 +398,14 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
             if (!bs.empty()) HIP_TRY(hipMemcpy(c->d_blur_strips, bs.data(), bs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             if (!bh.empty()) HIP_TRY(hipMemcpy(c->d_band_h, bh.data(), bh.size(), hipMemcpyHostToDevice));
             if (!bv.empty()) HIP_TRY(hipMemcpy(c->d_band_v, bv.data(), bv.size(), hipMemcpyHostToDevice));
+            std::vector<uint16_t> bb;
+            std::vector<uint8_t> bdh;
+            orbx_build_blur_desc(c->levels, c->taps, c->blur_tab, bb, bdh, c->bd_tab, &c->bd_levels, &c->bd_bk_stride);
+            c->n_bd_blocks = (int)(bb.size() / 2);
+            HIP_TRY(dev_alloc(&c->d_bd_blocks, std::max(bb.size(), (size_t)2)));
+            HIP_TRY(dev_alloc(&c->d_bd_band_h, std::max(bdh.size(), (size_t)16)));
+            if (!bb.empty()) HIP_TRY(hipMemcpy(c->d_bd_blocks, bb.data(), bb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            if (!bdh.empty()) HIP_TRY(hipMemcpy(c->d_bd_band_h, bdh.data(), bdh.size(), hipMemcpyHostToDevice));
         }
         std::vector<OrbxTap> taps, ytaps;
         for (int l = 1; l < c->levels.n_levels; ++l) {
@@ -400,6 +421,15 @@ static int ensure_geometry(orbx_ctx *c, int w0, int h0, int batch, int out_cap)
             c->resize2_ok[l - 1] = l >= 2 && orbx_resize2_fits(taps.data(), ytaps.data(), s.w, s.h, d.w, d.h);
             c->resize_lds_ok[l] = orbx_resize_lds_fits(taps.data(), ytaps.data(), s.w, s.h, d.w, d.h);
         }
+    }
+    // k_blur_desc's per-frame bucket starts and 32-byte item records: grown with the batch, the slot count or the bucket count
+    if (c->alloc_batch > c->alloc_bd_batch || c->levels.kcap_total > c->alloc_bd_kcap || c->bd_bk_stride > c->alloc_bd_stride) {
+        HIP_TRY(hipDeviceSynchronize());
+        c->alloc_bd_batch = std::max(c->alloc_batch, c->alloc_bd_batch);
+        c->alloc_bd_kcap = std::max(c->levels.kcap_total, c->alloc_bd_kcap);
+        c->alloc_bd_stride = std::max(c->bd_bk_stride, c->alloc_bd_stride);
+        HIP_TRY(dev_alloc(&c->d_bd_bk_start, (size_t)c->alloc_bd_stride * c->alloc_bd_batch));
+        HIP_TRY(dev_alloc(&c->d_bd_items, (size_t)32 * std::max(c->alloc_bd_kcap, 1) * c->alloc_bd_batch));
     }
     // frame strides of the arenas are the allocated ones
     c->buf.img_frame_stride = c->alloc_img_fs;
@@ -510,7 +540,7 @@ extern "C" void orbx_destroy(orbx_t *c)
     OrbxBuffers &b = c->buf;
     void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.pcode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
                     b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.kp_ang, b.sel_count, b.sel_prefix, c->d_slot_level, c->d_levels, c->d_umax, c->d_taps,
-                    c->d_l0_stage, c->d_out_block, c->d_fast_cells, c->d_fast_strips, c->d_blur_tiles, c->d_blur_strips, c->d_band_h, c->d_band_v};
+                    c->d_l0_stage, c->d_out_block, c->d_fast_cells, c->d_fast_strips, c->d_blur_tiles, c->d_blur_strips, c->d_band_h, c->d_band_v, c->d_bd_blocks, c->d_bd_band_h, c->d_bd_bk_start, c->d_bd_items};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_out_block) (void)hipHostFree(c->h_out_block);
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {
@@ -659,7 +689,14 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     };
     // 7x7 Gaussian of levels [lb, le): on the matrix pipe for the levels that are large enough when the call is a batch
     // (ORBX_VAR_BLUR = 2 forces it for any batch, 0 switches it off), the VALU kernels for the rest
+    // Levels [0, fl) get their descriptors from k_blur_desc (blur and sampling in one pass, no blurred copy); the blur pass and
+    // k_orient_desc serve the rest -- levels too narrow for it, or all of them on the two-kernel path (ORBX_VAR_DESC = 1).
+    const bool big_call = (size_t)n_frames * (size_t)LV.lv[0].w * (size_t)LV.lv[0].h >= (size_t)ORBX_FUSED_DESC_MIN_PIXELS;
+    const int fl = (c->desc_variant == 2 || (c->desc_variant == 0 && big_call)) ? c->bd_levels : 0;
+    c->last_fused_levels = fl;
     auto launch_blur = [&](hipStream_t st, int lb, int le) {
+        lb = std::max(lb, fl);
+        if (le <= lb) return;
         const int lm = (c->blur_mfma == 2 || (c->blur_mfma == 1 && n_frames >= 8)) ? std::min(c->blur_mfma_levels, le) : 0;
         if (lm > lb)
             orbx_launch_blur_mfma(st, d_l0, l0_fs, l0_pitch, LV, b, c->blur_tab, c->d_blur_strips, c->blur_strips_before,
@@ -667,6 +704,15 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         if (le > std::max(lb, lm))
             orbx_launch_blur(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_blur_tiles, c->n_blur_tiles, c->d_taps, n_frames,
                              std::max(lb, lm), le);
+    };
+    // orientation, then the descriptors: k_blur_desc for levels [0, fl), k_orient_desc (behind the blur pass) for the others
+    auto launch_desc = [&](hipEvent_t blur_done) {
+        orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames,
+                                fl < L ? blur_done : nullptr, fl);
+        if (fl > 0)
+            orbx_launch_desc_fused(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->bd_tab, fl, c->d_bd_blocks, c->n_bd_blocks, c->d_bd_band_h,
+                                   c->d_band_v, c->d_bd_bk_start + (size_t)f0 * c->bd_bk_stride, c->bd_bk_stride,
+                                   c->d_bd_items + (size_t)f0 * 32 * LV.kcap_total, c->taps, d_kp, d_desc, cap, d_n, n_frames);
     };
     // Level 0 needs no pyramid, so its FAST can start on the side stream beside the resizes.  That pays next to k_resize (no LDS,
     // 27 VGPRs: its waves fit between FAST's), not next to k_resize_lds, which wants the LDS that FAST's workgroups fill
@@ -712,8 +758,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         launch_blur(c->side[bslot], 0, L);
         HIP_TRY(hipEventRecord(c->ev_blur[bslot], c->side[bslot]));
         HIP_TRY(hipStreamWaitEvent(s, c->ev_fast0[slot], 0));
-        orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames,
-                                c->ev_blur[bslot]);
+        launch_desc(c->ev_blur[bslot]);
         HIP_TRY(hipGetLastError());
         return ORBX_OK;
     }
@@ -755,8 +800,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, L);
     if (t) HIP_TRY(hipEventRecord(c->ev[4], s));
     if (side && c->side_blur >= 3) { int rc = fork_blur(); if (rc) return rc; } // next to the orientation only
-    orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames,
-                            side ? c->ev_blur[bslot] : nullptr);
+    launch_desc(side ? c->ev_blur[bslot] : nullptr);
     if (t) { HIP_TRY(hipEventRecord(c->ev[5], s)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
     return ORBX_OK;
@@ -932,6 +976,18 @@ extern "C" int orbx_tap_level(orbx_t *c, int frame, int level, int blurred, uint
     if (out_bytes < (size_t)v.w * v.h) return fail(ORBX_E_CAPACITY, "buffer too small");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (blurred && level < c->last_fused_levels) {
+        // the last call described this level with k_blur_desc, which keeps the blurred rows in LDS only: the blur pass makes
+        // the copy now (all frames of the call, so that later taps find it), on the raw level that is still in place
+        if (level < c->blur_mfma_levels)
+            orbx_launch_blur_mfma(c->stream, c->last_l0, c->last_l0_fs, c->last_l0_pitch, c->levels, c->buf, c->blur_tab, c->d_blur_strips,
+                                  c->blur_strips_before, c->d_band_h, c->d_band_v, c->taps, c->last_frames, level, level + 1);
+        else
+            orbx_launch_blur(c->stream, c->last_l0, c->last_l0_fs, c->last_l0_pitch, c->d_levels, c->levels, c->buf, c->d_blur_tiles,
+                             c->n_blur_tiles, c->d_taps, c->last_frames, level, level + 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     const uint8_t *src; size_t pitch;
     if (blurred) { src = c->buf.img_arena + (size_t)frame * c->buf.img_frame_stride + v.blur_off; pitch = v.pitch; }
     else if (level == 0) { src = c->last_l0 + (size_t)frame * c->last_l0_fs; pitch = c->last_l0_pitch; }

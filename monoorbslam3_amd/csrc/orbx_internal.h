@@ -115,8 +115,22 @@ void orbx_launch_blur_mfma(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l
                            const OrbxBuffers &b, const BlurMfmaLevels &tab, const void *d_strips, const int *strips_before,
                            const void *d_band_h, const void *d_band_v, const int taps[7], int n_frames, int level_begin,
                            int level_end);
+// blur and descriptors in one pass (k_blur_desc): per-level record, passed by value
+struct BdLevels {
+    int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], n_ty[ORBX_MAX_LEVELS], n_bx[ORBX_MAX_LEVELS];
+    int bh_off[ORBX_MAX_LEVELS], bv_off[ORBX_MAX_LEVELS]; // in uint4, into the H-band table of k_blur_desc / the V-band table shared with k_blur_mfma
+    int bucket_base[ORBX_MAX_LEVELS];                     // first (block, trip) bucket of the level inside a frame's bucket-start array
+    float scale[ORBX_MAX_LEVELS];
+};
+void orbx_build_blur_desc(const OrbxLevels &levels, const int taps[7], const BlurMfmaLevels &mf, std::vector<uint16_t> &blocks,
+                          std::vector<uint8_t> &band_h, BdLevels &out, int *n_fused_levels, int *bk_stride);
+// k_desc_bins + k_blur_desc for levels [0, n_fused_levels); d_items: 32 bytes per key-point slot and frame, d_bk_start: bk_stride ints per frame
+void orbx_launch_desc_fused(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
+                            const OrbxLevels &levels, const OrbxBuffers &b, const BdLevels &tab, int n_fused_levels, const void *d_blocks,
+                            int n_blocks, const void *d_band_h, const void *d_band_v, int *d_bk_start, int bk_stride, void *d_items,
+                            const int taps[7], orbx_kp *out_kp, uint8_t *out_desc, int cap, int32_t *out_n, int n_frames);
 void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLevels &levels, const OrbxBuffers &b,
                         int n_frames, size_t sort_lds_bytes, int level_begin, int level_end);
 void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
-                             uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done);
+                             uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done, int desc_level_min = 0);

@@ -1848,7 +1848,7 @@ struct DescTab { int n_levels, kcap_total, pad[2]; DescLv lv[ORBX_MAX_LEVELS]; }
 template <int ROUNDS>
 __global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
                                                      orbx_kp *__restrict__ out_kp, uint8_t *__restrict__ out_desc,
-                                                     int cap, int32_t *__restrict__ out_n, int per_frame, int n_frames)
+                                                     int cap, int32_t *__restrict__ out_n, int per_frame, int n_frames, int level_min)
 {
     // the 37x37 neighbourhood of each keypoint is staged row by row (coalesced, ~45 cache lines) and the
     // 512 rotated samples are byte gathers from LDS instead of ~250 scattered cache-line touches
@@ -1891,7 +1891,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
             pr.level[k] = lvl;
             const DescLv lv = tab.lv[lvl]; // (a slot past the last one is given level 0; an empty slot of a level stages the corner of its own blurred level)
             const int i = slot - lv.kp_off;
-            live = live && i < cnts[lvl];
+            live = live && i < cnts[lvl] && lvl >= level_min; // (levels below level_min are described by k_blur_desc)
             const int oi = i + b.sel_prefix[frame * ORBX_MAX_LEVELS + lvl];
             pr.out_idx[k] = oi;
             live = live && oi < cap;
@@ -1987,7 +1987,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
 
 void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
-                             uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done)
+                             uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done, int desc_level_min)
 {
     const int pf_o = (levels.kcap_total + OR_KP - 1) / OR_KP;
     OrientLevels tab;
@@ -2005,6 +2005,7 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
         hipLaunchKernelGGL(k_angle, dim3((unsigned)(((size_t)levels.kcap_total * n_frames + 255) / 256)), dim3(256), 0, s, d_levels,
                            b, n_frames);
     }
+    if (desc_level_min >= levels.n_levels) return; // every level is described by k_blur_desc (orbx_launch_desc_fused)
     if (blur_done) (void)hipStreamWaitEvent(s, blur_done, 0); // the blurred levels come from a side stream
     DescTab dt;
     dt.n_levels = levels.n_levels; dt.kcap_total = levels.kcap_total; dt.pad[0] = dt.pad[1] = 0;
@@ -2018,7 +2019,8 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
     }
     const int per_wg = 4 * DP_K; // (the instantiations with 2 / 4 rounds per wave lost -- see the kernel -- and are not built)
     const int pf_d = (levels.kcap_total + per_wg - 1) / per_wg;
-        hipLaunchKernelGGL(k_orient_desc<1>, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, dt, b, out_kp, out_desc, cap, out_n, pf_d, n_frames);
+    hipLaunchKernelGGL(k_orient_desc<1>, dim3(orbx_xcd_grid(pf_d, n_frames)), dim3(256), 0, s, dt, b, out_kp, out_desc, cap, out_n, pf_d, n_frames,
+                       desc_level_min);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2035,8 +2037,20 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
 // k_desc_bins, one 32-byte record each (position, output slot, angle, cos, sin, response) through the scalar cache.
 // Same arithmetic as k_blur_mfma + k_orient_desc, bit for bit (tests: both paths against the oracle, and against each other).
 // ---------------------------------------------------------------------------------------------
-#define BD_WAVES BM_WAVES
-#define BD_COLS BM_COLS                  // blurred columns of a workgroup
+#ifndef BD_WAVES
+#define BD_WAVES 4                       // waves per workgroup = 32-column tile columns of a block (4 / 6 / 8 measured)
+#endif
+#define BD_COLS (32 * BD_WAVES)          // blurred columns of a workgroup
+#define BD_T (64 * BD_WAVES)             // threads
+#ifndef BD_ALIGN16
+#define BD_ALIGN16 0
+#endif
+// source bytes staged per row, in 16-byte chunks: 16 either side -- and, with BD_ALIGN16, one chunk more so that the staged row
+// can start at a 16-byte boundary of the level (arena rows are 64-byte aligned: every load then is one aligned 16-byte request)
+#define BD_SRC_W (BD_COLS + 32 + 16 * BD_ALIGN16)
+#define BD_CH (BD_SRC_W / 16)
+#define BD_SRC_P (BD_SRC_W + 16)         // LDS pitch of a staged source row
+static_assert(32 * BD_CH <= 2 * BD_T, "a thread stages at most two chunks");
 #define BD_HALO 18                       // a rotated pattern point lies within +-18 px of its key point (ORBX_EDGE - 1)
 #define BD_CW (BD_COLS - 2 * BD_HALO)    // key-point columns a workgroup serves
 #define BD_RING 128                      // blurred rows held in LDS: four trips
@@ -2051,8 +2065,21 @@ struct __attribute__((aligned(32))) BdItem { // one key point as k_blur_desc tak
 };
 // first blurred column of block bi, the block of a key-point column, the trip that completes a key point's window
 __host__ __device__ __forceinline__ int bd_first_col(int bi) { return bi * BD_CW; }
+// first staged source column of a block whose first blurred column is B0; `limit` = readable bytes of a row
+__host__ __device__ __forceinline__ int bd_origin(int B0, int limit)
+{
+    const int want = BD_ALIGN16 ? ((B0 - 16) & ~15) : B0 - 16;
+    return min(max(want, 0), limit - BD_SRC_W);
+}
 __host__ __device__ __forceinline__ int bd_block_of(int x) { return (x - BD_HALO) / BD_CW; }
 __host__ __device__ __forceinline__ int bd_trip_of(int y) { return (y + BD_HALO) >> 5; }
+// Each (block, trip) bucket has an EARLY and a LATE part.  A key point may wait one trip (load balance, below) unless its
+// window starts in the first four rows its trip can still see: the trip after would find those rows, four ring blocks back,
+// being overwritten by the waves that are already one trip ahead.
+__host__ __device__ __forceinline__ int bd_sub_bucket(int x, int y, int n_ty)
+{
+    return 2 * (bd_block_of(x) * n_ty + bd_trip_of(y)) + (((y + BD_HALO) & 31) >= 4 ? 1 : 0);
+}
 
 // Buckets the selected key points of one (frame, level) by (block, trip) -- a counting sort in LDS -- and writes their item
 // records; also the frame's total count (what k_orient_desc's first workgroup does on the two-kernel path).
@@ -2070,7 +2097,7 @@ __global__ __launch_bounds__(256) void k_desc_bins(const OrbxLevels *__restrict_
         for (int l = 0; l < L; ++l) tot += cnts[l];
         out_n[frame] = tot;
     }
-    const int n_ty = lv.n_ty[level], nb = lv.n_bx[level] * n_ty, kp_off = levels->lv[level].kp_off;
+    const int n_ty = lv.n_ty[level], nb = 2 * lv.n_bx[level] * n_ty, kp_off = levels->lv[level].kp_off;
     const int n = min(cnts[level], levels->lv[level].kcap);
     int *start = s_bins, *cursor = s_bins + nb + 1;
     for (int i = tid; i < nb; i += 256) cursor[i] = 0;
@@ -2078,7 +2105,7 @@ __global__ __launch_bounds__(256) void k_desc_bins(const OrbxLevels *__restrict_
     const uint2 *sel = b.sel + (size_t)frame * kc + kp_off;
     for (int i = tid; i < n; i += 256) {
         const uint32_t xy = sel[i].x;
-        atomicAdd(&cursor[bd_block_of((int)(xy & 0xFFFF)) * n_ty + bd_trip_of((int)(xy >> 16))], 1);
+        atomicAdd(&cursor[bd_sub_bucket((int)(xy & 0xFFFF), (int)(xy >> 16), n_ty)], 1);
     }
     __syncthreads();
     // exclusive scan of the nb counts: a contiguous run per thread, then the 256 run totals
@@ -2107,7 +2134,7 @@ __global__ __launch_bounds__(256) void k_desc_bins(const OrbxLevels *__restrict_
     for (int i = tid; i < n; i += 256) {
         const uint2 rec = sel[i];
         const float4 ang = b.kp_ang[(size_t)frame * kc + kp_off + i];
-        const int pos = atomicAdd(&cursor[bd_block_of((int)(rec.x & 0xFFFF)) * n_ty + bd_trip_of((int)(rec.x >> 16))], 1);
+        const int pos = atomicAdd(&cursor[bd_sub_bucket((int)(rec.x & 0xFFFF), (int)(rec.x >> 16), n_ty)], 1);
         BdItem it;
         it.xy = rec.x; it.out_idx = before + i < cap ? before + i : -1;
         it.angle = ang.x; it.cs = ang.y; it.sn = ang.z; it.response = (float)rec.y; it.pad[0] = it.pad[1] = 0;
@@ -2115,8 +2142,14 @@ __global__ __launch_bounds__(256) void k_desc_bins(const OrbxLevels *__restrict_
     }
 }
 
+// Five workgroups per CU is what the kernel's 28 KB of LDS allow; left alone the compiler takes 109 VGPRs (four waves per
+// SIMD).  Held to five waves it fits in 94 without spilling: 0.565 -> 0.51 ms per 512 frames (six: no gain, LDS-bound).
+#ifndef BD_WAVES_PER_EU
+#define BD_WAVES_PER_EU 5
+#endif
+#define BD_OCC __attribute__((amdgpu_waves_per_eu(BD_WAVES_PER_EU, BD_WAVES_PER_EU)))
 template <int K_SUM>
-__global__ __launch_bounds__(BM_T) void k_blur_desc(FastSrc src, BdLevels lv, const BdBlock *__restrict__ blocks,
+__global__ __launch_bounds__(BD_T) BD_OCC void k_blur_desc(FastSrc src, BdLevels lv, const BdBlock *__restrict__ blocks,
                                                    const uint4 *__restrict__ band_h, const uint4 *__restrict__ band_v,
                                                    const int *__restrict__ bk_start, int bk_stride, const BdItem *__restrict__ items,
                                                    int kcap_total, orbx_kp *__restrict__ out_kp, uint8_t *__restrict__ out_desc, int cap,
@@ -2125,7 +2158,7 @@ __global__ __launch_bounds__(BM_T) void k_blur_desc(FastSrc src, BdLevels lv, co
     constexpr int hbias = 128 * K_SUM - 32768;
     constexpr uint32_t vbias = 128u * K_SUM * 257u + 32768u;
     constexpr bool clamp255 = K_SUM != 256;
-    __shared__ __align__(16) uint8_t s_src[2][32 * BM_SRC_P];
+    __shared__ __align__(16) uint8_t s_src[2][32 * BD_SRC_P];
     __shared__ __align__(16) uint8_t s_ring[BD_RING * BD_RP];
     int frame, bid;
     if (!xcd_remap(n_blocks, n_frames, &frame, &bid)) return;
@@ -2135,13 +2168,13 @@ __global__ __launch_bounds__(BM_T) void k_blur_desc(FastSrc src, BdLevels lv, co
     const int w = lv.w[level], h = lv.h[level], pitch = src.pitch[level], n_ty = lv.n_ty[level];
     const int limit = level == 0 ? w : pitch;
     const int B0 = bd_first_col((int)bk.bi);
-    const int xo = min(max(B0 - 16, 0), limit - BM_SRC_W);
-    const int cw = min(max(B0 + 32 * wave - 16, xo), xo + BM_SRC_W - 64); // this wave's 64-column source window (two K-steps)
+    const int xo = bd_origin(B0, limit);
+    const int cw = min(max(B0 + 32 * wave - 16, xo), xo + BD_SRC_W - 64); // this wave's 64-column source window (two K-steps)
     (void)w;
     const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level];
     const uint4 *bh = band_h + lv.bh_off[level] + (size_t)((int)bk.bi * BD_WAVES + wave) * 128;
     const bl_v4i bh0 = __builtin_bit_cast(bl_v4i, bh[lane]), bh1 = __builtin_bit_cast(bl_v4i, bh[64 + lane]);
-    const int a_off = n * BM_SRC_P + (cw - xo) + 16 * hh;
+    const int a_off = n * BD_SRC_P + (cw - xo) + 16 * hh;
     // this lane's four sampling pairs (the same for every key point)
     float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
@@ -2151,11 +2184,11 @@ __global__ __launch_bounds__(BM_T) void k_blur_desc(FastSrc src, BdLevels lv, co
         px1[j] = (float)(int8_t)((pat >> 16) & 255); py1[j] = (float)(int8_t)(pat >> 24);
     }
     const float lscale = lv.scale[level];
-    const int *bks = bk_start + (size_t)frame * bk_stride + lv.bucket_base[level] + (int)bk.bi * n_ty;
+    const int *bks = bk_start + (size_t)frame * bk_stride + lv.bucket_base[level] + 2 * (int)bk.bi * n_ty;
     const BdItem *its = items + (size_t)frame * kcap_total;
 
-    const int c0r = tid / BM_CH, c0c = tid - BM_CH * c0r, c1r = (BM_T + tid) / BM_CH, c1c = (BM_T + tid) - BM_CH * c1r;
-    const bool second = tid < 32 * BM_CH - BM_T;
+    const int c0r = tid / BD_CH, c0c = tid - BD_CH * c0r, c1r = (BD_T + tid) / BD_CH, c1c = (BD_T + tid) - BD_CH * c1r;
+    const bool second = tid < 32 * BD_CH - BD_T;
     auto g_load = [&](int T, uint4 *u0, uint4 *u1) {
         const int r0 = min(max(32 * T - 3 + c0r, 0), h - 1), r1 = min(max(32 * T - 3 + min(c1r, 31), 0), h - 1);
         const UnalignedU4 a = *reinterpret_cast<const UnalignedU4 *>(S + (size_t)r0 * pitch + xo + 16 * c0c);
@@ -2164,8 +2197,8 @@ __global__ __launch_bounds__(BM_T) void k_blur_desc(FastSrc src, BdLevels lv, co
         *u1 = make_uint4(b2.x, b2.y, b2.z, b2.w);
     };
     auto s_store = [&](int buf, const uint4 &u0, const uint4 &u1) {
-        *reinterpret_cast<uint4 *>(&s_src[buf][c0r * BM_SRC_P + 16 * c0c]) = u0;
-        if (second) *reinterpret_cast<uint4 *>(&s_src[buf][c1r * BM_SRC_P + 16 * c1c]) = u1;
+        *reinterpret_cast<uint4 *>(&s_src[buf][c0r * BD_SRC_P + 16 * c0c]) = u0;
+        if (second) *reinterpret_cast<uint4 *>(&s_src[buf][c1r * BD_SRC_P + 16 * c1c]) = u1;
     };
     auto h_tile = [&](int buf, bl_v4i *hi, bl_v4i *lo) { // as in k_blur_mfma
         bl_v4i a0 = reinterpret_cast<const UnalignedV4 *>(&s_src[buf][a_off])->v;
@@ -2235,10 +2268,19 @@ __global__ __launch_bounds__(BM_T) void k_blur_desc(FastSrc src, BdLevels lv, co
     h_tile(0, &hiP, &loP);
     __syncthreads();
     const uint4 *bv = band_v + lv.bv_off[level];
+    int done = bks[0]; // items of this block described so far (the same value in every wave)
     for (int ty = 0; ty < n_ty; ++ty, bv += 128) {
-        // this trip's bucket: the wave takes items wave, wave + BD_WAVES, ...; the first record is requested now and used
-        // after the barrier, under the trip's arithmetic
-        const int it_begin = bks[ty] + wave, it_end = bks[ty + 1];
+        // Key points to describe in this trip.  The ring keeps a trip's rows for one more trip, so the LATE part of bucket ty may
+        // wait until trip ty + 1: pending = what is due now (everything up to the early part of bucket ty) + the late part, and
+        // the trip takes the largest multiple of the wave count out of it (at least what is due, everything in the last trip)
+        // -- with four or five key points per bucket a fixed one-bucket-per-trip rule makes three waves wait for the one that
+        // got two.  The buckets of a block are contiguous in the item array and every wave computes the same cursor, so the rule
+        // costs no communication.  The wave takes items it_begin, it_begin + BD_WAVES, ...; the first record is requested now
+        // and used after the barrier.
+        const int due = bks[2 * ty + 1], avail = bks[2 * ty + 2];
+        const int take = ty + 1 == n_ty ? avail - done : max(due - done, (avail - done) / BD_WAVES * BD_WAVES);
+        const int it_begin = done + wave, it_end = done + take;
+        done = it_end;
         BdItem first;
         first.out_idx = -1;
         if (it_begin < it_end) first = its[it_begin];
@@ -2266,10 +2308,12 @@ __global__ __launch_bounds__(BM_T) void k_blur_desc(FastSrc src, BdLevels lv, co
             *reinterpret_cast<uint32_t *>(&so[n * BD_RP + 32 * wave + 8 * g + 4 * hh]) = __builtin_amdgcn_perm(b2, a, 0x05040100u);
         }
         __syncthreads(); // the trip's blurred rows and the source of the next trip are complete
+#ifndef BD_PROBE_NODESC // (timing probe: the blur part alone)
         if (it_begin < it_end) {
             describe(first);
             for (int k = it_begin + BD_WAVES; k < it_end; k += BD_WAVES) describe(its[k]);
         }
+#endif
         hiP = hiN; loP = loN;
     }
 }
@@ -2281,7 +2325,8 @@ void orbx_build_blur_desc(const OrbxLevels &levels, const int taps[7], const Blu
 {
     blocks.clear(); band_h.clear();
     memset(&out, 0, sizeof out);
-    const int n_lv = orbx_blur_mfma_levels(levels);
+    int n_lv = 0; // levels wide enough for a block's staged source row (and for k_blur_mfma, whose V bands are shared)
+    while (n_lv < orbx_blur_mfma_levels(levels) && levels.lv[n_lv].w >= BD_SRC_W) ++n_lv;
     int buckets = 0;
     for (int l = 0; l < n_lv; ++l) {
         const OrbxLevel &v = levels.lv[l];
@@ -2293,13 +2338,13 @@ void orbx_build_blur_desc(const OrbxLevels &levels, const int taps[7], const Blu
         const int n_bx = w - ORBX_EDGE - 1 >= ORBX_EDGE ? bd_block_of(w - ORBX_EDGE - 1) + 1 : 0;
         out.n_bx[l] = n_bx;
         out.bucket_base[l] = buckets;
-        buckets += n_bx * out.n_ty[l] + 1;
+        buckets += 2 * n_bx * out.n_ty[l] + 1; // an early and a late part per (block, trip), and the end
         for (int bi = 0; bi < n_bx; ++bi) {
             blocks.push_back((uint16_t)l); blocks.push_back((uint16_t)bi);
-            const int B0 = bd_first_col(bi), xo = std::min(std::max(B0 - 16, 0), limit - BM_SRC_W);
+            const int B0 = bd_first_col(bi), xo = bd_origin(B0, limit);
             for (int k = 0; k < BD_WAVES; ++k) {
                 int B[64][32] = {};
-                const int x0 = B0 + 32 * k, cwin = std::min(std::max(x0 - 16, xo), xo + BM_SRC_W - 64);
+                const int x0 = B0 + 32 * k, cwin = std::min(std::max(x0 - 16, xo), xo + BD_SRC_W - 64);
                 for (int n = 0; n < 32 && x0 + n < w; ++n)
                     for (int i = 0; i < 7; ++i) B[reflect101_host(x0 + n + i - 3, w) - cwin][n] += taps[i];
                 for (int s = 0; s < 2; ++s)
@@ -2319,7 +2364,7 @@ void orbx_launch_desc_fused(hipStream_t s, const uint8_t *l0, size_t l0_fs, int 
 {
     if (n_fused_levels <= 0) return;
     int max_nb = 1;
-    for (int l = 0; l < n_fused_levels; ++l) max_nb = std::max(max_nb, tab.n_bx[l] * tab.n_ty[l]);
+    for (int l = 0; l < n_fused_levels; ++l) max_nb = std::max(max_nb, 2 * tab.n_bx[l] * tab.n_ty[l]);
     hipLaunchKernelGGL(k_desc_bins, dim3(n_fused_levels, n_frames), dim3(256), sizeof(int) * (2 * (size_t)max_nb + 1), s, d_levels, tab, b,
                        d_bk_start, bk_stride, reinterpret_cast<BdItem *>(d_items), cap, out_n);
     if (n_blocks <= 0) return;
@@ -2332,12 +2377,12 @@ void orbx_launch_desc_fused(hipStream_t s, const uint8_t *l0, size_t l0_fs, int 
     int K = 0;
     for (int i = 0; i < 7; ++i) K += taps[i];
     if (K == 256)
-        hipLaunchKernelGGL(k_blur_desc<256>, dim3(orbx_xcd_grid(n_blocks, n_frames)), dim3(BM_T), 0, s, src, tab,
+        hipLaunchKernelGGL(k_blur_desc<256>, dim3(orbx_xcd_grid(n_blocks, n_frames)), dim3(BD_T), 0, s, src, tab,
                            reinterpret_cast<const BdBlock *>(d_blocks), reinterpret_cast<const uint4 *>(d_band_h),
                            reinterpret_cast<const uint4 *>(d_band_v), d_bk_start, bk_stride, reinterpret_cast<const BdItem *>(d_items),
                            levels.kcap_total, out_kp, out_desc, cap, n_blocks, n_frames);
     else
-        hipLaunchKernelGGL(k_blur_desc<257>, dim3(orbx_xcd_grid(n_blocks, n_frames)), dim3(BM_T), 0, s, src, tab,
+        hipLaunchKernelGGL(k_blur_desc<257>, dim3(orbx_xcd_grid(n_blocks, n_frames)), dim3(BD_T), 0, s, src, tab,
                            reinterpret_cast<const BdBlock *>(d_blocks), reinterpret_cast<const uint4 *>(d_band_h),
                            reinterpret_cast<const uint4 *>(d_band_v), d_bk_start, bk_stride, reinterpret_cast<const BdItem *>(d_items),
                            levels.kcap_total, out_kp, out_desc, cap, n_blocks, n_frames);

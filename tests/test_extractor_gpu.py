@@ -284,6 +284,33 @@ def test_gaussian_on_the_matrix_pipe(oracle_mod, w, h, blur_variant):
     assert len(kps) == len(okps) and np.array_equal(desc, odesc)
 
 
+@pytest.mark.parametrize("w,h,nf,batch,blur_variant", [(1242, 375, 2000, 1, 0), (752, 480, 1000, 3, 0), (1920, 1080, 2000, 1, 0),
+                                                       (640, 360, 800, 9, 1), (331, 200, 400, 2, 0), (500, 163, 700, 1, 1),
+                                                       (1242, 375, 6000, 2, 0)])
+def test_blur_and_descriptors_in_one_pass(oracle_mod, w, h, nf, batch, blur_variant):
+    """ORBExtractor.cpp:527-532 through k_blur_desc (ORBX_VAR_DESC = 2): a workgroup walks down a block of columns, keeps the
+    blurred rows in an LDS ring and samples the descriptors of the block's key points from it -- no blurred level in memory.
+    Key points and 32-byte descriptors equal the oracle's for both tap sets; widths that end inside a block, levels too
+    narrow for the kernel (they keep the blur pass + k_orient_desc inside the same call), quotas where a bucket holds many
+    key points, frames of a batch.  The blurred-level tap still answers (the blur pass is run for it on demand)."""
+    from monoorbslam3_amd.extractor import ORBExtractor
+    ex = ORBExtractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch, blur_variant=blur_variant,
+                      variants={"desc": "fused"})
+    orc = oracle_mod.Oracle(nf, 1.2, 8, 20, 7, blur_variant=blur_variant)
+    imgs = synth.make_frames(batch, w, h, seed=5 * w + h + nf)
+    if blur_variant == 1:
+        imgs[:, : h // 3, : w // 2] = 255  # saturated area: the sum-257 taps must clamp
+        imgs[:, h // 2:, ::7] ^= 0x5A        # ... and texture beside it
+    out = [ex(imgs[0])] if batch == 1 else ex.extract_batch(imgs)
+    for f in sorted({0, batch - 1}):
+        _check_frame(ex, orc, imgs[f], out[f][0], out[f][1], frame=f, stages=(f == 0))
+    # the two-kernel twin on the same handle gives the same bytes
+    ex.set_variant("desc", "separate")
+    out2 = [ex(imgs[0])] if batch == 1 else ex.extract_batch(imgs)
+    for a, b2 in zip(out, out2):
+        assert np.array_equal(a[0], b2[0]) and np.array_equal(a[1], b2[1])
+
+
 @pytest.mark.parametrize("w,h,nf,n_patches,side", [(1242, 375, 2000, 12, 40), (752, 480, 1000, 6, 30), (640, 200, 3000, 5, 48)])
 def test_quadtree_on_crowded_corners(oracle_mod, w, h, nf, n_patches, side):
     """Every corner of the frame sits in a few small noise patches: the quadtree has to divide seven to nine times before
