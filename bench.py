@@ -55,16 +55,18 @@ def level_bytes(ex, w, h):
     return [a * b for a, b in sizes]
 
 
-def algorithmic_bytes(ex, w, h, kp_per_frame):
-    """Per-frame compulsory HBM bytes of each stage."""
+def algorithmic_bytes(ex, w, h, kp_per_frame, one_pass):
+    """Per-frame compulsory HBM bytes of each stage.  one_pass: the blur and the descriptors run as
+    k_blur_desc (the raw pyramid read once, nothing blurred written); else the blur pass (read P, write P) + k_orient_desc."""
     lb = level_bytes(ex, w, h)
     P, L0, Llast = sum(lb), lb[0], lb[-1]
     return {
         "resize": (P - Llast) + (P - L0),
         "fast": P,
-        "blur": 2 * P,
+        "blur": 0 if one_pass else 2 * P,
         "octree": 0,
-        "orient_desc": min(kp_per_frame * 961, P) + min(kp_per_frame * 1369, P) + kp_per_frame * 60,
+        "orient": min(kp_per_frame * 961, P),
+        "desc": (P if one_pass else min(kp_per_frame * 1369, P)) + kp_per_frame * 60,
     }, P
 
 
@@ -179,6 +181,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-match", action="store_true", help="time extraction only")
+    ap.add_argument("--no-density-sweep", action="store_true",
+                    help="skip the extra (untimed) extraction runs on frames with about a tenth and a third of the headline workload's corner density")
     ap.add_argument("--match-placement", default="eager", choices=["after-fast", "eager"],
                     help="when the match of a batch starts: behind the next batch's FAST stage, beside its latency-bound stages "
                          "(measured: 190.0 k frames/s against 191.5 k eager -- FAST is stretched by the blur and the resize chain beside it, not by "
@@ -473,44 +477,44 @@ def main():
         torch.cuda.synchronize()
         match_ms += ev_m0.elapsed_time(ev_m1) / n_prof
     ex.set_stage_timing(False)
-    # ---- the same kernels timed INSIDE overlapped steps (three streams as in the timed region): FAST by events on its own
-    # launch streams (orbx_set_stage_timing(2)), the match by events on the match stream
-    fast_in_step_ms, match_in_step_ms = None, None
-    if hasattr(ex, "fast_time_in_step_ms"):
-        torch.cuda.synchronize()
-        ex.set_stage_timing(2)
-        accf, accm, n_in = 0.0, 0.0, 6
-        evm = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_in + 2)]
-        prev = None
-        for k in range(n_in + 2):
-            i = step_no[0] % NBUF
-            step_no[0] += 1
-            side.wait_event(ev_matched[i])
-            ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, d_kp[i].data_ptr(), d_desc[i].data_ptr(), cap,
-                                    d_n[i].data_ptr(), stream)
-            ev_extracted[i].record(side)
-            if args.no_match:
-                ev_matched[i].record(mstream)
-            else:
-                j = prev if lagged else i      # the same placement as the timed steps
-                if j is not None:
-                    if lagged:
-                        ex.stream_wait_fast(mstream.cuda_stream)
-                    mstream.wait_event(ev_extracted[j])
-                    evm[k][0].record(mstream)
-                    match(j, mstream.cuda_stream)
-                    evm[k][1].record(mstream)
-                    ev_matched[j].record(mstream)
-                prev = i
-            if k >= 2:  # the FAST events of this step are read before the next step re-records them
-                accf += ex.fast_time_in_step_ms()[0] / n_in
-        if lagged and prev is not None:
-            launch_match(prev)
-        torch.cuda.synchronize()
-        if not args.no_match:
-            accm = sum(evm[k][0].elapsed_time(evm[k][1]) for k in range(2, n_in + 2)) / n_in
-        ex.set_stage_timing(False)
-        fast_in_step_ms, match_in_step_ms = accf, (accm if not args.no_match else None)
+    # ---- the same kernels timed INSIDE overlapped steps (the streams of the timed region): every extractor stage by events on
+    # the stream its kernels are launched on (orbx_set_stage_timing(2)), the match by events on the match stream
+    torch.cuda.synchronize()
+    ex.set_stage_timing(2)
+    n_in = 6
+    acc_in = {}
+    evm = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_in + 2)]
+    prev = None
+    for k in range(n_in + 2):
+        i = step_no[0] % NBUF
+        step_no[0] += 1
+        side.wait_event(ev_matched[i])
+        ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, d_kp[i].data_ptr(), d_desc[i].data_ptr(), cap,
+                                d_n[i].data_ptr(), stream)
+        ev_extracted[i].record(side)
+        if args.no_match:
+            ev_matched[i].record(mstream)
+        else:
+            j = prev if lagged else i      # the same placement as the timed steps
+            if j is not None:
+                if lagged:
+                    ex.stream_wait_fast(mstream.cuda_stream)
+                mstream.wait_event(ev_extracted[j])
+                evm[k][0].record(mstream)
+                match(j, mstream.cuda_stream)
+                evm[k][1].record(mstream)
+                ev_matched[j].record(mstream)
+            prev = i
+        if k >= 2:  # the stage events of this step are read before the next step re-records them
+            for name, v in ex.stage_times_in_step_ms().items():
+                acc_in[name] = acc_in.get(name, 0.0) + v / n_in
+    if lagged and prev is not None:
+        launch_match(prev)
+    torch.cuda.synchronize()
+    match_in_step_ms = None
+    if not args.no_match:
+        match_in_step_ms = sum(evm[k][0].elapsed_time(evm[k][1]) for k in range(2, n_in + 2)) / n_in
+    ex.set_stage_timing(False)
     counts = d_n[0].cpu().numpy()
     # ---- the timed match is checked, not only timed: a sample of frame 0's rows against frame 1 by a numpy popcount scan
     match_check = None
@@ -529,17 +533,20 @@ def main():
         match_check = {"rows": int(len(rows)), "equal_to_numpy_popcount_scan": ok}
         assert ok, "the best/second-best match of the timed step differs from a numpy popcount scan"
     kp_mean = float(counts.mean())
-    alg, P = algorithmic_bytes(ex, W, H, int(round(kp_mean)))
+    one_pass = acc.get("blur", 0.0) < 0.03 * max(acc.get("desc", 0.0), 1e-9)   # no separate blur pass ran: k_blur_desc
+    alg, P = algorithmic_bytes(ex, W, H, int(round(kp_mean)), one_pass)
     stage_gbs = {k: (alg[k] * B / (acc[k] * 1e-3) / 1e9 if acc[k] > 0 and alg[k] > 0 else None) for k in acc}
     acc_all = dict(acc)
     acc_all["match_best2"] = match_ms
     alg["match_best2"] = int(2 * round(kp_mean) * 32 + round(kp_mean) * 8)
     stage_gbs["match_best2"] = alg["match_best2"] * B / (match_ms * 1e-3) / 1e9 if match_ms > 0 else None
-    # `roofline` is reported for the kernel that takes the most time among ALL stages of a step, the match included, by its
-    # time INSIDE an overlapped step where that was measured (FAST, match), else by its isolated time.
+    # `roofline` is reported for the stage that takes the most time INSIDE an overlapped step, by ONE rule for all of them, the
+    # match included: HIP events on the stream(s) each stage's kernels are launched on (a stage that did not run has no entry).
     acc = acc_all
-    in_step = {"fast": fast_in_step_ms, "match_best2": match_in_step_ms}
-    dominant = max(acc, key=lambda k: in_step.get(k) or acc[k])
+    in_step = {k: v for k, v in acc_in.items() if v and v > 0}
+    if match_in_step_ms:
+        in_step["match_best2"] = match_in_step_ms
+    dominant = max(in_step, key=lambda k: in_step[k])
     # HBM bytes / VALU instructions per stage from separate rocprofv3 --pmc passes (tools/profile_round.sh).  They are
     # REPLAYED from files under profiles/, not measured in this run: each carries the hash of the kernel sources it was
     # collected on, and is dropped from the line when the sources have changed since.
@@ -574,7 +581,7 @@ def main():
             fast_mix = fm
     except Exception:
         pass
-    fb_ms = acc["fast"] + acc["orient_desc"]
+    fb_ms = acc["fast"] + acc["orient"] + acc["desc"] + acc["blur"]   # FAST + everything rBRIEF needs (orientation, blur, sampling)
     fast_brief_gbs = 2 * P * B / (fb_ms * 1e-3) / 1e9
     pairs = float((counts.astype(np.float64) * np.roll(counts, -1)).sum())
 
@@ -602,8 +609,8 @@ def main():
             r["launch_ms_in_step"] = round(in_step[k], 4)
             r["achieved_in_step"] = round(gi, 1)
             r["frac_in_step"] = round(gi / HBM_PEAK_GBS, 4)
-            r["in_step_note"] = ("HIP events on the kernel's own stream(s) inside overlapped steps issued one at a time "
-                                 "(the previous step's match still in flight); FAST = its launches summed (two when level 0 starts beside the pyramid)")
+            r["in_step_note"] = ("HIP events on the stage's own launch stream(s) inside overlapped steps issued one at a time "
+                                 "(the previous step's match still in flight); a stage = its launch groups summed")
         if k == "fast" and fast_mix:
             r["limiter"] = {"kind": "valu_issue_mix_weighted", "issue_floor_ms": fast_mix["issue_floor_ms_per_launch"],
                             "frac_of_floor": round(fast_mix["issue_floor_ms_per_launch"] / acc[k], 3),
@@ -624,6 +631,37 @@ def main():
                 r["in_step_note"] += ("; the match shares the machine with the next step's pyramid while it runs, so its in-step "
                                       "time (0.55-0.9 ms, against 0.30 alone) can exceed FAST's and make it the stage reported here")
         return r
+
+    # ---- corner-density sweep (extra key; the headline workload is unchanged): the synthetic frames are corner-rich by design
+    # (every level must exceed its quota) -- 5.5 % of all pyramid pixels are FAST corners at threshold 20 -- and
+    # FAST's sparse stages scale with that.  The same batch size with about a tenth and a third of the shapes shows what the
+    # stage costs at a density closer to a street scene's.  Isolated stage times (one stream), three steps each.
+    density = None
+    if world == 1 and not args.no_density_sweep and (W, H, NF) == (1242, 375, 2000):
+        density = []
+        for n_shapes in (50, 150, None):
+            fb = synth.make_frames(n_distinct, W, H, seed=synth.DEFAULT_SEED + 101 * rank, n_shapes=n_shapes)
+            fr = torch.from_numpy(fb).to(dev)
+            if B > n_distinct:
+                fr = fr.repeat((B + n_distinct - 1) // n_distinct, 1, 1)[:B].contiguous()
+            ex.set_stage_timing(True)
+            accd = {}
+            for it in range(4):
+                ex.extract_batch_device(fr.data_ptr(), B, W, H, W, W * H, d_kp[0].data_ptr(), d_desc[0].data_ptr(), cap, d_n[0].data_ptr(), stream)
+                if it:
+                    for k, v in ex.stage_times_ms().items():
+                        accd[k] = accd.get(k, 0.0) + v / 3
+            torch.cuda.synchronize()
+            ex.set_stage_timing(False)
+            total = sum(accd.values())
+            density.append({"shapes_per_frame": n_shapes if n_shapes is not None else 500,
+                            "fast9_corner_fraction_level0": round(synth.fast9_corner_fraction(fb[0]), 5),
+                            "keypoints_per_frame": round(float(d_n[0].float().mean().item()), 1),
+                            "stages_ms": {k: round(v, 4) for k, v in accd.items()},
+                            "extract_frames_per_s_isolated_stages": round(B / (total * 1e-3), 1),
+                            "fast_algorithmic_GBps": round(P * B / (accd["fast"] * 1e-3) / 1e9, 1),
+                            "fast_frac_of_hbm_peak": round(P * B / (accd["fast"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            del fr
 
     out = {
         "metric": baseline_metric(),
@@ -655,14 +693,17 @@ def main():
                      "fv_nodes_per_frame": round(float(rec["n_fv"][0].float().mean().item()), 1),
                      "grid_items_per_frame": round(float(rec["cell_start"][0][:, -1].float().mean().item()), 1)}
                     if rec else None),
-        "stages_ms": {k: round(v, 4) for k, v in acc.items()},
+        "stages_ms": dict({k: round(v, 4) for k, v in acc.items()}, orient_desc=round(acc["orient"] + acc["desc"], 4)),
+        "descriptor_path": "k_blur_desc (blur + descriptors in one pass, no blurred level written)" if one_pass else "blur pass + k_orient_desc",
         "match_ms": round(match_ms, 4),
         "match_check": match_check,
         "stage_algorithmic_GBps": {k: (round(v, 1) if v else None) for k, v in stage_gbs.items()},
         "stages_ms_note": "HIP events around each stage with every kernel on ONE stream (orbx_set_stage_timing), extra untimed "
                           "steps; the timed steps overlap FAST / blur / match on three streams, so the stages sum to more "
                           "than ms_per_step",
-        "stages_ms_in_step": {k: (round(v, 4) if v else None) for k, v in in_step.items()},
+        "stages_ms_in_step": {k: round(v, 4) for k, v in in_step.items()},
+        "dominant_rule": "the stage with the largest time inside an overlapped step (stages_ms_in_step), one rule for every stage",
+        "density_sweep": density,
         "roofline": roof(dominant),
         "roofline_fast": roof("fast"),
         "roofline_match": dict(roof("match_best2"), mfma=mfma),

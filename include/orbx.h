@@ -148,19 +148,22 @@ int orbx_get_variant(const orbx_t *h, int which, int *value);
 /* ---- per-kernel timing (HIP events on the handle's stream) ---- */
 #define ORBX_STAGE_RESIZE 0
 #define ORBX_STAGE_FAST 1
-#define ORBX_STAGE_BLUR 2
+#define ORBX_STAGE_BLUR 2   /* the separate blur pass (zero when k_blur_desc describes every level) */
 #define ORBX_STAGE_OCTREE 3
-#define ORBX_STAGE_DESC 4
-#define ORBX_N_STAGES 5
+#define ORBX_STAGE_ORIENT 4 /* k_orient + k_angle */
+#define ORBX_STAGE_DESC 5   /* k_desc_bins + k_blur_desc and / or k_orient_desc */
+#define ORBX_N_STAGES 6
 /* enable = 1: every later extract call records HIP events around each stage, with every kernel on ONE stream (isolated
  * stage times).  enable = 2: the call keeps its streams (FAST, blur and the caller's other work overlap as in production) and
- * events on each FAST launch's own stream bracket it: orbx_fast_times_in_step_ms then gives the kernel's time as it runs
- * beside the others. */
+ * events on each stage's own launch stream bracket its launches: orbx_stage_times_in_step_ms then gives every stage's time as it
+ * runs beside the others. */
 int orbx_set_stage_timing(orbx_t *h, int enable);
-/* timing mode 2: sum over the last extract call's FAST launches (one or two: level 0 may start early on the side stream) of
- * the time between the events around each launch, and their number.  Synchronises on those events. */
+/* timing mode 2: per stage, the sum over the last extract call's launch groups of that stage (FAST: one or two, level 0 may
+ * start early on the side stream) of the time between the events around each group.  Synchronises on those events. */
+int orbx_stage_times_in_step_ms(orbx_t *h, float *ms /* ORBX_N_STAGES */);
+/* timing mode 2, FAST only (kept for callers of the earlier interface): sum and number of its launch groups */
 int orbx_fast_times_in_step_ms(orbx_t *h, float *ms_sum, int *n_launches);
-/* milliseconds each stage took in the last extract call (synchronises) */
+/* timing mode 1: milliseconds each stage took in the last extract call (synchronises) */
 int orbx_stage_times_ms(orbx_t *h, float *ms /* ORBX_N_STAGES */);
 
 const char *orbx_last_error(void);

@@ -64,6 +64,7 @@ def lib():
         "orbx_set_stage_timing": (i32, [vp, i32]),
         "orbx_fast_times_in_step_ms": (i32, [vp, C.POINTER(f32), C.POINTER(i32)]),
         "orbx_stage_times_ms": (i32, [vp, vp]),
+        "orbx_stage_times_in_step_ms": (i32, [vp, vp]),
         "orbx_last_error": (C.c_char_p, []),
         "orbx_version": (C.c_char_p, []),
     }

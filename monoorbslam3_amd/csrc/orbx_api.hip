@@ -70,7 +70,8 @@ struct orbx_ctx {
     int resize2;                      // ORBX_VAR_RESIZE2: 0 = never two levels per launch, 1 = calls with few frames (default), 2 = always
     int *d_umax, *d_taps;
     hipEvent_t ev_after_fast; bool after_fast_valid; // recorded behind the FAST launches of every call (orbx_stream_wait_fast)
-    hipEvent_t ev_fast_t[4]; int fast_t_n; // timing mode 2: events around the (up to two) FAST launches of a step
+    // timing mode 2: events around the (up to two) launch groups of every stage of a step, on the stream they are launched on
+    hipEvent_t ev_in[ORBX_N_STAGES][4]; int ev_in_n[ORBX_N_STAGES];
     uint16_t *d_fast_cells; int n_fast_cells;
     uint16_t *d_fast_strips; int n_fast_strips, n_fast_strips0; // strips of all levels / of level 0
     int fast_variant;                                           // ORBX_VAR_FAST: 0 = by call size (default), 1 = one wave per cell, 2 = strips
@@ -548,7 +549,8 @@ extern "C" void orbx_destroy(orbx_t *c)
         if (c->d_ytap[l]) (void)hipFree(c->d_ytap[l]);
     }
     for (int i = 0; i <= ORBX_N_STAGES; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (int i = 0; i < 4; ++i) if (c->ev_fast_t[i]) (void)hipEventDestroy(c->ev_fast_t[i]);
+    for (int st = 0; st < ORBX_N_STAGES; ++st)
+        for (int i = 0; i < 4; ++i) if (c->ev_in[st][i]) (void)hipEventDestroy(c->ev_in[st][i]);
     if (c->ev_after_fast) (void)hipEventDestroy(c->ev_after_fast);
     for (int i = 0; i < 8; ++i) {
         if (c->sub[i]) { (void)hipStreamSynchronize(c->sub[i]); (void)hipStreamDestroy(c->sub[i]); }
@@ -628,6 +630,18 @@ static OrbxBuffers offset_buffers(const OrbxBuffers &a, int f0, int kcap_total)
     return b;
 }
 
+// timing mode 2: a pair of events on stream `st` around what is launched during the object's life (at most two groups per stage)
+struct InStep {
+    orbx_ctx *c; int stage; hipStream_t st; int k;
+    InStep(orbx_ctx *c_, int stage_, hipStream_t st_) : c(c_), stage(stage_), st(st_), k(-1)
+    {
+        if (c->timing != 2 || !c->ev_in[0][0] || c->ev_in_n[stage] >= 2) return;
+        k = c->ev_in_n[stage]++;
+        (void)hipEventRecord(c->ev_in[stage][2 * k], st);
+    }
+    ~InStep() { if (k >= 0) (void)hipEventRecord(c->ev_in[stage][2 * k + 1], st); }
+};
+
 static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs, int l0_pitch, int f0, int n_frames,
                    orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n, bool t, int slot, bool latency)
 {
@@ -676,16 +690,12 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     const uint16_t *d_units = strips ? c->d_fast_strips : c->d_fast_cells;
     const int n_units = strips ? c->n_fast_strips : c->n_fast_cells;
     const int n_cells0 = strips ? c->n_fast_strips0 : LV.lv[0].n_cols * LV.lv[0].n_rows;
-    int fast_launch_no = 0;
     auto launch_fast = [&](hipStream_t st, const uint16_t *units, int n) {
-        // timing mode 2: the step keeps its streams, and HIP events on the launch's own stream bracket each FAST launch, so
-        // that the kernel is timed as it runs beside the others (orbx_fast_times_in_step_ms)
-        const bool ft = c->timing == 2 && fast_launch_no < 2 && c->ev_fast_t[0];
-        if (ft) (void)hipEventRecord(c->ev_fast_t[2 * fast_launch_no], st);
+        // timing mode 2: the step keeps its streams, and HIP events on the launch's own stream bracket each launch group, so
+        // that the kernels are timed as they run beside the others (orbx_stage_times_in_step_ms)
+        InStep ft(c, ORBX_STAGE_FAST, st);
         if (strips) orbx_launch_fast_strips(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, units, n, n_frames);
         else orbx_launch_fast(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, units, n, n_frames);
-        if (ft) { (void)hipEventRecord(c->ev_fast_t[2 * fast_launch_no + 1], st); c->fast_t_n = fast_launch_no + 1; }
-        ++fast_launch_no;
     };
     // 7x7 Gaussian of levels [lb, le): on the matrix pipe for the levels that are large enough when the call is a batch
     // (ORBX_VAR_BLUR = 2 forces it for any batch, 0 switches it off), the VALU kernels for the rest
@@ -697,6 +707,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     auto launch_blur = [&](hipStream_t st, int lb, int le) {
         lb = std::max(lb, fl);
         if (le <= lb) return;
+        InStep bt(c, ORBX_STAGE_BLUR, st);
         const int lm = (c->blur_mfma == 2 || (c->blur_mfma == 1 && n_frames >= 8)) ? std::min(c->blur_mfma_levels, le) : 0;
         if (lm > lb)
             orbx_launch_blur_mfma(st, d_l0, l0_fs, l0_pitch, LV, b, c->blur_tab, c->d_blur_strips, c->blur_strips_before,
@@ -707,12 +718,18 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     };
     // orientation, then the descriptors: k_blur_desc for levels [0, fl), k_orient_desc (behind the blur pass) for the others
     auto launch_desc = [&](hipEvent_t blur_done) {
+        // (stage timing: mode 1 has the boundary recorded by the launcher; mode 2 brackets orientation and descriptors apart,
+        // the launcher's own event standing between them)
+        const bool in2 = c->timing == 2 && c->ev_in[0][0];
+        if (in2) { (void)hipEventRecord(c->ev_in[ORBX_STAGE_ORIENT][0], s); c->ev_in_n[ORBX_STAGE_ORIENT] = 1; }
         orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames,
-                                fl < L ? blur_done : nullptr, fl);
+                                fl < L ? blur_done : nullptr, fl, in2 ? c->ev_in[ORBX_STAGE_ORIENT][1] : (t ? c->ev[ORBX_STAGE_ORIENT + 1] : nullptr));
         if (fl > 0)
             orbx_launch_desc_fused(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->bd_tab, fl, c->d_bd_blocks, c->n_bd_blocks, c->d_bd_band_h,
                                    c->d_band_v, c->d_bd_bk_start + (size_t)f0 * c->bd_bk_stride, c->bd_bk_stride,
                                    c->d_bd_items + (size_t)f0 * 32 * LV.kcap_total, c->taps, d_kp, d_desc, cap, d_n, n_frames);
+        // the descriptor bracket opens at the orientation bracket's closing event (orbx_stage_times_in_step_ms)
+        if (in2) { (void)hipEventRecord(c->ev_in[ORBX_STAGE_DESC][1], s); c->ev_in_n[ORBX_STAGE_DESC] = 1; }
     };
     // Level 0 needs no pyramid, so its FAST can start on the side stream beside the resizes.  That pays next to k_resize (no LDS,
     // 27 VGPRs: its waves fit between FAST's), not next to k_resize_lds, which wants the LDS that FAST's workgroups fill
@@ -770,7 +787,10 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         if (early_fast > 1) // level 0 needs no pyramid for its blur either
             launch_blur(c->side[slot], 0, 1);
     }
-    for (int l = 1; l < L;) l = launch_resize(s, l, nullptr) + 1;
+    {
+        InStep rt(c, ORBX_STAGE_RESIZE, s);
+        for (int l = 1; l < L;) l = launch_resize(s, l, nullptr) + 1;
+    }
     if (t) HIP_TRY(hipEventRecord(c->ev[1], s));
     const bool side = !t && c->side_blur && slot >= 0;
     auto fork_blur = [&]() -> int { // the blur only needs the pyramid: side stream, joined before the descriptor kernel
@@ -797,11 +817,14 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     if (!side)
         launch_blur(s, 0, L);
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));
-    orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, L);
+    {
+        InStep ot(c, ORBX_STAGE_OCTREE, s);
+        orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, L);
+    }
     if (t) HIP_TRY(hipEventRecord(c->ev[4], s));
     if (side && c->side_blur >= 3) { int rc = fork_blur(); if (rc) return rc; } // next to the orientation only
-    launch_desc(side ? c->ev_blur[bslot] : nullptr);
-    if (t) { HIP_TRY(hipEventRecord(c->ev[5], s)); c->ev_valid = true; }
+    launch_desc(side ? c->ev_blur[bslot] : nullptr); // (records ev[5] between orientation and descriptors when timed)
+    if (t) { HIP_TRY(hipEventRecord(c->ev[ORBX_N_STAGES], s)); c->ev_valid = true; }
     HIP_TRY(hipGetLastError());
     return ORBX_OK;
 }
@@ -812,6 +835,7 @@ static int enqueue_batch(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t
                          orbx_kp *d_kp, uint8_t *d_desc, int cap, int32_t *d_n, bool latency)
 {
     c->last_l0 = d_l0; c->last_l0_fs = l0_fs; c->last_l0_pitch = l0_pitch; c->last_frames = n_frames;
+    for (int i = 0; i < ORBX_N_STAGES; ++i) c->ev_in_n[i] = 0;
     const int ns = c->timing == 1 ? 1 : std::min(c->n_sub, n_frames / 8);
     if (ns <= 1) return enqueue(c, s, d_l0, l0_fs, l0_pitch, 0, n_frames, d_kp, d_desc, cap, d_n, c->timing == 1, 8, latency);
     HIP_TRY(hipEventRecord(c->ev_fork, s));
@@ -1058,10 +1082,11 @@ extern "C" int orbx_set_stage_timing(orbx_t *c, int enable)
     if (!c) return fail(ORBX_E_ARG, "null handle");
     c->timing = enable;
     c->ev_valid = false;
-    c->fast_t_n = 0;
-    if (enable == 2 && !c->ev_fast_t[0]) {
+    for (int i = 0; i < ORBX_N_STAGES; ++i) c->ev_in_n[i] = 0;
+    if (enable == 2 && !c->ev_in[0][0]) {
         HIP_TRY(hipSetDevice(c->device));
-        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&c->ev_fast_t[i]));
+        for (int st = ORBX_N_STAGES - 1; st >= 0; --st) // [0][0] last: it marks the set as complete
+            for (int i = 3; i >= 0; --i) HIP_TRY(hipEventCreate(&c->ev_in[st][i]));
     }
     return ORBX_OK;
 }
@@ -1075,20 +1100,33 @@ extern "C" int orbx_stream_wait_fast(orbx_t *c, void *stream)
     return ORBX_OK;
 }
 
+extern "C" int orbx_stage_times_in_step_ms(orbx_t *c, float *ms)
+{
+    if (!c || !ms) return fail(ORBX_E_ARG, "null argument");
+    if (c->timing != 2 || c->ev_in_n[ORBX_STAGE_FAST] < 1) return fail(ORBX_E_ARG, "no extract call in timing mode 2 yet");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int st = 0; st < ORBX_N_STAGES; ++st) {
+        ms[st] = 0.f;
+        for (int i = 0; i < c->ev_in_n[st]; ++i) {
+            float t = 0.f;
+            // the descriptor bracket opens where the orientation bracket closes
+            hipEvent_t e0 = st == ORBX_STAGE_DESC ? c->ev_in[ORBX_STAGE_ORIENT][1] : c->ev_in[st][2 * i];
+            HIP_TRY(hipEventSynchronize(c->ev_in[st][2 * i + 1]));
+            HIP_TRY(hipEventElapsedTime(&t, e0, c->ev_in[st][2 * i + 1]));
+            ms[st] += t;
+        }
+    }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_fast_times_in_step_ms(orbx_t *c, float *ms_sum, int *n_launches)
 {
     if (!c || !ms_sum) return fail(ORBX_E_ARG, "null argument");
-    if (c->timing != 2 || c->fast_t_n < 1) return fail(ORBX_E_ARG, "no extract call in timing mode 2 yet");
-    HIP_TRY(hipSetDevice(c->device));
-    float sum = 0.f;
-    for (int i = 0; i < c->fast_t_n; ++i) {
-        float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(c->ev_fast_t[2 * i + 1]));
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev_fast_t[2 * i], c->ev_fast_t[2 * i + 1]));
-        sum += ms;
-    }
-    *ms_sum = sum;
-    if (n_launches) *n_launches = c->fast_t_n;
+    float ms[ORBX_N_STAGES];
+    int rc = orbx_stage_times_in_step_ms(c, ms);
+    if (rc) return rc;
+    *ms_sum = ms[ORBX_STAGE_FAST];
+    if (n_launches) *n_launches = c->ev_in_n[ORBX_STAGE_FAST];
     return ORBX_OK;
 }
 

@@ -1987,7 +1987,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
 
 void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
-                             uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done, int desc_level_min)
+                             uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done, int desc_level_min,
+                             hipEvent_t after_orient)
 {
     const int pf_o = (levels.kcap_total + OR_KP - 1) / OR_KP;
     OrientLevels tab;
@@ -2005,6 +2006,7 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
         hipLaunchKernelGGL(k_angle, dim3((unsigned)(((size_t)levels.kcap_total * n_frames + 255) / 256)), dim3(256), 0, s, d_levels,
                            b, n_frames);
     }
+    if (after_orient) (void)hipEventRecord(after_orient, s); // stage timing: orientation | descriptors
     if (desc_level_min >= levels.n_levels) return; // every level is described by k_blur_desc (orbx_launch_desc_fused)
     if (blur_done) (void)hipStreamWaitEvent(s, blur_done, 0); // the blurred levels come from a side stream
     DescTab dt;

@@ -15,7 +15,7 @@ from . import _lib
 # cv::KeyPoint layout (28 bytes)
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
-STAGES = ("resize", "fast", "blur", "octree", "orient_desc")
+STAGES = ("resize", "fast", "blur", "octree", "orient", "desc")
 # kernel-choice switches of include/orbx.h (ORBX_VAR_*): name -> (index, named values)
 VARIANTS = {
     "fast": (0, {"auto": 0, "cells": 1, "strips": 2}),
@@ -219,6 +219,12 @@ class ORBExtractor:
         ms, n = C.c_float(), C.c_int()
         _lib.check(self._L.orbx_fast_times_in_step_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def stage_times_in_step_ms(self):
+        """Timing mode 2: every stage of the last call, timed by events on the streams its kernels were launched on."""
+        ms = np.zeros(len(STAGES), np.float32)
+        _lib.check(self._L.orbx_stage_times_in_step_ms(self._h, _vp(ms)))
+        return dict(zip(STAGES, ms.tolist()))
 
     def stage_times_ms(self):
         ms = np.zeros(len(STAGES), np.float32)

@@ -77,12 +77,15 @@ def make_canvas(width, height, seed=DEFAULT_SEED, n_shapes=None):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
-def make_frames(n, width, height, seed=DEFAULT_SEED):
+def make_frames(n, width, height, seed=DEFAULT_SEED, n_shapes=None):
     """n distinct frames (n, height, width) u8: shifted crops of one larger canvas
-    plus per-frame +-2 noise, cheap enough for batches of hundreds."""
+    plus per-frame +-2 noise, cheap enough for batches of hundreds.  n_shapes (default: the corner-rich calibration of
+    make_canvas, ~500 per 1242x375) sets the corner density: ~50 / 150 give about a tenth / a third of it."""
     rng = np.random.RandomState(seed + 7)
     mx, my = 64, 48
-    canvas = make_canvas(width + mx, height + my, seed)
+    if n_shapes is not None:
+        n_shapes = int(round(n_shapes * (width + mx) * (height + my) / (1242.0 * 375.0)))
+    canvas = make_canvas(width + mx, height + my, seed, n_shapes=n_shapes)
     out = np.empty((n, height, width), dtype=np.uint8)
     for i in range(n):
         ox = rng.randint(0, mx + 1)
@@ -92,6 +95,25 @@ def make_frames(n, width, height, seed=DEFAULT_SEED):
             f = f + rng.randint(-2, 3, size=f.shape).astype(np.int16)
         out[i] = np.clip(f, 0, 255).astype(np.uint8)
     return out
+
+
+def fast9_corner_fraction(img, threshold=20):
+    """Fraction of the pixels of `img` (3-px frame excluded) that are FAST-9/16 corners at `threshold` (numpy, for reporting the
+    density of a synthetic workload; not used by any parity check)."""
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0),
+            (-3, 1), (-2, 2), (-1, 3)]
+    im = np.asarray(img).astype(np.int16)
+    h, w = im.shape
+    v = im[3:h - 3, 3:w - 3]
+    p = np.stack([im[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] for dx, dy in ring])
+    out = np.zeros(v.shape, bool)
+    for fl in (p < v - threshold, p > v + threshold):
+        ext = np.concatenate([fl, fl[:8]])
+        run = np.ones((16,) + v.shape, bool)
+        for i in range(9):
+            run &= ext[i:i + 16]
+        out |= run.any(axis=0)
+    return float(out.mean())
 
 
 def make_descriptor_pair(n, seed=DEFAULT_SEED, flip_p=0.1):

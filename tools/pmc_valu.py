@@ -11,8 +11,8 @@ from collections import defaultdict
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from monoorbslam3_amd._lib import kernels_sha16  # noqa: E402  (hash of the kernel sources the counters belong to)
 
-STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_fast_strip": "fast", "k_blur_cols": "blur", "k_blur_edges": "blur", "k_blur_mfma": "blur", "k_angle": "orient_desc",
-         "k_octree_lds": "octree", "k_octree": "octree", "k_orient": "orient_desc", "k_orient_desc": "orient_desc",
+STAGE = {"k_resize": "resize", "k_fast_cells_wave": "fast", "k_fast_strip": "fast", "k_blur_cols": "blur", "k_blur_edges": "blur", "k_blur_mfma": "blur", "k_angle": "orient",
+         "k_octree_lds": "octree", "k_octree": "octree", "k_orient": "orient", "k_orient_desc": "desc", "k_blur_desc": "desc", "k_desc_bins": "desc",
          "k_best2": "match_best2", "k_best2_mfma": "match_best2", "k_best2_fp4": "match_best2", "k_resize2": "resize", "k_resize_lds": "resize"}
 def kname(full):
     """'void k_blur_mfma<256>(FastSrc, ...)' -> 'k_blur_mfma'"""
