@@ -722,12 +722,15 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         // the launcher's own event standing between them)
         const bool in2 = c->timing == 2 && c->ev_in[0][0];
         if (in2) { (void)hipEventRecord(c->ev_in[ORBX_STAGE_ORIENT][0], s); c->ev_in_n[ORBX_STAGE_ORIENT] = 1; }
+        int *bk = c->d_bd_bk_start + (size_t)f0 * c->bd_bk_stride;
+        uint8_t *items = c->d_bd_items + (size_t)f0 * 32 * LV.kcap_total;
+        if (fl > 0) orbx_launch_desc_bins(s, c->d_levels, b, c->bd_tab, fl, bk, c->bd_bk_stride, items, cap, d_n, n_frames);
         orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames,
-                                fl < L ? blur_done : nullptr, fl, in2 ? c->ev_in[ORBX_STAGE_ORIENT][1] : (t ? c->ev[ORBX_STAGE_ORIENT + 1] : nullptr));
+                                fl < L ? blur_done : nullptr, fl, in2 ? c->ev_in[ORBX_STAGE_ORIENT][1] : (t ? c->ev[ORBX_STAGE_ORIENT + 1] : nullptr),
+                                fl > 0 ? items : nullptr);
         if (fl > 0)
-            orbx_launch_desc_fused(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->bd_tab, fl, c->d_bd_blocks, c->n_bd_blocks, c->d_bd_band_h,
-                                   c->d_band_v, c->d_bd_bk_start + (size_t)f0 * c->bd_bk_stride, c->bd_bk_stride,
-                                   c->d_bd_items + (size_t)f0 * 32 * LV.kcap_total, c->taps, d_kp, d_desc, cap, d_n, n_frames);
+            orbx_launch_desc_fused(s, d_l0, l0_fs, l0_pitch, LV, b, c->bd_tab, fl, c->d_bd_blocks, c->n_bd_blocks, c->d_bd_band_h, c->d_band_v,
+                                   bk, c->bd_bk_stride, items, c->taps, d_kp, d_desc, cap, n_frames);
         // the descriptor bracket opens at the orientation bracket's closing event (orbx_stage_times_in_step_ms)
         if (in2) { (void)hipEventRecord(c->ev_in[ORBX_STAGE_DESC][1], s); c->ev_in_n[ORBX_STAGE_DESC] = 1; }
     };

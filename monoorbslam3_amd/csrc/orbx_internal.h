@@ -124,14 +124,17 @@ struct BdLevels {
 };
 void orbx_build_blur_desc(const OrbxLevels &levels, const int taps[7], const BlurMfmaLevels &mf, std::vector<uint16_t> &blocks,
                           std::vector<uint8_t> &band_h, BdLevels &out, int *n_fused_levels, int *bk_stride);
-// k_desc_bins + k_blur_desc for levels [0, n_fused_levels); d_items: 32 bytes per key-point slot and frame, d_bk_start: bk_stride ints per frame
-void orbx_launch_desc_fused(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
-                            const OrbxLevels &levels, const OrbxBuffers &b, const BdLevels &tab, int n_fused_levels, const void *d_blocks,
-                            int n_blocks, const void *d_band_h, const void *d_band_v, int *d_bk_start, int bk_stride, void *d_items,
-                            const int taps[7], orbx_kp *out_kp, uint8_t *out_desc, int cap, int32_t *out_n, int n_frames);
+// k_desc_bins (before the orientation: it fixes the order the key points of levels [0, n_fused_levels) are processed in) and
+// k_blur_desc (after it); d_items: 32 bytes per key-point slot and frame, d_bk_start: bk_stride ints per frame
+void orbx_launch_desc_bins(hipStream_t s, const OrbxLevels *d_levels, const OrbxBuffers &b, const BdLevels &tab, int n_fused_levels,
+                           int *d_bk_start, int bk_stride, void *d_items, int cap, int32_t *out_n, int n_frames);
+void orbx_launch_desc_fused(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels &levels, const OrbxBuffers &b,
+                            const BdLevels &tab, int n_fused_levels, const void *d_blocks, int n_blocks, const void *d_band_h,
+                            const void *d_band_v, const int *d_bk_start, int bk_stride, const void *d_items, const int taps[7],
+                            orbx_kp *out_kp, uint8_t *out_desc, int cap, int n_frames);
 void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLevels &levels, const OrbxBuffers &b,
                         int n_frames, size_t sort_lds_bytes, int level_begin, int level_end);
 void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
                              uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done, int desc_level_min = 0,
-                             hipEvent_t after_orient = nullptr);
+                             hipEvent_t after_orient = nullptr, void *d_items = nullptr);

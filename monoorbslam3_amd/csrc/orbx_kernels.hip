@@ -968,6 +968,8 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
                     FS_WAVE_ORDER();
                     while (cq_tail - cq_head >= 64) { stage_score(64); FS_WAVE_ORDER(); }
                 }
+                // more corners than the list holds already: the rest of the pass would be thrown away with it
+                if (list_n > FS_LIST) { FS_COUNT(9, 1); return false; }
             }
         }
         while (iq_tail > iq_head) {
@@ -977,7 +979,7 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         }
         while (cq_tail > cq_head) { stage_score(min(cq_tail - cq_head, 64)); FS_WAVE_ORDER(); }
 
-        if (list_n > FS_LIST) return false; // more corners than the list holds: the caller redoes the range in narrow pieces
+        if (list_n > FS_LIST) { FS_COUNT(9, 1); return false; } // more corners than the list holds: the caller redoes the range in pieces
 
         // ---- stage 5: the score map takes the tile's place (every stage that reads pixels has drained), then the strict
         // 3x3 NMS inside each cell, and the keepers with a column in [out_lo, out_hi) leave
@@ -1028,18 +1030,27 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
     // is redone in ranges of FS_NARROW columns, each computed with one more column either side so that the 3x3
     // neighbourhoods of its own columns are complete.
     thr = levels->ini_th;
-    int lo = 0, hi = Ws, cell = -1, narrow = -1; // narrow >= 0: first column of the next narrow range of [lo, hi)
+    // narrow >= 0: first column of the next piece of [lo, hi), nw its width.  A range that overflowed is first redone in pieces of
+    // two cells (the dense upper levels hold 550-650 corners per four-cell strip: two passes instead of eight thin ones), and
+    // only a piece that overflows again in slices of FS_NARROW columns, which always fit.
+    int lo = 0, hi = Ws, cell = -1, narrow = -1, nw = FS_NARROW;
     bool retry = false;
     for (;;) {
         int clo = lo, chi = hi, olo = lo, ohi = hi;
         if (narrow >= 0) {
-            olo = narrow; ohi = min(narrow + FS_NARROW, hi);
+            olo = narrow; ohi = min(narrow + nw, hi);
             clo = max(olo - 1, 0); chi = min(ohi + 1, Ws);
         }
         load_tile();
-        if (!run_pass(clo, chi, olo, ohi)) { narrow = lo; continue; } // cannot happen for a narrow range
+        if (narrow >= 0) FS_COUNT(10, 1);
+        if (retry) FS_COUNT(11, 1);
+        if (!run_pass(clo, chi, olo, ohi)) {
+            if (narrow < 0) { narrow = lo; nw = hi - lo > 2 * ORBX_CELL ? 2 * ORBX_CELL : FS_NARROW; }
+            else nw = FS_NARROW; // (cannot happen for a slice of FS_NARROW columns)
+            continue;
+        }
         if (narrow >= 0) {
-            narrow += FS_NARROW;
+            narrow += nw;
             if (narrow < hi) continue;
             narrow = -1;
         }
@@ -1693,7 +1704,8 @@ struct OrientLevels { // what k_orient needs of every level, passed by value so 
 template <bool WITH_ANGLE> // true (calls with a few frames): the lane that holds the moments also does k_angle's work -- one launch less
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, size_t l0_fs, int l0_pitch,
                                                 const OrbxLevels *__restrict__ levels, OrientLevels tab, OrbxBuffers b,
-                                                const int *__restrict__ u_max, int per_frame, int n_frames)
+                                                const int *__restrict__ u_max, int per_frame, int n_frames,
+                                                const uint4 *__restrict__ items, int item_levels)
 {
     // byte masks of the circular patch, one 16-byte row per (row, half) task: they depend on the task only, so they are
     // built once per workgroup (thread = (task, dword)) instead of per key point
@@ -1713,7 +1725,10 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, 
     // counts, from which level, pitch and offset are SELECTED rather than gathered: one memory round trip, not four.
     const int mt = tid >> 2, mw = tid & 3, mv = min(mt >> 1, 2 * ORBX_HALF_PATCH) - ORBX_HALF_PATCH;
     const int md_raw = u_max[mv < 0 ? -mv : mv];
-    const uint2 rec = b.sel[(size_t)frame * kc + min(slot, kc - 1)];
+    uint2 rec = b.sel[(size_t)frame * kc + min(slot, kc - 1)];
+    // levels below item_levels: slot s is the s-th key point of its level in k_desc_bins' (block, trip) order -- neighbours in
+    // the image are neighbours in the list, so a workgroup's patches overlap in the L1 -- and the moments go back by that index
+    const uint32_t item_xy = items ? items[2 * ((size_t)frame * kc + min(slot, kc - 1))].x : 0u;
     int level = 0, rpitch = l0_pitch, cnt = cnts[0], kp_off = 0;
     size_t raw_off = 0;
 #pragma unroll
@@ -1726,6 +1741,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, 
         cnt = ge ? cnts[l] : cnt;
     }
     const bool live = slot < kc && (slot - kp_off) < cnt;
+    if (level < item_levels) rec.x = item_xy;
     {
         const int d = mt < 2 * (2 * ORBX_HALF_PATCH + 1) ? md_raw : -1;
         // right half keeps bytes idx <= d (idx = 4w + byte), left half keeps idx >= 16 - d
@@ -1793,7 +1809,8 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, 
 }
 
 // IC_Angle's last line (reference :41) and the sine / cosine of computeOrbDescriptor (:54), one thread per key-point slot
-__global__ __launch_bounds__(256) void k_angle(const OrbxLevels *__restrict__ levels, OrbxBuffers b, int n_frames)
+__global__ __launch_bounds__(256) void k_angle(const OrbxLevels *__restrict__ levels, OrbxBuffers b, int n_frames, float4 *__restrict__ items,
+                                               int item_levels)
 {
     const int kc = levels->kcap_total;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1802,7 +1819,13 @@ __global__ __launch_bounds__(256) void k_angle(const OrbxLevels *__restrict__ le
     const float ang = orb_fast_atan2((float)__float_as_int(m.y), (float)__float_as_int(m.x));
     float cs, sn;
     orb_sincos_deg(ang, &cs, &sn);
-    b.kp_ang[i] = make_float4(ang, cs, sn, 0.f);
+    if (items && b.slot_level[i % (size_t)kc] < item_levels) { // k_blur_desc's record: (xy, out_idx, angle, cos | sin, response, -, -)
+        float4 lo = items[2 * i], hi = items[2 * i + 1];
+        lo.z = ang; lo.w = cs; hi.x = sn;
+        items[2 * i] = lo; items[2 * i + 1] = hi;
+    } else {
+        b.kp_ang[i] = make_float4(ang, cs, sn, 0.f);
+    }
 }
 
 // parity tap: the device's (cos, sin) of the descriptor rotation on caller-supplied angles (orbx_tap_sincos)
@@ -1988,7 +2011,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
 void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
                              uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done, int desc_level_min,
-                             hipEvent_t after_orient)
+                             hipEvent_t after_orient, void *d_items)
 {
     const int pf_o = (levels.kcap_total + OR_KP - 1) / OR_KP;
     OrientLevels tab;
@@ -1997,14 +2020,17 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
         tab.pitch[l] = l < levels.n_levels ? levels.lv[l].pitch : 0;
         tab.raw_off[l] = l < levels.n_levels ? (unsigned long long)levels.lv[l].raw_off : 0ull;
     }
-    if (n_frames < 24) { // latency-bound: one launch
+    // d_items (levels [0, desc_level_min) are described by k_blur_desc): key points of those levels are taken in k_desc_bins' order
+    // and their angles go into the item records
+    const int item_levels = d_items ? desc_level_min : 0;
+    if (n_frames < 24 && !item_levels) { // latency-bound: one launch
         hipLaunchKernelGGL(k_orient<true>, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, tab,
-                           b, u_max, pf_o, n_frames);
+                           b, u_max, pf_o, n_frames, nullptr, 0);
     } else {
         hipLaunchKernelGGL(k_orient<false>, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, tab,
-                           b, u_max, pf_o, n_frames);
+                           b, u_max, pf_o, n_frames, reinterpret_cast<const uint4 *>(item_levels ? d_items : nullptr), item_levels);
         hipLaunchKernelGGL(k_angle, dim3((unsigned)(((size_t)levels.kcap_total * n_frames + 255) / 256)), dim3(256), 0, s, d_levels,
-                           b, n_frames);
+                           b, n_frames, reinterpret_cast<float4 *>(item_levels ? d_items : nullptr), item_levels);
     }
     if (after_orient) (void)hipEventRecord(after_orient, s); // stage timing: orientation | descriptors
     if (desc_level_min >= levels.n_levels) return; // every level is described by k_blur_desc (orbx_launch_desc_fused)
@@ -2084,7 +2110,8 @@ __host__ __device__ __forceinline__ int bd_sub_bucket(int x, int y, int n_ty)
 }
 
 // Buckets the selected key points of one (frame, level) by (block, trip) -- a counting sort in LDS -- and writes their item
-// records; also the frame's total count (what k_orient_desc's first workgroup does on the two-kernel path).
+// records (position, output slot, response; k_orient / k_angle, which run over the items in this order, add the angle);
+// also the frame's total count (what k_orient_desc's first workgroup does on the two-kernel path).
 __global__ __launch_bounds__(256) void k_desc_bins(const OrbxLevels *__restrict__ levels, BdLevels lv, OrbxBuffers b,
                                                    int *__restrict__ bk_start, int bk_stride, BdItem *__restrict__ items, int cap,
                                                    int32_t *__restrict__ out_n)
@@ -2132,14 +2159,15 @@ __global__ __launch_bounds__(256) void k_desc_bins(const OrbxLevels *__restrict_
     for (int i = tid; i < nb; i += 256) { gs[i] = kp_off + start[i]; cursor[i] = start[i]; }
     if (tid == 0) gs[nb] = kp_off + n;
     __syncthreads();
-    const int before = b.sel_prefix[frame * ORBX_MAX_LEVELS + level];
+    int before = 0; // key points of the levels below: this level's records start there (k_orient writes the same prefix for k_orient_desc)
+    for (int l = 0; l < level; ++l) before += cnts[l];
     for (int i = tid; i < n; i += 256) {
         const uint2 rec = sel[i];
-        const float4 ang = b.kp_ang[(size_t)frame * kc + kp_off + i];
         const int pos = atomicAdd(&cursor[bd_sub_bucket((int)(rec.x & 0xFFFF), (int)(rec.x >> 16), n_ty)], 1);
         BdItem it;
         it.xy = rec.x; it.out_idx = before + i < cap ? before + i : -1;
-        it.angle = ang.x; it.cs = ang.y; it.sn = ang.z; it.response = (float)rec.y; it.pad[0] = it.pad[1] = 0;
+        it.angle = 0.f; it.cs = 1.f; it.sn = 0.f; // k_angle fills these in (the orientation runs over the items in this order)
+        it.response = (float)rec.y; it.pad[0] = it.pad[1] = 0;
         items[(size_t)frame * kc + kp_off + pos] = it;
     }
 }
@@ -2359,17 +2387,22 @@ void orbx_build_blur_desc(const OrbxLevels &levels, const int taps[7], const Blu
     *bk_stride = std::max(buckets, 1);
 }
 
-void orbx_launch_desc_fused(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
-                            const OrbxLevels &levels, const OrbxBuffers &b, const BdLevels &tab, int n_fused_levels, const void *d_blocks,
-                            int n_blocks, const void *d_band_h, const void *d_band_v, int *d_bk_start, int bk_stride, void *d_items,
-                            const int taps[7], orbx_kp *out_kp, uint8_t *out_desc, int cap, int32_t *out_n, int n_frames)
+void orbx_launch_desc_bins(hipStream_t s, const OrbxLevels *d_levels, const OrbxBuffers &b, const BdLevels &tab, int n_fused_levels,
+                           int *d_bk_start, int bk_stride, void *d_items, int cap, int32_t *out_n, int n_frames)
 {
     if (n_fused_levels <= 0) return;
     int max_nb = 1;
     for (int l = 0; l < n_fused_levels; ++l) max_nb = std::max(max_nb, 2 * tab.n_bx[l] * tab.n_ty[l]);
     hipLaunchKernelGGL(k_desc_bins, dim3(n_fused_levels, n_frames), dim3(256), sizeof(int) * (2 * (size_t)max_nb + 1), s, d_levels, tab, b,
                        d_bk_start, bk_stride, reinterpret_cast<BdItem *>(d_items), cap, out_n);
-    if (n_blocks <= 0) return;
+}
+
+void orbx_launch_desc_fused(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels &levels, const OrbxBuffers &b,
+                            const BdLevels &tab, int n_fused_levels, const void *d_blocks, int n_blocks, const void *d_band_h,
+                            const void *d_band_v, const int *d_bk_start, int bk_stride, const void *d_items, const int taps[7],
+                            orbx_kp *out_kp, uint8_t *out_desc, int cap, int n_frames)
+{
+    if (n_fused_levels <= 0 || n_blocks <= 0) return;
     FastSrc src;
     for (int l = 0; l < levels.n_levels; ++l) {
         src.base[l] = l == 0 ? l0 : b.img_arena + levels.lv[l].raw_off;

@@ -43,7 +43,8 @@ ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, kp.data_ptr(), de.
 _lib.check(L.orbx_dev_fast_prof(ex._h, out.ctypes.data, 1))           # warm-up discarded
 ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, kp.data_ptr(), de.data_ptr(), cap, n.data_ptr(), st)
 _lib.check(L.orbx_dev_fast_prof(ex._h, out.ctypes.data, 1))
-names = ["strips", "tile_loads", "compass_steps", "arc_batches", "score_batches", "nms_batches", "passes", "items", "pixels"]
+names = ["strips", "tile_loads", "compass_steps", "arc_batches", "score_batches", "nms_batches", "passes", "items", "pixels",
+         "passes_overflowed", "narrow_passes", "retry_passes"]
 res = {k: int(v) for k, v in zip(names, out)}
 res["frames"] = B
 print(res)
