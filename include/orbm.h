@@ -164,6 +164,33 @@ int orbm_window_lists_device(orbm_t *h, const void *d_kps, const uint8_t *d_desc
                              const int32_t *d_q_max_level, const uint8_t *d_q_ok, int nq, int strict,
                              const float *d_sigma2, int cap, int32_t *d_counts, uint32_t *d_lists, void *stream);
 
+/* SearchByBow (Tracking.cpp:262 -> ORBMatcher.cpp:118-201) and SearchForTriangulation (LocalMapping.cpp:168 -> :417-522) on
+ * device-resident records, greedy pass included: descriptors and key-point records (orbx_kp: the angle is read from them) as
+ * orbx_extract_batch_device leaves them, the two
+ * FeatureVectors as orbv_transform_device leaves them (node ids ascending, CSR offsets, feature indices, the node COUNT in device
+ * memory), so the BoW branch of the tracking thread -- extract, computeBow, SearchByBow -- has no host hop either.
+ *   d_kf_mp_ok [n1]   key-frame features that have a live map point (:141-146): the queries
+ *   d_frame_mp [n2]   in / out as in the host entry point: -1 = free; a match writes the key-frame feature index
+ *   d_has_mp1 / d_has_mp2: features that already have a map point (skipped, :452 / :466); d_matches12 [n1] receives the matches
+ * A feature of side 2 lies in one vocabulary node, so the reference's order-dependent loop only couples queries of the same
+ * node: every node is resolved by its own workgroup with the fixed point of the projection searches below, on the 8 closest
+ * initially-free candidates per query (a query whose list is used up rescans its node on the device).  Rotation histogram
+ * (the reference's 1/30 factor) and ComputeThreeMaxima on the device as well.
+ * d_result (int32 x 8, device): [0] matches, [1] = 1 if a node holds more than 4096 features on a side (that node is skipped:
+ * use the host entry point), [2] the most sweeps a node needed, [3] matches before the rotation filter.
+ * One call in flight per handle (the scratch is the handle's).  Enqueued on `stream` (NULL = the handle's); no host wait. */
+int orbm_search_by_bow_device(orbm_t *h, float nn_ratio, int check_orientation, const uint8_t *d_desc1, const void *d_kps1,
+                              const uint8_t *d_kf_mp_ok, int n1, const uint32_t *d_fv1_nodes, const int32_t *d_fv1_off,
+                              const uint32_t *d_fv1_idx, const int32_t *d_n_fv1, const uint8_t *d_desc2, const void *d_kps2,
+                              int32_t *d_frame_mp, int n2, const uint32_t *d_fv2_nodes, const int32_t *d_fv2_off,
+                              const uint32_t *d_fv2_idx, const int32_t *d_n_fv2, int32_t *d_result, void *stream);
+int orbm_search_for_triangulation_device(orbm_t *h, int check_orientation, const uint8_t *d_desc1, const void *d_kps1,
+                                         const uint8_t *d_has_mp1, int n1, const uint32_t *d_fv1_nodes, const int32_t *d_fv1_off,
+                                         const uint32_t *d_fv1_idx, const int32_t *d_n_fv1, const uint8_t *d_desc2,
+                                         const void *d_kps2, const uint8_t *d_has_mp2, int n2, const uint32_t *d_fv2_nodes,
+                                         const int32_t *d_fv2_off, const uint32_t *d_fv2_idx, const int32_t *d_n_fv2,
+                                         int32_t *d_matches12, int32_t *d_result, void *stream);
+
 /* The two SearchByProjection calls of the tracking thread (Tracking.cpp:289-336) on a device-resident frame record, greedy
  * pass included (modules/ORB/ORBMatcher.cpp:229-246 and :379-407): nothing returns to the host between the extraction,
  * orbf_frame_post_device and the matched map points.  Queries (device arrays, as the host entry points above take them):

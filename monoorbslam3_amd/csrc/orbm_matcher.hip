@@ -965,6 +965,260 @@ __global__ void k_projection_levels(const int32_t *__restrict__ lv, int n, int h
     if (i < n) { lo_out[i] = lv[i] - 1; hi_out[i] = lv[i] + hi; }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// SearchByBow / SearchForTriangulation on device-resident frame records (ORBMatcher.cpp:136-185, :448-506): the node join,
+// the candidate lists, the greedy pass, the rotation histogram and ComputeThreeMaxima without a host hop.
+//   k_bow_queries   one workgroup: joins the two FeatureVectors (binary search of every node of side 1 in side 2), counts the
+//                   usable features per shared node, prefix sum, and writes one query per (shared node, usable feature) in
+//                   the reference's order -- nodes ascending, features of a node in list order
+//   k_topk_lists    (above) the K closest initially-free candidates of every query, sorted
+//   k_bow_resolve   a feature of side 2 belongs to ONE node, so queries of different nodes never compete: one workgroup per
+//                   node runs k_projection_resolve's fixed point on the node's queries (query i sees a candidate as free iff
+//                   no query j < i of the node currently holds it); a query whose sorted list is used up before it is decided
+//                   rescans its node with distances computed on the spot (rare: the list's last distance bounds the unseen
+//                   ones, as in the host replay).  Accepted matches go to frame_mp / matches12 and into the histogram.
+//   k_bow_finish    ComputeThreeMaxima and the removal of the matches outside the three main bins; the counters.
+// MODE 0 = SearchByBow (best / second, :164 ratio test in float), MODE 1 = SearchForTriangulation (best only, strict < TH_LOW,
+// `bestIdx2 > 0`, :484).
+// ---------------------------------------------------------------------------------------------
+#define BQ_T 1024
+struct BowFv { const uint32_t *nodes; const int32_t *off; const uint32_t *idx; const int32_t *n_nodes; }; // a FeatureVector as orbv leaves it
+__global__ __launch_bounds__(BQ_T) void k_bow_queries(BowFv f1, BowFv f2, const uint8_t *__restrict__ mask1, int mask_polarity, int n1,
+                                                      int max_nodes, int32_t *__restrict__ node_p2, int32_t *__restrict__ node_qbegin,
+                                                      int32_t *__restrict__ q_idx, int32_t *__restrict__ c_begin, int32_t *__restrict__ c_len,
+                                                      int32_t *__restrict__ q_node, int32_t *__restrict__ n_queries)
+{
+    __shared__ int s_part[BQ_T];
+    const int tid = threadIdx.x;
+    const int nn1 = min(*f1.n_nodes, max_nodes), nn2 = *f2.n_nodes;
+    // usable features per node of side 1 that side 2 shares (mask_polarity 1: mask must be set; 0: must be clear)
+    const int per = (nn1 + BQ_T - 1) / BQ_T;
+    int mine = 0;
+    for (int k = 0; k < per; ++k) {
+        const int p1 = tid * per + k;
+        if (p1 >= nn1) break;
+        const uint32_t id = f1.nodes[p1];
+        int lo = 0, hi = nn2; // lower_bound of id among side 2's node ids (:180-183)
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (f2.nodes[m] < id) lo = m + 1; else hi = m; }
+        const int p2 = lo < nn2 && f2.nodes[lo] == id ? lo : -1;
+        int cnt = 0;
+        if (p2 >= 0)
+            for (int a = f1.off[p1]; a < f1.off[p1 + 1]; ++a) cnt += (mask1[f1.idx[a]] != 0) == (mask_polarity != 0);
+        node_p2[p1] = p2;
+        node_qbegin[p1] = cnt; // the count for now
+        mine += cnt;
+    }
+    s_part[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < BQ_T; off <<= 1) {
+        const int v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int base = s_part[tid] - mine;
+    if (tid == BQ_T - 1) { *n_queries = min(s_part[tid], n1); }
+    for (int k = 0; k < per; ++k) {
+        const int p1 = tid * per + k;
+        if (p1 >= nn1) break;
+        const int cnt = node_qbegin[p1], p2 = node_p2[p1];
+        node_qbegin[p1] = base;
+        if (p2 >= 0) {
+            const int cb = f2.off[p2], cl = f2.off[p2 + 1] - cb;
+            int q = base;
+            for (int a = f1.off[p1]; a < f1.off[p1 + 1]; ++a) {
+                const int i1 = (int)f1.idx[a];
+                if ((mask1[i1] != 0) != (mask_polarity != 0)) continue;
+                if (q < n1) { q_idx[q] = i1; c_begin[q] = cb; c_len[q] = cl; q_node[q] = p1; }
+                ++q;
+            }
+        }
+        base += cnt;
+    }
+    if (tid == 0) node_qbegin[nn1] = 0x7fffffff; // (never read as a begin: the resolve kernel ends a node at the next begin or n_queries)
+}
+
+// the K smallest keys of every query's list with the query count on the device (k_topk_lists reads it from the host)
+template <int TOPK>
+__global__ __launch_bounds__(256) void k_topk_lists_n(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                                                      const int32_t *__restrict__ q_idx, const int32_t *__restrict__ c_begin,
+                                                      const int32_t *__restrict__ c_len, const int32_t *__restrict__ n_queries,
+                                                      const int32_t *__restrict__ c_idx, const int32_t *__restrict__ frame_mp,
+                                                      const uint8_t *__restrict__ busy2, uint32_t *__restrict__ out)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= *n_queries) return;
+    const Desc256 da = load_desc(a + (size_t)q_idx[q] * 32);
+    const int cb = c_begin[q], n = c_len[q];
+    uint32_t k[TOPK];
+#pragma unroll
+    for (int i = 0; i < TOPK; ++i) k[i] = 0xFFFFFFFFu;
+    for (int t = lane; t < n; t += 64) {
+        const int j = c_idx[cb + t];
+        if (frame_mp ? frame_mp[j] != -1 : busy2[j] != 0) continue; // not free when the call starts (:150 / :466)
+        uint32_t v = ((uint32_t)ham256(da, load_desc(b + (size_t)j * 32)) << 16) | (uint32_t)min(t, 65535);
+#pragma unroll
+        for (int i = 0; i < TOPK; ++i) {
+            const uint32_t lo = min(k[i], v);
+            v = max(k[i], v);
+            k[i] = lo;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TOPK; ++r) {
+        uint32_t m = k[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+        if (lane == 0) out[(size_t)q * TOPK + r] = m;
+        if (k[0] == m && m != 0xFFFFFFFFu) {
+#pragma unroll
+            for (int i = 0; i + 1 < TOPK; ++i) k[i] = k[i + 1];
+            k[TOPK - 1] = 0xFFFFFFFFu;
+        }
+    }
+}
+
+#define BR_T 256
+#define BR_TOPK 8
+#define BR_MAX_NODE 4096 // features of one node on either side the resolve kernel keeps state for in LDS (a dense single node: 2000)
+template <int MODE>
+__global__ __launch_bounds__(BR_T) void k_bow_resolve(BowFv f1, BowFv f2, int max_nodes, const int32_t *__restrict__ node_p2,
+                                                      const int32_t *__restrict__ node_qbegin, const int32_t *__restrict__ n_queries,
+                                                      const int32_t *__restrict__ q_idx, const uint32_t *__restrict__ topk,
+                                                      const uint8_t *__restrict__ desc1, const uint8_t *__restrict__ desc2,
+                                                      const orbx_kp *__restrict__ kps1, const orbx_kp *__restrict__ kps2,
+                                                      const uint8_t *__restrict__ busy2, float nn_ratio, int check_orientation,
+                                                      int32_t *__restrict__ frame_mp, int32_t *__restrict__ matches12,
+                                                      int32_t *__restrict__ hist, int32_t *__restrict__ match_list, int32_t *__restrict__ result)
+{
+    __shared__ int32_t s_owner[BR_MAX_NODE], s_assign[BR_MAX_NODE];
+    const int tid = threadIdx.x;
+    const int nn1 = min(*f1.n_nodes, max_nodes), nq_all = *n_queries;
+    for (int p1 = blockIdx.x; p1 < nn1; p1 += gridDim.x) {
+        const int p2 = node_p2[p1];
+        if (p2 < 0) continue;
+        const int qb = node_qbegin[p1];
+        int qe = p1 + 1 < nn1 ? node_qbegin[p1 + 1] : nq_all;
+        qe = min(qe, nq_all);
+        const int nq = qe - qb;
+        if (nq <= 0) continue;
+        const int cb = f2.off[p2], nc = f2.off[p2 + 1] - cb;
+        if (nq > BR_MAX_NODE || nc > BR_MAX_NODE) { if (tid == 0) atomicExch(&result[1], 1); continue; } // reported, nothing done for the node
+        __syncthreads(); // (the previous node's state is no longer read)
+        // initially free candidates: SearchByBow -- no map point yet (:150); triangulation -- no map point on side 2 (:466)
+        for (int t = tid; t < nc; t += BR_T) {
+            const int j = (int)f2.idx[cb + t];
+            const bool free0 = MODE == 0 ? frame_mp[j] == -1 : busy2[j] == 0;
+            s_owner[t] = free0 ? INT_MAX : -1;
+        }
+        for (int i = tid; i < nq; i += BR_T) s_assign[i] = -1;
+        // one sweep's outcome for query i of the node: the list position it takes, or -1
+        auto choose = [&](int i) -> int {
+            const uint32_t *e = topk + (size_t)(qb + i) * BR_TOPK;
+            int best = MODE == 0 ? 256 : ORBM_TH_LOW, second = 256, bt = -1, found = 0, last_dd = 0;
+            bool exhausted = false, resolved = false;
+            for (int r = 0; r < BR_TOPK && found < (MODE == 0 ? 2 : 1); ++r) {
+                const uint32_t key = e[r];
+                if (key == 0xFFFFFFFFu) { exhausted = true; break; }
+                const int t = (int)(key & 0xFFFF), dd = (int)(key >> 16);
+                last_dd = dd;
+                if (s_owner[t] < i) continue; // taken by an earlier query of this call (:150 / :466)
+                if (found == 0) { if (dd < best) { best = dd; bt = t; } }
+                else second = min(dd, 256);
+                ++found;
+            }
+            if (MODE == 0) {
+                resolved = found == 2 || exhausted || (found == 1 && best > ORBM_TH_LOW);
+                if (!resolved && found == 1 && (float)best < nn_ratio * (float)min(last_dd, 256)) { second = min(last_dd, 256); resolved = true; }
+            } else {
+                resolved = found == 1 || exhausted || last_dd >= ORBM_TH_LOW;
+            }
+            if (!resolved) { // the sorted list is used up: the whole node, distances computed here
+                const Desc256 da = load_desc(desc1 + (size_t)q_idx[qb + i] * 32);
+                best = MODE == 0 ? 256 : ORBM_TH_LOW; second = 256; bt = -1;
+                for (int t = 0; t < nc; ++t) {
+                    if (s_owner[t] < i) continue;
+                    const int dd = ham256(da, load_desc(desc2 + (size_t)f2.idx[cb + t] * 32));
+                    if (dd < best) { second = best; best = dd; bt = t; }
+                    else if (MODE == 0 && dd < second) second = dd;
+                }
+            }
+            if (MODE == 0) return (bt >= 0 && best <= ORBM_TH_LOW && (float)best < nn_ratio * (float)second) ? bt : -1; // :164
+            return (bt >= 0 && (int)f2.idx[cb + bt] > 0) ? bt : -1; // :484 -- feature 0 of key frame 2 is never accepted
+        };
+        int sweeps = 0;
+        for (;;) {
+            __syncthreads();
+            int changed = 0;
+            for (int i = tid; i < nq; i += BR_T) {
+                const int t = choose(i);
+                if (t != s_assign[i]) { s_assign[i] = t; changed = 1; }
+            }
+            ++sweeps;
+            const int any = __syncthreads_or(changed);
+            if (!any || sweeps > nq + 1) break;
+            // owner[t] = the first query that holds t (queries only ever compete inside their node)
+            for (int t = tid; t < nc; t += BR_T) if (s_owner[t] >= 0) s_owner[t] = INT_MAX;
+            __syncthreads();
+            for (int i = tid; i < nq; i += BR_T)
+                if (s_assign[i] >= 0) atomicMin(&s_owner[s_assign[i]], i);
+        }
+        // the stable choices become matches; rotation histogram (:170-174 / :491-495, the reference's 1/30 factor)
+        for (int i = tid; i < nq; i += BR_T) {
+            const int t = s_assign[i];
+            if (t < 0) continue;
+            const int i1 = q_idx[qb + i], i2 = (int)f2.idx[cb + t];
+            if (MODE == 0) frame_mp[i2] = i1; else matches12[i1] = i2;
+            int bin = -1;
+            if (check_orientation) {
+                const float factor = 1.f / ORBM_HISTO_LENGTH;
+                float rot = ORB_FSUB(kps1[i1].angle, kps2[i2].angle);
+                if (rot < 0.f) rot = ORB_FADD(rot, 360.f);
+                bin = orb_round_f(ORB_FMUL(rot, factor));
+                if (bin == ORBM_HISTO_LENGTH) bin = 0;
+                atomicAdd(&hist[bin], 1);
+            }
+            const int at = atomicAdd(&result[0], 1);
+            match_list[2 * at] = MODE == 0 ? i2 : i1;
+            match_list[2 * at + 1] = bin;
+        }
+        if (tid == 0) atomicMax(&result[2], sweeps);
+    }
+}
+
+// ComputeThreeMaxima (:594-622) over the call's histogram and the removal of the matches outside the three main bins
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bow_finish(int check_orientation, const int32_t *__restrict__ hist, const int32_t *__restrict__ match_list,
+                                                    int32_t *__restrict__ frame_mp, int32_t *__restrict__ matches12, int32_t *__restrict__ result)
+{
+    __shared__ int s_keep[3], s_removed;
+    const int tid = threadIdx.x, n = result[0];
+    if (tid == 0) {
+        s_removed = 0;
+        int max1 = 0, max2 = -1, max3 = -2, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < ORBM_HISTO_LENGTH; ++i) {
+            const int v = hist[i];
+            if (v > max1) { max3 = max2; max2 = max1; max1 = v; i3 = i2; i2 = i1; i1 = i; }
+            else if (v > max2) { max3 = max2; max2 = v; i3 = i2; i2 = i; }
+            else if (v > max3) { max3 = v; i3 = i; }
+        }
+        if (max2 < max1 / 10) { i2 = -1; i3 = -1; }
+        else if (max3 < max1 / 10) i3 = -1;
+        s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+    }
+    __syncthreads();
+    if (check_orientation)
+        for (int k = tid; k < n; k += 256) {
+            const int bin = match_list[2 * k + 1];
+            if (bin == s_keep[0] || bin == s_keep[1] || bin == s_keep[2]) continue;
+            if (MODE == 0) frame_mp[match_list[2 * k]] = -1; else matches12[match_list[2 * k]] = -1;
+            atomicAdd(&s_removed, 1);
+        }
+    __syncthreads();
+    if (tid == 0) { result[3] = n; result[0] = n - s_removed; }
+}
+
 struct orbm_ctx {
     int device;
     hipStream_t stream;
@@ -1953,6 +2207,70 @@ extern "C" int orbm_search_by_projection_points_device(orbm_t *c, float nn_ratio
 
 // The window lists of one device-resident frame record (orbx_extract_batch_device -> orbf_frame_post_device): the grid
 // is the CSR orbf built, nothing visits the host.  See include/orbm.h.
+
+// SearchByBow / SearchForTriangulation on device-resident records (include/orbm.h)
+static int bow_device(orbm_ctx *c, int mode, float nn_ratio, int check_orientation, const uint8_t *d_desc1, const void *d_kps1,
+                      const uint8_t *d_mask1, int n1, const uint32_t *d_fv1_nodes, const int32_t *d_fv1_off, const uint32_t *d_fv1_idx,
+                      const int32_t *d_n_fv1, const uint8_t *d_desc2, const void *d_kps2, const uint8_t *d_busy2, int32_t *d_frame_mp,
+                      int32_t *d_matches12, int n2, const uint32_t *d_fv2_nodes, const int32_t *d_fv2_off, const uint32_t *d_fv2_idx,
+                      const int32_t *d_n_fv2, int32_t *d_result, void *stream)
+{
+    if (!c || !d_desc1 || !d_desc2 || !d_mask1 || !d_fv1_nodes || !d_fv1_off || !d_fv1_idx || !d_n_fv1 || !d_fv2_nodes || !d_fv2_off ||
+        !d_fv2_idx || !d_n_fv2 || !d_result || !d_kps1 || !d_kps2 || (mode == 0 ? !d_frame_mp : (!d_matches12 || !d_busy2)))
+        return orbx_set_error(ORBX_E_ARG, "null argument");
+    if (n1 < 0 || n2 < 0) return orbx_set_error(ORBX_E_ARG, "bad size");
+    M_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    M_TRY(hipMemsetAsync(d_result, 0, 32, s));
+    if (mode == 1 && n1 > 0) M_TRY(hipMemsetAsync(d_matches12, 0xFF, sizeof(int32_t) * (size_t)n1, s)); // -1 (:457)
+    if (n1 == 0 || n2 == 0) return ORBX_OK;
+    // scratch (the handle's, one call in flight per handle): node_p2[n1], node_qbegin[n1 + 1], q_idx / c_begin / c_len / q_node [n1],
+    // n_queries, hist[30], match_list[2 n1], topk[n1 * K]
+    const size_t N = (size_t)n1;
+    M_TRY(c->w_grid.need(sizeof(int32_t) * (N * 8 + 64 + N * BR_TOPK + 8)));
+    int32_t *node_p2 = (int32_t *)c->w_grid.p, *node_qbegin = node_p2 + N, *q_idx = node_qbegin + N + 1, *c_begin = q_idx + N, *c_len = c_begin + N,
+            *q_node = c_len + N, *n_queries = q_node + N, *hist = n_queries + 1, *match_list = hist + 32;
+    uint32_t *topk = (uint32_t *)(match_list + 2 * N);
+    M_TRY(hipMemsetAsync(n_queries, 0, sizeof(int32_t) * 33, s));
+    const BowFv f1 = {d_fv1_nodes, d_fv1_off, d_fv1_idx, d_n_fv1}, f2 = {d_fv2_nodes, d_fv2_off, d_fv2_idx, d_n_fv2};
+    hipLaunchKernelGGL(k_bow_queries, dim3(1), dim3(BQ_T), 0, s, f1, f2, d_mask1, mode == 0 ? 1 : 0, n1, n1, node_p2, node_qbegin, q_idx, c_begin,
+                       c_len, q_node, n_queries);
+    hipLaunchKernelGGL(k_topk_lists_n<BR_TOPK>, dim3((n1 + 3) / 4), dim3(256), 0, s, d_desc1, d_desc2, q_idx, c_begin, c_len, n_queries,
+                       reinterpret_cast<const int32_t *>(d_fv2_idx), mode == 0 ? d_frame_mp : nullptr, d_busy2, topk);
+    const int grid = std::min(n1, 1024);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_bow_resolve<0>, dim3(grid), dim3(BR_T), 0, s, f1, f2, n1, node_p2, node_qbegin, n_queries, q_idx, topk, d_desc1, d_desc2,
+                           (const orbx_kp *)d_kps1, (const orbx_kp *)d_kps2, d_busy2, nn_ratio, check_orientation, d_frame_mp, d_matches12, hist, match_list, d_result);
+    else
+        hipLaunchKernelGGL(k_bow_resolve<1>, dim3(grid), dim3(BR_T), 0, s, f1, f2, n1, node_p2, node_qbegin, n_queries, q_idx, topk, d_desc1, d_desc2,
+                           (const orbx_kp *)d_kps1, (const orbx_kp *)d_kps2, d_busy2, nn_ratio, check_orientation, d_frame_mp, d_matches12, hist, match_list, d_result);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_bow_finish<0>, dim3(1), dim3(256), 0, s, check_orientation, hist, match_list, d_frame_mp, d_matches12, d_result);
+    else
+        hipLaunchKernelGGL(k_bow_finish<1>, dim3(1), dim3(256), 0, s, check_orientation, hist, match_list, d_frame_mp, d_matches12, d_result);
+    M_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+extern "C" int orbm_search_by_bow_device(orbm_t *c, float nn_ratio, int check_orientation, const uint8_t *d_desc1, const void *d_kps1,
+                                         const uint8_t *d_kf_mp_ok, int n1, const uint32_t *d_fv1_nodes, const int32_t *d_fv1_off,
+                                         const uint32_t *d_fv1_idx, const int32_t *d_n_fv1, const uint8_t *d_desc2, const void *d_kps2,
+                                         int32_t *d_frame_mp, int n2, const uint32_t *d_fv2_nodes, const int32_t *d_fv2_off,
+                                         const uint32_t *d_fv2_idx, const int32_t *d_n_fv2, int32_t *d_result, void *stream)
+{
+    return bow_device(c, 0, nn_ratio, check_orientation, d_desc1, d_kps1, d_kf_mp_ok, n1, d_fv1_nodes, d_fv1_off, d_fv1_idx, d_n_fv1, d_desc2,
+                      d_kps2, nullptr, d_frame_mp, nullptr, n2, d_fv2_nodes, d_fv2_off, d_fv2_idx, d_n_fv2, d_result, stream);
+}
+extern "C" int orbm_search_for_triangulation_device(orbm_t *c, int check_orientation, const uint8_t *d_desc1, const void *d_kps1,
+                                                    const uint8_t *d_has_mp1, int n1, const uint32_t *d_fv1_nodes, const int32_t *d_fv1_off,
+                                                    const uint32_t *d_fv1_idx, const int32_t *d_n_fv1, const uint8_t *d_desc2,
+                                                    const void *d_kps2, const uint8_t *d_has_mp2, int n2, const uint32_t *d_fv2_nodes,
+                                                    const int32_t *d_fv2_off, const uint32_t *d_fv2_idx, const int32_t *d_n_fv2,
+                                                    int32_t *d_matches12, int32_t *d_result, void *stream)
+{
+    return bow_device(c, 1, 0.f, check_orientation, d_desc1, d_kps1, d_has_mp1, n1, d_fv1_nodes, d_fv1_off, d_fv1_idx, d_n_fv1, d_desc2,
+                      d_kps2, d_has_mp2, nullptr, d_matches12, n2, d_fv2_nodes, d_fv2_off, d_fv2_idx, d_n_fv2, d_result, stream);
+}
+
 extern "C" int orbm_window_lists_device(orbm_t *c, const void *d_kps, const uint8_t *d_desc, const int32_t *d_cell_start,
                                         const int32_t *d_cell_items, int grid_cols, int grid_rows, const uint8_t *d_q_desc,
                                         const float *d_q_xy, const float *d_q_radius, const int32_t *d_q_min_level,

@@ -56,6 +56,9 @@ def _mlib():
                                                              vp, vp, vp]),
             "orbm_search_by_projection_points_device": (i32, [vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32,
                                                               vp, vp, vp]),
+            "orbm_search_by_bow_device": (i32, [vp, f32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+            "orbm_search_for_triangulation_device": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp,
+                                                           vp, vp]),
             "orbm_window_lists_device": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]),
             "orbm_distinctive_descriptors": (i32, [vp, vp, vp, i32, vp]),
             "orbm_distinctive_descriptors_device": (i32, [vp, vp, vp, i32, vp, vp]),
@@ -290,6 +293,23 @@ class ORBMatcher:
                 p("desc2"), p("cell_start"), p("cell_items"), grid_cols, grid_rows, n2, list_cap, p("frame_mp"), p("result"), st))
 
     # -- static SearchByProjection(keyFrame, mapPoints, Map*, th): the fuse (ORBMatcher.cpp:524-592) ------------
+    def SearchByBowDevice(self, d, n1, n2, stream=None):
+        """orbm_search_by_bow_device on torch device tensors: d = dict(desc1, kps1 (orbx_kp records), kf_mp_ok, fv1=(nodes, off, idx, n), desc2, kps2,
+        frame_mp (in / out), fv2=(nodes, off, idx, n), result (int32 x 8))."""
+        p = lambda t: t.data_ptr()  # noqa: E731
+        _lib.check(self._hd._L.orbm_search_by_bow_device(
+            self._hd._h, self.nn_ratio, int(self.be_check_orientation), p(d["desc1"]), p(d["kps1"]), p(d["kf_mp_ok"]), n1,
+            p(d["fv1"][0]), p(d["fv1"][1]), p(d["fv1"][2]), p(d["fv1"][3]), p(d["desc2"]), p(d["kps2"]), p(d["frame_mp"]), n2,
+            p(d["fv2"][0]), p(d["fv2"][1]), p(d["fv2"][2]), p(d["fv2"][3]), p(d["result"]), stream))
+
+    def SearchForTriangulationDevice(self, d, n1, n2, stream=None):
+        """orbm_search_for_triangulation_device: d = dict(desc1, kps1, has_mp1, fv1, desc2, kps2, has_mp2, fv2, matches12, result)."""
+        p = lambda t: t.data_ptr()  # noqa: E731
+        _lib.check(self._hd._L.orbm_search_for_triangulation_device(
+            self._hd._h, int(self.be_check_orientation), p(d["desc1"]), p(d["kps1"]), p(d["has_mp1"]), n1, p(d["fv1"][0]), p(d["fv1"][1]),
+            p(d["fv1"][2]), p(d["fv1"][3]), p(d["desc2"]), p(d["kps2"]), p(d["has_mp2"]), n2, p(d["fv2"][0]), p(d["fv2"][1]),
+            p(d["fv2"][2]), p(d["fv2"][3]), p(d["matches12"]), p(d["result"]), stream))
+
     def SearchFuse(self, q_desc, q_xy, q_radius, q_level, q_ok, kps, desc, img_w, img_h, sigma2):
         """Per-point core of the fuse: (best_idx, best_dist, n_found); the observation rewiring stays with the caller."""
         qd = np.ascontiguousarray(q_desc, dtype=np.uint8)

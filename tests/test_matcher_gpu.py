@@ -379,6 +379,84 @@ def test_search_for_triangulation_dense_2000x2000(oracle_mod, check_ori):
     assert n_got > (50 if check_ori else 500)
 
 
+def _dev_fv(fv, torch, dev, pad):
+    """A FeatureVector as orbv_transform_device leaves it: node ids, CSR offsets, feature indices and the node COUNT on the device
+    (arrays padded to the capacity, as the per-frame rows of a batch are)."""
+    nodes, off, idx = fv
+    t = lambda a, dt, n: torch.from_numpy(np.concatenate([np.asarray(a, dt), np.zeros(max(n - len(a), 0), dt)])).to(dev)  # noqa: E731
+    return (t(nodes, np.uint32, pad).view(torch.int32), t(off, np.int32, pad + 1), t(idx, np.uint32, pad).view(torch.int32),
+            torch.tensor([len(nodes)], dtype=torch.int32, device=dev))
+
+
+def _bow_cases():
+    out = []
+    for bits, n in ((10, 2000), (4, 2000), (0, 600)):          # ~1000 nodes of ~2 features, 16 nodes of ~125, one node
+        a, b, _ = synth.make_descriptor_pair(n, seed=bits + 1)
+        out.append(("prefix%d" % bits, a, b, bits, 0.7))
+    for bits in (0, 2):                                        # clustered near-duplicates: the top-8 lists run dry
+        a, b = _clustered_pair(31 + bits)
+        out.append(("clustered%d" % bits, a, b, bits, 0.99))
+    a, b, _ = synth.make_descriptor_pair(2000, seed=31)        # BASELINE config 3: dense 2000 x 2000 in one node
+    out.append(("dense2000", a, b, 0, 0.7))
+    return out
+
+
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_bow_and_triangulation_on_the_device(oracle_mod, check_ori):
+    """orbm_search_by_bow_device / orbm_search_for_triangulation_device (ORBMatcher.cpp:118-201, :417-522 with the node join,
+    the greedy pass, the rotation histogram and ComputeThreeMaxima on the device): frame_mp / matches12 and the counts equal
+    the oracle's sequential loops and the host entry points on every node granularity of profiles/r03_match_latency.txt --
+    ~1000 nodes, 16 nodes, one node --, on clustered descriptors (many key-frame features want the same frame features, lists
+    used up, rows rescanned on the device) and on the dense 2000 x 2000 case."""
+    import torch
+    from monoorbslam3_amd.matcher import MatcherHandle, ORBMatcher
+    dev = torch.device("cuda", 0)
+    mh = MatcherHandle(device=0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    for name, a, b, bits, ratio in _bow_cases():
+        n1, n2 = len(a), len(b)
+        rng = np.random.RandomState(len(name) + bits)
+        ang1 = rng.uniform(0, 360, n1).astype(np.float32)
+        ang2 = rng.uniform(0, 360, n2).astype(np.float32)
+        if n1 == n2:
+            ang2 = ((ang1[rng.permutation(n1)] + rng.normal(0, 20, n1)) % 360).astype(np.float32)
+        ok = (rng.uniform(size=n1) > 0.2).astype(np.uint8)
+        mp0 = np.where(rng.uniform(size=n2) > 0.92, 7, -1).astype(np.int32)
+        h1 = (rng.uniform(size=n1) > 0.7).astype(np.uint8)
+        h2 = (rng.uniform(size=n2) > 0.8).astype(np.uint8)
+        fv1, fv2 = synth.feature_vector_by_prefix(a, bits), synth.feature_vector_by_prefix(b, bits)
+        m = ORBMatcher(ratio, check_ori, handle=mh)
+        from monoorbslam3_amd.extractor import KP_DTYPE
+        k1, k2 = np.zeros(n1, KP_DTYPE), np.zeros(n2, KP_DTYPE)
+        k1["angle"], k2["angle"] = ang1, ang2
+        kp = lambda k: torch.from_numpy(np.frombuffer(k.tobytes(), np.uint8).copy()).to(dev)  # noqa: E731
+        d = dict(desc1=up(a), kps1=kp(k1), kf_mp_ok=up(ok), fv1=_dev_fv(fv1, torch, dev, n1), desc2=up(b), kps2=kp(k2),
+                 frame_mp=up(mp0), fv2=_dev_fv(fv2, torch, dev, n2), result=torch.zeros(8, dtype=torch.int32, device=dev),
+                 has_mp1=up(h1), has_mp2=up(h2), matches12=torch.full((n1,), -5, dtype=torch.int32, device=dev))
+        # -- SearchByBow
+        n_ref, mp_ref = oracle_mod.search_by_bow(ratio, check_ori, a, ang1, ok, fv1, b, ang2, mp0, fv2)
+        n_host, mp_host = m.SearchByBow(a, ang1, ok, fv1, b, ang2, mp0, fv2)
+        m.SearchByBowDevice(d, n1, n2, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        res = d["result"].cpu().numpy()
+        assert res[1] == 0, name
+        assert res[0] == n_ref == n_host, (name, res, n_ref)
+        assert np.array_equal(d["frame_mp"].cpu().numpy(), mp_ref) and np.array_equal(mp_host, mp_ref), name
+        assert n_ref > 0
+        # -- SearchForTriangulation
+        n_ref, m_ref = oracle_mod.search_for_triangulation(check_ori, a, ang1, h1, fv1, b, ang2, h2, fv2)
+        m.SearchForTriangulationDevice(d, n1, n2, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        res = d["result"].cpu().numpy()
+        assert res[1] == 0 and res[0] == n_ref, (name, res, n_ref)
+        assert np.array_equal(d["matches12"].cpu().numpy(), m_ref), name
+    # nothing to do: empty sides leave frame_mp alone and report no match
+    d["result"].fill_(9)
+    m.SearchByBowDevice(d, 0, n2, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert d["result"].cpu().numpy()[0] == 0
+
+
 def test_search_fuse(oracle_mod):
     """Per-point core of the static fuse SearchByProjection(keyFrame, mapPoints, Map*, th) (ORBMatcher.cpp:524-592):
     KeyFrame window with the strict test, chi-square gate, closest descriptor at distance <= TH_LOW."""

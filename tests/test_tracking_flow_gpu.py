@@ -156,3 +156,58 @@ def test_tracking_chain_stays_on_the_device():
     assert int(n_inl[0]) == ref["n_inliers"][0] and np.array_equal(inl[:ne].cpu().numpy().astype(bool), ref["inlier"])
     t_true = np.array([-dx * Z / fx, -dy * Z / fy, 0.0])
     assert np.abs(t_out.cpu().numpy()[0] - t_true).max() < 0.02
+
+
+def test_bow_branch_stays_on_the_device():
+    """Tracking.cpp:255-273 (the branch without a motion model) with no host hop: orbx_extract_batch_device of the key frame
+    and the frame in one batch -> orbv_transform_device (computeBow, levelsup 4) -> orbm_search_by_bow_device, one stream, the
+    first wait at the very end.  frame_mp and the match count equal the host entry point's on the records and FeatureVectors
+    read back afterwards."""
+    import torch
+    from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
+    from monoorbslam3_amd.matcher import ORBMatcher
+    from monoorbslam3_amd.vocabulary import ORBVocabulary
+    dev = torch.device("cuda", 0)
+    w, h = 752, 480
+    canvas = synth.make_canvas(w + 80, h + 60, seed=77)
+    f = np.stack([canvas[30:30 + h, 40:40 + w], canvas[34:34 + h, 47:47 + w]])  # the frame sees the key frame's scene shifted by (7, 4)
+    ex = ORBExtractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
+    voc = ORBVocabulary.from_arrays(synth.make_vocabulary(10, 5, seed=3), device=0)
+    cap = ex.max_keypoints(w, h)
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+    img = torch.from_numpy(np.ascontiguousarray(f)).to(dev)
+    d_kp, d_desc, d_n = z((2, cap, 28), torch.uint8), z((2, cap, 32), torch.uint8), z((2,), torch.int32)
+    bow_ids, bow_vals, n_words = z((2, cap), torch.int32), z((2, cap), torch.float64), z((2,), torch.int32)
+    fv_nodes, fv_off, fv_idx, n_fv = z((2, cap), torch.int32), z((2, cap + 1), torch.int32), z((2, cap), torch.int32), z((2,), torch.int32)
+    kf_ok = torch.ones(cap, dtype=torch.uint8, device=dev)          # every key-frame feature has a live map point
+    frame_mp = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+    result = z((8,), torch.int32)
+    chain = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(chain)
+    st = chain.cuda_stream
+    ex.extract_batch_device(img.data_ptr(), 2, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), st)
+    voc.transform_device(2, d_desc.data_ptr(), d_n.data_ptr(), cap, 4, bow_ids.data_ptr(), bow_vals.data_ptr(), n_words.data_ptr(),
+                         fv_nodes.data_ptr(), fv_off.data_ptr(), fv_idx.data_ptr(), n_fv.data_ptr(), st)
+    m = ORBMatcher(0.7, True)
+    # the counts are only needed as upper bounds by the call's signature: the capacity serves (slots past a frame's count
+    # appear in no FeatureVector node, so they are neither queries nor candidates)
+    d = dict(desc1=d_desc[0], kps1=d_kp[0], kf_mp_ok=kf_ok, fv1=(fv_nodes[0], fv_off[0], fv_idx[0], n_fv[0:1]), desc2=d_desc[1], kps2=d_kp[1],
+             frame_mp=frame_mp, fv2=(fv_nodes[1], fv_off[1], fv_idx[1], n_fv[1:2]), result=result)
+    m.SearchByBowDevice(d, cap, cap, stream=st)
+    torch.cuda.synchronize()   # the first wait of the chain
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))
+    # ---- the same through the host entry point
+    n = d_n.cpu().numpy()
+    kps = [np.frombuffer(d_kp[i, :n[i]].cpu().numpy().tobytes(), KP_DTYPE) for i in range(2)]
+    desc = [d_desc[i, :n[i]].cpu().numpy() for i in range(2)]
+    nf = n_fv.cpu().numpy()
+    fvs = [(fv_nodes[i, :nf[i]].cpu().numpy().view(np.uint32), fv_off[i, :nf[i] + 1].cpu().numpy(),
+            fv_idx[i, :fv_off[i, nf[i]]].cpu().numpy().view(np.uint32)) for i in range(2)]
+    n_host, mp_host = m.SearchByBow(desc[0], kps[0]["angle"], np.ones(n[0], np.uint8), fvs[0], desc[1], kps[1]["angle"],
+                                    np.full(n[1], -1, np.int32), fvs[1])
+    res = result.cpu().numpy()
+    got = frame_mp.cpu().numpy()
+    print("BoW branch on the device: result", res.tolist(), "host matches", n_host, "key points", n.tolist(), "nodes", nf.tolist())
+    assert res[1] == 0 and res[0] == n_host and n_host > 100
+    assert np.array_equal(got[:n[1]], mp_host) and np.all(got[n[1]:] == -1)
