@@ -37,6 +37,43 @@ for bits, label in ((0, "dense: one node, 2000x2000 pairs"), (4, "16 nodes (~125
     nm = m.SearchByBow(a, ang1, ok, fv1, b, ang2, mp0, fv2)[0]
     ms2 = timeit(lambda: m.SearchForTriangulation(a, ang1, 1 - ok, fv1, b, ang2, np.zeros(n, np.uint8), fv2))
     print("%-36s SearchByBow %.3f ms (%d matches)   SearchForTriangulation %.3f ms" % (label, ms, nm, ms2))
+# ---- the same searches on device-resident records: device time of the enqueued chain (HIP events), nothing read back
+import torch  # noqa: E402
+from monoorbslam3_amd.extractor import KP_DTYPE  # noqa: E402
+dev = torch.device("cuda", 0)
+up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+k1r, k2r = np.zeros(n, KP_DTYPE), np.zeros(n, KP_DTYPE)
+k1r["angle"], k2r["angle"] = ang1, ang2
+kp = lambda k: torch.from_numpy(np.frombuffer(k.tobytes(), np.uint8).copy()).to(dev)  # noqa: E731
+
+
+def dev_fv(fv):
+    nodes, off, idx = fv
+    pad = lambda x, dt, m: torch.from_numpy(np.concatenate([np.asarray(x, dt), np.zeros(max(m - len(x), 0), dt)])).to(dev)  # noqa: E731
+    return (pad(nodes, np.uint32, n).view(torch.int32), pad(off, np.int32, n + 1), pad(idx, np.uint32, n).view(torch.int32),
+            torch.tensor([len(nodes)], dtype=torch.int32, device=dev))
+
+
+for bits, label in ((0, "dense: one node, 2000x2000 pairs"), (4, "16 nodes (~125/node)"), (10, "~1000 nodes (~2/node)")):
+    fv1, fv2 = synth.feature_vector_by_prefix(a, bits), synth.feature_vector_by_prefix(b, bits)
+    d = dict(desc1=up(a), kps1=kp(k1r), kf_mp_ok=up(ok), fv1=dev_fv(fv1), desc2=up(b), kps2=kp(k2r), frame_mp=up(mp0), fv2=dev_fv(fv2),
+             result=torch.zeros(8, dtype=torch.int32, device=dev), has_mp1=up(1 - ok), has_mp2=up(np.zeros(n, np.uint8)),
+             matches12=torch.zeros(n, dtype=torch.int32, device=dev))
+    st = torch.cuda.current_stream().cuda_stream
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    tb, tt = [], []
+    for _ in range(12):
+        d["frame_mp"].fill_(-1)
+        e0.record()
+        m.SearchByBowDevice(d, n, n, stream=st)
+        e1.record()
+        m.SearchForTriangulationDevice(d, n, n, stream=st)
+        e2.record()
+        torch.cuda.synchronize()
+        tb.append(e0.elapsed_time(e1)); tt.append(e1.elapsed_time(e2))
+    r = d["result"].cpu().numpy()
+    print("%-36s SearchByBow on the device %.3f ms   SearchForTriangulation %.3f ms (device time, median; %d sweeps at most)"
+          % (label, sorted(tb)[6], sorted(tt)[6], r[2]))
 print("hamming_matrix 2000x2000 (8 MB out): %.3f ms;  best2 2000x2000: %.3f ms" % (
     timeit(lambda: ORBMatcher.hamming_matrix(a, b)), timeit(lambda: ORBMatcher.best2(a, b))))
 
