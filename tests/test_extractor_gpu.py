@@ -311,6 +311,51 @@ def test_blur_and_descriptors_in_one_pass(oracle_mod, w, h, nf, batch, blur_vari
         assert np.array_equal(a[0], b2[0]) and np.array_equal(a[1], b2[1])
 
 
+def test_one_pass_descriptors_edge_cases(oracle_mod):
+    """k_blur_desc on what a tracker can hand it: frames without a single corner (every count zero, nothing written), one
+    handle used for two frame sizes in turn and back, a capacity smaller than the key-point count on the device entry point
+    (the first `cap` records are written, the count reports the need), and corners crowded into a few patches (hundreds of
+    key points in one (block, trip) bucket)."""
+    import torch
+    from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
+    ex = ORBExtractor(900, 1.2, 8, 20, 7, variants={"desc": "fused"})
+    orc = oracle_mod.Oracle(900, 1.2, 8, 20, 7)
+    flat = np.full((3, 300, 500), 90, np.uint8)
+    for kps, desc in ex.extract_batch(flat):
+        assert len(kps) == 0 and desc.shape == (0, 32)
+    for (w, h) in ((500, 300), (801, 333), (500, 300)):
+        imgs = synth.make_frames(2, w, h, seed=w + h)
+        out = ex.extract_batch(imgs)
+        for f in range(2):
+            _check_frame(ex, orc, imgs[f], out[f][0], out[f][1], frame=f, stages=False)
+    # crowded: every corner inside a few noise patches
+    rng = np.random.RandomState(11)
+    img = np.full((2, 360, 640), 128, np.uint8)
+    for _ in range(5):
+        x0, y0 = rng.randint(20, 640 - 70), rng.randint(20, 360 - 70)
+        img[:, y0:y0 + 48, x0:x0 + 48] = rng.randint(0, 256, (48, 48)).astype(np.uint8)
+    ex5 = ORBExtractor(3000, 1.2, 8, 5, 2, variants={"desc": "fused"})
+    orc5 = oracle_mod.Oracle(3000, 1.2, 8, 5, 2)
+    out = ex5.extract_batch(img)
+    _check_frame(ex5, orc5, img[1], out[1][0], out[1][1], frame=1, stages=False)
+    assert len(out[1][0]) > 1000
+    # device entry point with a capacity below the count
+    w, h = 640, 360
+    fr = synth.make_frames(1, w, h, seed=3)
+    okps, odesc, _ = orc.extract(fr[0])
+    cap = len(okps) - 37
+    d_img = torch.from_numpy(fr).cuda()
+    kp = torch.zeros((1, cap + 8, 28), dtype=torch.uint8, device="cuda")
+    de = torch.full((1, cap + 8, 32), 0xEE, dtype=torch.uint8, device="cuda")
+    n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_img.data_ptr(), 1, w, h, w, w * h, kp.data_ptr(), de.data_ptr(), cap, n.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(n[0]) == len(okps)
+    got = np.frombuffer(kp[0, :cap].cpu().numpy().tobytes(), KP_DTYPE)
+    assert np.array_equal(got["x"], okps["x"][:cap]) and np.array_equal(de[0, :cap].cpu().numpy(), odesc[:cap])
+    assert (de[0, cap:].cpu().numpy() == 0xEE).all()  # nothing beyond the capacity is touched
+
+
 @pytest.mark.parametrize("w,h,nf,n_patches,side", [(1242, 375, 2000, 12, 40), (752, 480, 1000, 6, 30), (640, 200, 3000, 5, 48)])
 def test_quadtree_on_crowded_corners(oracle_mod, w, h, nf, n_patches, side):
     """Every corner of the frame sits in a few small noise patches: the quadtree has to divide seven to nine times before
@@ -420,7 +465,8 @@ def test_stream_layout_variants_give_identical_results(tmp_path):
     for name, var in (("default", {}), ("streams3", {"streams": 3}), ("no_side", {"side_blur": 0}),
                       ("blur_after_fast", {"side_blur": 2}), ("blur_beside_orientation", {"side_blur": 3}),
                       ("no_early_fast", {"early_fast": 0}), ("early_blur", {"early_fast": 2}), ("desc_separate", {"desc": "separate"}),
-                      ("desc_fused", {"desc": "fused"}), ("copy_back", {"zero_copy": 0})):
+                      ("desc_fused", {"desc": "fused"}), ("desc_fused_streams3", {"desc": "fused", "streams": 3}),
+                      ("desc_fused_blur_valu", {"desc": "fused", "blur": "valu"}), ("copy_back", {"zero_copy": 0})):
         results[name] = subprocess.check_output([sys.executable, str(script), json.dumps(var)], text=True).strip().splitlines()[-1]
     assert len(set(results.values())) == 1, results
     assert int(results["default"].split()[0]) > 24 * 500
