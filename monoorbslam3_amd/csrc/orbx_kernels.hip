@@ -2256,22 +2256,40 @@ __global__ __launch_bounds__(BD_T) BD_OCC void k_blur_desc(FastSrc src, BdLevels
         if (it.out_idx < 0) return;
         const int x = (int)(it.xy & 0xFFFF), y = (int)(it.xy >> 16);
         const float a = it.cs, bb = it.sn;
-        // cvRound through the float adder as in k_orient_desc: bits(v + 1.5 * 2^23) = M + round(v); M's low bits are zero, so
-        // the ring row is (M + dr + y) & 127, and M is taken out of the column once per key point
+        // cvRound through the float adder as in k_orient_desc: bits(v + 1.5 * 2^23) = M + round(v), M's low bits are zero
         const float MAGIC = 12582912.f;
         const uint32_t M = 0x4B400000u;
-        uint32_t yv = (uint32_t)y, colbase = (uint32_t)(x - B0) - M;
-        asm("" : "+v"(yv), "+v"(colbase)); // vector registers: a scalar operand halves the issue rate of the adds below
         u64 bits[4];
+        // A window that does not run over the end of the ring (seven in ten) is addressed linearly: with r0 = M + dr, c0 = M + dc the
+        // byte is at (top + 18 + dr) * RP + (x - B0) + dc = mad24(r0, RP, c0) + K, two operations per sample (the 24-bit
+        // multiply sees 0x400000 + dr, and K takes that constant and M out again); the others wrap row by row with & 127.
+        const int top = (y - BD_HALO) & (BD_RING - 1);
+        if (top + 2 * BD_HALO < BD_RING) {
+            uint32_t K = (uint32_t)((top + BD_HALO) * BD_RP + (x - B0)) - 0x400000u * (uint32_t)BD_RP - M;
+            asm("" : "+v"(K)); // a vector register: a scalar operand halves the issue rate of the add below
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t r0 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px0[j], bb), ORB_FMUL(py0[j], a)), MAGIC));
-            const uint32_t c0 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px0[j], a), ORB_FMUL(py0[j], bb)), MAGIC));
-            const uint32_t r1 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px1[j], bb), ORB_FMUL(py1[j], a)), MAGIC));
-            const uint32_t c1 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px1[j], a), ORB_FMUL(py1[j], bb)), MAGIC));
-            const int t0 = s_ring[((r0 + yv) & (BD_RING - 1)) * BD_RP + c0 + colbase];
-            const int t1 = s_ring[((r1 + yv) & (BD_RING - 1)) * BD_RP + c1 + colbase];
-            bits[j] = __ballot(t0 < t1);
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t r0 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px0[j], bb), ORB_FMUL(py0[j], a)), MAGIC));
+                const uint32_t c0 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px0[j], a), ORB_FMUL(py0[j], bb)), MAGIC));
+                const uint32_t r1 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px1[j], bb), ORB_FMUL(py1[j], a)), MAGIC));
+                const uint32_t c1 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px1[j], a), ORB_FMUL(py1[j], bb)), MAGIC));
+                const int t0 = s_ring[__umul24(r0, BD_RP) + c0 + K];
+                const int t1 = s_ring[__umul24(r1, BD_RP) + c1 + K];
+                bits[j] = __ballot(t0 < t1);
+            }
+        } else {
+            uint32_t yv = (uint32_t)y, colbase = (uint32_t)(x - B0) - M;
+            asm("" : "+v"(yv), "+v"(colbase));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t r0 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px0[j], bb), ORB_FMUL(py0[j], a)), MAGIC));
+                const uint32_t c0 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px0[j], a), ORB_FMUL(py0[j], bb)), MAGIC));
+                const uint32_t r1 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px1[j], bb), ORB_FMUL(py1[j], a)), MAGIC));
+                const uint32_t c1 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px1[j], a), ORB_FMUL(py1[j], bb)), MAGIC));
+                const int t0 = s_ring[((r0 + yv) & (BD_RING - 1)) * BD_RP + c0 + colbase];
+                const int t1 = s_ring[((r1 + yv) & (BD_RING - 1)) * BD_RP + c1 + colbase];
+                bits[j] = __ballot(t0 < t1);
+            }
         }
         if (lane < 4) {
             const u64 wd = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
