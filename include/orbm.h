@@ -204,7 +204,12 @@ int orbm_search_for_triangulation_device(orbm_t *h, int check_orientation, const
  * no bound).  d_result (int32 x 8, device): [0] matches (the return value), [1] = 1 if the lists did not fit the pool --
  * then nothing was changed and the call is to be repeated with a larger list_cap --, [2] sweeps of the fixed point,
  * [3] window-list entries; map points -> frame: [4] numOutViewAndBad, [5] fail1, [6] fail2 (:353-354).
- * nq + n2 <= 38400.  Enqueued on `stream` (NULL = the handle's); no host synchronisation. */
+ * nq + n2 <= 38400.  Enqueued on `stream` (NULL = the handle's); no host synchronisation -- with two provisos: the packed
+ * lists live in the handle's scratch, so ONE call may be in flight per handle (use a handle per thread / per stream), and the
+ * first call that needs a larger scratch (nq * list_cap grew) reallocates it, which waits for the device once.  When the lists
+ * overflow the pool ([1] = 1) d_frame_mp is left as it was: a chain that goes on to orbba_pose_edges_device then optimises the
+ * pose on the matches d_frame_mp already held -- size list_cap so that this cannot happen (48 covers the tracking radii at 2000
+ * features; the window of a lost-track search needs more), or read d_result back before trusting the pose. */
 int orbm_search_by_projection_frame_device(orbm_t *h, int check_orientation, const uint8_t *d_q_desc, const float *d_q_xy,
                                            const float *d_q_radius, const int32_t *d_q_octave, const float *d_q_angle,
                                            const uint8_t *d_q_ok, int nq, const void *d_kps2, const uint8_t *d_desc2,
