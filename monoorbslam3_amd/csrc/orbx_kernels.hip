@@ -2373,8 +2373,16 @@ void orbx_build_blur_desc(const OrbxLevels &levels, const int taps[7], const Blu
 {
     blocks.clear(); band_h.clear();
     memset(&out, 0, sizeof out);
-    int n_lv = 0; // levels wide enough for a block's staged source row (and for k_blur_mfma, whose V bands are shared)
-    while (n_lv < orbx_blur_mfma_levels(levels) && levels.lv[n_lv].w >= BD_SRC_W) ++n_lv;
+    // levels wide enough for a block's staged source row (and for k_blur_mfma, whose V bands are shared) and small enough for
+    // k_desc_bins' bucket tables in 64 KB of LDS (two ints per (block, trip, early / late) bucket: beyond about 8000 x 4000 pixels
+    // the level keeps the blur pass + k_orient_desc)
+    auto buckets_fit = [&](const OrbxLevel &v) {
+        const int n_bx = v.w - ORBX_EDGE - 1 >= ORBX_EDGE ? bd_block_of(v.w - ORBX_EDGE - 1) + 1 : 0;
+        return (size_t)2 * n_bx * ((v.h + 31) / 32) * 2 * sizeof(int) + sizeof(int) <= (size_t)60 * 1024;
+    };
+    int n_lv = 0;
+    if (levels.n_levels > 0 && buckets_fit(levels.lv[0])) // (level 0 is the largest: if it fits, all do)
+        while (n_lv < orbx_blur_mfma_levels(levels) && levels.lv[n_lv].w >= BD_SRC_W) ++n_lv;
     int buckets = 0;
     for (int l = 0; l < n_lv; ++l) {
         const OrbxLevel &v = levels.lv[l];

@@ -285,6 +285,7 @@ def test_gaussian_on_the_matrix_pipe(oracle_mod, w, h, blur_variant):
 
 
 @pytest.mark.parametrize("w,h,nf,batch,blur_variant", [(1242, 375, 2000, 1, 0), (752, 480, 1000, 3, 0), (1920, 1080, 2000, 1, 0),
+                                                       (3840, 2160, 4000, 1, 0), (2600, 60, 500, 2, 0), (200, 1400, 600, 1, 1),
                                                        (640, 360, 800, 9, 1), (331, 200, 400, 2, 0), (500, 163, 700, 1, 1),
                                                        (1242, 375, 6000, 2, 0)])
 def test_blur_and_descriptors_in_one_pass(oracle_mod, w, h, nf, batch, blur_variant):
