@@ -450,6 +450,17 @@ def test_search_by_bow_and_triangulation_on_the_device(oracle_mod, check_ori):
         res = d["result"].cpu().numpy()
         assert res[1] == 0 and res[0] == n_ref, (name, res, n_ref)
         assert np.array_equal(d["matches12"].cpu().numpy(), m_ref), name
+    # a vocabulary node with more features than the resolve kernel keeps state for: reported, that node untouched
+    big = 4500
+    a, b, _ = synth.make_descriptor_pair(big, seed=99)
+    kb = np.zeros(big, KP_DTYPE)
+    fvb = synth.feature_vector_by_prefix(a, 0)
+    db = dict(desc1=up(a), kps1=kp(kb), kf_mp_ok=up(np.ones(big, np.uint8)), fv1=_dev_fv(fvb, torch, dev, big), desc2=up(b), kps2=kp(kb),
+              frame_mp=torch.full((big,), -1, dtype=torch.int32, device=dev), fv2=_dev_fv(synth.feature_vector_by_prefix(b, 0), torch, dev, big),
+              result=torch.zeros(8, dtype=torch.int32, device=dev))
+    m.SearchByBowDevice(db, big, big, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert db["result"].cpu().numpy()[1] == 1 and db["result"].cpu().numpy()[0] == 0 and (db["frame_mp"].cpu().numpy() == -1).all()
     # nothing to do: empty sides leave frame_mp alone and report no match
     d["result"].fill_(9)
     m.SearchByBowDevice(d, 0, n2, stream=torch.cuda.current_stream().cuda_stream)
