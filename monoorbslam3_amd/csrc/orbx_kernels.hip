@@ -814,6 +814,7 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
     __syncthreads();
 
     int iq_head = 0, iq_tail = 0, cq_head = 0, cq_tail = 0, list_n = 0;
+    bool tile_ok = false; // the LDS tile holds the strip's pixels (a pass that found corners builds its score map over them)
     int thr = 0;
     uint32_t Kd = 0; // per byte 128 - t6
     bool both_possible = false; // t6 == 0: a pixel can pass the 6-bit arc test in both polarities
@@ -980,6 +981,8 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         while (cq_tail > cq_head) { stage_score(min(cq_tail - cq_head, 64)); FS_WAVE_ORDER(); }
 
         if (list_n > FS_LIST) { FS_COUNT(9, 1); return false; } // more corners than the list holds: the caller redoes the range in pieces
+        if (list_n == 0) return true; // no corner at this threshold: nothing to suppress, and the tile stays intact for the next pass
+        tile_ok = false;
 
         // ---- stage 5: the score map takes the tile's place (every stage that reads pixels has drained), then the strict
         // 3x3 NMS inside each cell, and the keepers with a column in [out_lo, out_hi) leave
@@ -1041,7 +1044,7 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
             olo = narrow; ohi = min(narrow + nw, hi);
             clo = max(olo - 1, 0); chi = min(ohi + 1, Ws);
         }
-        load_tile();
+        if (!tile_ok) { load_tile(); tile_ok = true; }
         if (narrow >= 0) FS_COUNT(10, 1);
         if (retry) FS_COUNT(11, 1);
         if (!run_pass(clo, chi, olo, ohi)) {
