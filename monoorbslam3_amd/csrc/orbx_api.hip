@@ -204,6 +204,10 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // level, so a small call is bounded by its longest walk, and the blur pass it replaces hides beside FAST on a side stream:
 // measured at 1242x375 (tools/desc_crossover.sh) the one-pass kernel loses up to 96 frames (161 k against 165 k frames/s) and
 // wins from 128 (174.5 k against 168.4 k; 512 frames: 207 k against 197 k).
+// synchronous calls with a few frames: level-0 size from which the side chain (level 0's FAST and quadtree) is issued first
+#ifndef ORBX_SIDE_FIRST_PIXELS
+#define ORBX_SIDE_FIRST_PIXELS 1200000ull
+#endif
 #ifndef ORBX_FUSED_DESC_MIN_PIXELS
 #define ORBX_FUSED_DESC_MIN_PIXELS 55000000ull
 #endif
@@ -760,20 +764,32 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         int cells_before[ORBX_MAX_LEVELS + 1];
         cells_before[0] = 0;
         for (int l = 0; l < L; ++l) cells_before[l + 1] = cells_before[l] + LV.lv[l].n_cols * LV.lv[l].n_rows;
+        // Which chain the call ends up waiting for depends on the frame: at 1242x375 it is the main one, at 1920x1080 level 0's
+        // (its FAST and its quadtree -- one workgroup, 15 000 candidates -- take 47 + 88 us against 64 + 62 for levels 1..7 together).
+        // From a megapixel on the side chain is therefore ISSUED as soon as its inputs exist, ahead of the remaining resizes.
+        const bool side_first = (size_t)LV.lv[0].w * (size_t)LV.lv[0].h >= (size_t)ORBX_SIDE_FIRST_PIXELS;
+        auto launch_side = [&]() -> int {
+            HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_start[slot], 0));
+            launch_fast(c->side[slot], d_units, cells_before[G]);
+            orbx_launch_octree(c->side[slot], c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, G);
+            HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
+            return ORBX_OK;
+        };
         bool started = false;
         for (int l = 1; l < L;) {
             // the first launch also clears the candidate counters
             const int done = launch_resize(s, l, l == 1 ? b.cand_count : nullptr); // last level this launch produced
-            if (!started && done >= std::max(G - 1, 1)) { HIP_TRY(hipEventRecord(c->ev_start[slot], s)); started = true; } // counters are zero, levels < G exist
+            if (!started && done >= std::max(G - 1, 1)) { // counters are zero, levels < G exist
+                HIP_TRY(hipEventRecord(c->ev_start[slot], s));
+                started = true;
+                if (side_first) { int rc = launch_side(); if (rc) return rc; }
+            }
             l = done + 1;
         }
         HIP_TRY(hipEventRecord(c->ev_pyr[bslot], s));
         if (cells_before[L] > cells_before[G]) launch_fast(s, d_units + 4 * cells_before[G], cells_before[L] - cells_before[G]);
         orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, G, L);
-        HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_start[slot], 0));
-        launch_fast(c->side[slot], d_units, cells_before[G]);
-        orbx_launch_octree(c->side[slot], c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, G);
-        HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
+        if (!side_first) { int rc = launch_side(); if (rc) return rc; }
         HIP_TRY(hipStreamWaitEvent(c->side[bslot], c->ev_pyr[bslot], 0));
         launch_blur(c->side[bslot], 0, L);
         HIP_TRY(hipEventRecord(c->ev_blur[bslot], c->side[bslot]));

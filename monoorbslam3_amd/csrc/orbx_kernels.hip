@@ -1639,7 +1639,10 @@ int orbx_build_blur_tiles(const OrbxLevels &levels, uint16_t *out /* 4 per tile,
     return n;
 }
 
-// DistributeOctree (orbx_octree.h), compiled for two workgroup sizes
+// DistributeOctree (orbx_octree.h), compiled for three workgroup sizes
+#ifndef ORBX_OCT_HUGE_PIXELS
+#define ORBX_OCT_HUGE_PIXELS 1200000 // level size from which a call with a few frames gives the level 1024 threads (1920 x 1080: levels 0 and 1)
+#endif
 namespace oct_wide {
 #define OCT_NT ORBX_OCT_THREADS
 #include "orbx_octree.h"
@@ -1650,6 +1653,11 @@ namespace oct_batch {
 #include "orbx_octree.h"
 #undef OCT_NT
 } // namespace oct_batch
+namespace oct_huge { // a call with a few frames and a level of a megapixel or more: 1024 threads share its 10 000+ candidates
+#define OCT_NT 1024
+#include "orbx_octree.h"
+#undef OCT_NT
+} // namespace oct_huge
 
 // one 16-byte aligned layout for every level: [sort keys 8 (P2 + 16 pad keys)] [node 0/1: 4 M each] [cc: 16 M] [rank, newpos: 2 M each]
 // [node_of_rank: 2 NSC] [childpos: 8 NSC]
@@ -1680,10 +1688,16 @@ void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLev
     if (lds_bytes <= 160 * 1024 - 256 && small_nodes) {
         const void *fn = batch ? reinterpret_cast<const void *>(oct_batch::k_octree_lds) : reinterpret_cast<const void *>(oct_wide::k_octree_lds);
         (void)orbx_lds_opt_in(fn, lds_bytes); // per device; a refusal shows as the launch error the caller checks
-        if (batch)
+        int max_px = 0;
+        for (int l = level_begin; l < level_end; ++l) max_px = std::max(max_px, levels.lv[l].w * levels.lv[l].h);
+        if (batch) {
             hipLaunchKernelGGL(oct_batch::k_octree_lds, grid, dim3(ORBX_OCT_THREADS_BATCH), lds_bytes, s, d_levels, b, level_begin);
-        else
+        } else if (max_px >= ORBX_OCT_HUGE_PIXELS) {
+            (void)orbx_lds_opt_in(reinterpret_cast<const void *>(oct_huge::k_octree_lds), lds_bytes);
+            hipLaunchKernelGGL(oct_huge::k_octree_lds, grid, dim3(1024), lds_bytes, s, d_levels, b, level_begin);
+        } else {
             hipLaunchKernelGGL(oct_wide::k_octree_lds, grid, dim3(ORBX_OCT_THREADS), lds_bytes, s, d_levels, b, level_begin);
+        }
     } else {
         // quotas too large for the LDS-resident list: same algorithm with the list in global scratch
         hipLaunchKernelGGL(oct_wide::k_octree, grid, dim3(ORBX_OCT_THREADS), sort_lds_bytes, s, d_levels, b, level_begin);

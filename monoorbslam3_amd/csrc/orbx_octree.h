@@ -4,11 +4,12 @@
 // waves per CU: four 256-thread workgroups per CU instead of two 512-thread ones hide each other's barrier / LDS latency --
 // quadtree of 512 frames 0.28 -> 0.23 ms).  Not a stand-alone header.
 #ifndef OCT_NT
-#error "define OCT_NT (threads per workgroup, a multiple of 64, at most 512: the block scans keep 8 wave totals)"
+#error "define OCT_NT (threads per workgroup, a multiple of 64, at most 1024: the block scans keep 16 wave totals)"
 #endif
-// The block scans below hold one running total per wave in an 8-entry LDS array: a 1024-thread build (-DORBX_OCT_THREADS=1024,
-// tried in round 3) wrote past it and faulted.  Refuse such a build instead of relying on a comment.
-static_assert(OCT_NT % 64 == 0 && OCT_NT >= 64 && OCT_NT <= 512, "quadtree workgroups are whole waves, at most 8 of them (the block scans keep 8 wave totals)");
+// The block scans below hold one running total per wave -- two scans at a time -- in a 32-entry half of their LDS array: at most
+// 16 waves.  (Round 3's 1024-thread build kept the second scan's totals at a fixed offset of 8 and faulted; the offset now follows
+// the wave count, and anything beyond 16 waves is refused at compile time.)
+static_assert(OCT_NT % 64 == 0 && OCT_NT >= 64 && OCT_NT <= 1024, "quadtree workgroups are whole waves, at most 16 of them (the block scans keep 2 x 16 wave totals per half of their array)");
 
 // ---------------------------------------------------------------------------------------------
 // DistributeOctree, one workgroup per (frame, level).
@@ -73,12 +74,12 @@ __device__ __forceinline__ void block_scan_excl2(int va, int vb, int *ea, int *e
     int *buf = lds + 32 * par;
     par ^= 1;
     const int x = wave_scan_incl(va), z = wave_scan_incl(vb);
-    if (lane == 63) { buf[wid] = x; buf[8 + wid] = z; }
+    if (lane == 63) { buf[wid] = x; buf[OCT_NT / 64 + wid] = z; }
     __syncthreads();
     int pa = 0, pb = 0, sa = 0, sb = 0;
 #pragma unroll
     for (int i = 0; i < OCT_NT / 64; ++i) {
-        const int t = buf[i], u = buf[8 + i];
+        const int t = buf[i], u = buf[OCT_NT / 64 + i];
         if (i < wid) { pa += t; pb += u; }
         sa += t; sb += u;
     }
