@@ -795,15 +795,20 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
         // first is stored (row and item clamped instead of branching: surplus lanes repeat the last row / item).  The
         // bytes an item may hold beyond Ws + 6 are never looked at for a region pixel, and the loads stay inside the
         // frame (the tile's last row is at most h - 17 and its last byte at most w - 8 of that row).
+        // (row clamped in offset space: min(row, th - 1) * pitch + tx = min(row * pitch + tx, (th - 1) * pitch + tx) -- an add and a
+        // min per row group where a multiply per row group stood: nine quarter-rate 32-bit multiplies per strip)
         const int n_q = (Ws + 14) >> 3;
         const int tx = min(lane & 15, n_q - 1) * 8, ty0 = lane >> 4;
         unsigned long long v[9];
         int dst[9];
+        const int src_max = (th - 1) * pitch + tx, dst_max = (th - 1) * FS_TP + tx;
+        int so = ty0 * pitch + tx, dn = ty0 * FS_TP + tx;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int ty = min(ty0 + 4 * k, th - 1);
-            dst[k] = ty * FS_TP + tx;
-            v[k] = reinterpret_cast<const UnalignedU64b *>(S + (size_t)(ty * pitch + tx))->v;
+            const int sk = min(so, src_max);
+            dst[k] = min(dn, dst_max);
+            v[k] = reinterpret_cast<const UnalignedU64b *>(S + sk)->v;
+            so += 4 * pitch; dn += 4 * FS_TP;
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
