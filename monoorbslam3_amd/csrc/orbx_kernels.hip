@@ -456,24 +456,44 @@ __device__ __forceinline__ void fastc_load_ring(const uint8_t *t, int d[16])
 }
 struct __attribute__((packed, aligned(1))) UnalignedU64b { unsigned long long v; };
 
-__global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxLevels *__restrict__ levels,
-                                                        const FastCell *__restrict__ cells, u64 *__restrict__ cand,
-                                                        size_t cand_fs, int *__restrict__ cand_count, int n_cells,
-                                                        int n_frames)
+#ifdef OCT_PROF
+// development build (make prof): start / end time stamp (100 MHz) and the CU of every cell's workgroup of frame 0 (tools/fast_cell_times.py)
+#define FC_PROF_CELLS 16384
+__device__ unsigned long long g_fc_times[3 * FC_PROF_CELLS];
+unsigned long long *orbx_dev_fast_cell_times_symbol() { unsigned long long *p = nullptr; (void)hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_fc_times)); return p; }
+#endif
+// NW waves per cell (T = 64 NW threads): a call with a few frames is bounded by how long ONE cell takes, and the stages of a
+// cell are data-parallel over its 240 four-pixel groups and its queued pixels -- with two or four waves the compass pass is
+// two / one iteration instead of four and the queue batches run side by side.  The waves of a cell meet at workgroup
+// barriers; queue positions come from a wave scan plus the totals of the waves before (compass) or from one LDS atomic per
+// batch (pair test, keepers): the order of a cell's candidates is free (the quadtree does not depend on it).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_fast_cells_wave(FastSrc src, const OrbxLevels *__restrict__ levels,
+                                                             const FastCell *__restrict__ cells, u64 *__restrict__ cand,
+                                                             size_t cand_fs, int *__restrict__ cand_count, int n_cells,
+                                                             int n_frames)
 {
+    constexpr int T = 64 * NW;
+    constexpr int NIT = (30 * 8 + T - 1) / T;  // compass iterations: 240 (row, group) items
+    constexpr int NLD = (36 * 5 + T - 1) / T;  // eight-byte tile items per thread
+    static_assert(NW == 1 || NW == 2 || NW == 4, "one, two or four waves per cell");
     __shared__ __align__(16) uint8_t tile[36 * FC_TP];
     __shared__ __align__(16) uint8_t score[32 * FC_SP];
-    // queue2 aliases queue1: the 8-pair test compacts in place (a batch is read before it is written, and it is
-    // written at positions <= the ones just read)
     __shared__ uint16_t queue1[ORBX_CELL * ORBX_CELL];
-    uint16_t *queue2 = queue1;
+    // one wave compacts queue 1 in place (a batch is read before it is written, at positions <= the ones just read);
+    // several waves write a second queue
+    __shared__ uint16_t queue2_own[NW > 1 ? ORBX_CELL * ORBX_CELL : 1];
+    uint16_t *queue2 = NW > 1 ? queue2_own : queue1;
     __shared__ uint32_t keepers[15 * 15];
-    __shared__ int s_nkeep;
+    __shared__ int s_nkeep, s_q2n, s_wtot[4];
 
     int frame, cell_id;
     if (!xcd_remap(n_cells, n_frames, &frame, &cell_id)) return;
+#ifdef OCT_PROF
+    const unsigned long long fc_t0 = wall_clock64();
+#endif
     const FastCell cl = cells[cell_id];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int level = cl.level;
     const OrbxLevel &lv = levels->lv[level];
     const int x0 = ORBX_EDGE + cl.cx * ORBX_CELL, y0 = ORBX_EDGE + cl.cy * ORBX_CELL;
@@ -482,26 +502,26 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
     const int pitch = src.pitch[level];
     const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level] + (size_t)(y0 - 3) * pitch + (x0 - 4);
 
-    for (int i = lane; i < 32 * FC_SP / 16; i += 64) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
-    if (lane == 0) s_nkeep = 0;
+    for (int i = tid; i < 32 * FC_SP / 16; i += T) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) { s_nkeep = 0; s_q2n = 0; }
     {
-        // The 36 x 40-byte tile as 5 x th eight-byte items, three per lane, all requested before the first is stored (the
+        // The 36 x 40-byte tile as 5 x th eight-byte items, all of a thread's requested before the first is stored (the
         // index is clamped instead of branching: a surplus lane re-reads the last item).  Items of the last cell column may
         // reach past the end of the image row -- into the row's padding or the next row, never past the frame: the tile's
         // last row is at most h - 17 -- and those bytes are never looked at: the compass test masks the columns beyond the
         // cell and a ring of a cell pixel ends at column w - 17.
         const int n_items = 5 * th;
-        unsigned long long v[3];
-        int dst[3];
+        unsigned long long v[NLD];
+        int dst[NLD];
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int i = min(lane + 64 * it, n_items - 1);
+        for (int it = 0; it < NLD; ++it) {
+            const int i = min(tid + T * it, n_items - 1);
             const int ty = i / 5, tx = (i - 5 * ty) * 8;
             dst[it] = ty * FC_TP + tx;
             v[it] = reinterpret_cast<const UnalignedU64b *>(S + (size_t)ty * pitch + tx)->v;
         }
 #pragma unroll
-        for (int it = 0; it < 3; ++it) *reinterpret_cast<unsigned long long *>(&tile[dst[it]]) = v[it];
+        for (int it = 0; it < NLD; ++it) *reinterpret_cast<unsigned long long *>(&tile[dst[it]]) = v[it];
     }
     __syncthreads();
     int thr = levels->ini_th;
@@ -511,13 +531,13 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
         //   V - max(min(S,N), min(E,W)) > T   (both pairs hold a darker point)   or
         //   min(max(S,N), max(E,W)) - V > T   (both pairs hold a brighter point).
         // Two pixels per instruction in packed i16; m - (T+1) has its sign bit set iff the pixel fails, and the sign
-        // bytes of the item's four pixels are gathered with one v_perm.  acc collects them: bit 8j + 4 + it set =
+        // bytes of the item's four pixels are gathered with one v_perm.  acc collects them: bit 8j + (8 - NIT) + it set =
         // pixel j of iteration `it` is NOT a candidate.
         const s16x2 T1 = {(short)(thr + 1), (short)(thr + 1)};
         uint32_t acc = 0xFFFFFFFFu;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int i = it * 64 + lane;
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * T + tid;
             const int r = i >> 3, g = (i & 7) + 1;
             uint32_t w = 0x80808080u; // rows below the cell: no candidates
             if (r < ch) {
@@ -546,9 +566,10 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
         }
         uint32_t mask;
         {
-            const int g = (lane & 7) + 1;
+            constexpr uint32_t ITBITS = ((0xFFu << (8 - NIT)) & 0xFFu) * 0x01010101u; // the NIT result bits of every byte
+            const int g = (tid & 7) + 1;
             const int nvalid = min(max(cw + 4 - 4 * g, 0), 4); // region columns end at tc = 4 + cw
-            const uint32_t vmask = nvalid >= 4 ? 0xF0F0F0F0u : (0xF0F0F0F0u & ((1u << (8 * nvalid)) - 1u));
+            const uint32_t vmask = nvalid >= 4 ? ITBITS : (ITBITS & ((1u << (8 * nvalid)) - 1u));
             mask = ~acc & vmask;
         }
         int q1n;
@@ -560,20 +581,32 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
                 const int y = __shfl_up(incl, o);
                 if (lane >= o) incl += y;
             }
-            q1n = __shfl(incl, 63);
             int slot = incl - cnt;
+            if (NW > 1) { // the waves before this one
+                if (lane == 63) s_wtot[wid] = incl;
+                __syncthreads();
+                q1n = 0;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    const int t = s_wtot[k];
+                    if (k < wid) slot += t;
+                    q1n += t;
+                }
+            } else {
+                q1n = __shfl(incl, 63);
+            }
             uint32_t m = mask;
             while (m) {
                 const int b = __ffs(m) - 1;
                 m &= m - 1;
-                const int i = ((b & 7) - 4) * 64 + lane; // bit 8j + 4 + it
+                const int i = ((b & 7) - (8 - NIT)) * T + tid; // bit 8j + (8 - NIT) + it
                 queue1[slot++] = (uint16_t)(((i >> 3) << 8) | (4 * ((i & 7) + 1) + (b >> 3))); // (row, tc)
             }
         }
         __syncthreads();
         // ---- exact 8-pair test -> queue 2
         int q2n = 0;
-        for (int i0 = 0; i0 < q1n; i0 += 64) {
+        for (int i0 = 64 * wid; i0 < q1n; i0 += T) {
             const int i = i0 + lane;
             bool ok = false;
             int e = 0;
@@ -585,12 +618,18 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
             }
             const u64 mk = __ballot(ok);
             const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-            if (ok) queue2[q2n + pre] = (uint16_t)e;
+            int at = q2n;
+            if (NW > 1) {
+                if (lane == 0 && mk) at = atomicAdd(&s_q2n, (int)__popcll(mk));
+                at = __builtin_amdgcn_readfirstlane(at);
+            }
+            if (ok) queue2[at + pre] = (uint16_t)e;
             q2n += (int)__popcll(mk);
         }
         __syncthreads();
+        if (NW > 1) q2n = s_q2n;
         // ---- exact strength
-        for (int i = lane; i < q2n; i += 64) {
+        for (int i = tid; i < q2n; i += T) {
             const int e = queue2[i], r = e >> 8, tc = e & 255;
             int d[16];
             fastc_load_ring(&tile[(r + 3) * FC_TP + tc], d);
@@ -599,7 +638,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
         }
         __syncthreads();
         // ---- strict 3x3 NMS (everything outside the cell is 0 in the score map)
-        for (int i = lane; i < q2n; i += 64) {
+        for (int i = tid; i < q2n; i += T) {
             const int e = queue2[i], r = e >> 8, tc = e & 255;
             const uint8_t *sp = &score[(r + 1) * FC_SP + tc - 3];
             const int sc = sp[0];
@@ -610,14 +649,28 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(FastSrc src, const OrbxL
         __syncthreads();
         if (s_nkeep > 0 || pass == 1) break;
         thr = levels->min_th; // reference :604-607: nothing at the ini threshold -> redo the cell at the min threshold
+        if (NW > 1) { // (every thread has read the old count: it passed the barrier above after the read of q2n)
+            if (tid == 0) s_q2n = 0;
+        }
     }
     const int nk = s_nkeep;
+#ifdef OCT_PROF
+    if (frame == 0 && tid == 0) {
+        // global cell number: the launch's cells start at `cells`, the handle's list at level 0 -- (level, cy, cx) is the key
+        const int slot = (cl.level * 4096 + cl.cy * 64 + cl.cx) % FC_PROF_CELLS;
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_fc_times[3 * slot] = fc_t0;
+        g_fc_times[3 * slot + 1] = wall_clock64();
+        g_fc_times[3 * slot + 2] = ((unsigned long long)cl.level << 32) | hw;
+    }
+#endif
     if (nk == 0) return;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], nk);
-    base = __shfl(base, 0);
-    u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + base;
-    for (int i = lane; i < nk; i += 64) {
+    __shared__ int s_base;
+    if (tid == 0) s_base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], nk);
+    __syncthreads();
+    u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + s_base;
+    for (int i = tid; i < nk; i += T) {
         const uint32_t e = keepers[i];
         const uint32_t x = cl.cx * ORBX_CELL + ((e >> 8) & 255), y = cl.cy * ORBX_CELL + (e & 255);
         out[i] = (u64)(x | (y << 16)) | ((u64)(e >> 16) << 32);
@@ -1122,7 +1175,8 @@ int orbx_build_fast_cells(const OrbxLevels &levels, uint16_t *out /* 4 per cell,
 }
 
 void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
-                      const OrbxLevels &levels, const OrbxBuffers &b, const void *d_cells, int n_cells, int n_frames)
+                      const OrbxLevels &levels, const OrbxBuffers &b, const void *d_cells, int n_cells, int n_frames,
+                      int waves_per_cell)
 {
     if (n_cells <= 0) return;
     FastSrc src;
@@ -1131,9 +1185,14 @@ void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pit
         src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
         src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
     }
-    hipLaunchKernelGGL(k_fast_cells_wave, dim3(orbx_xcd_grid(n_cells, n_frames)), dim3(64), 0, s, src, d_levels,
-                       reinterpret_cast<const FastCell *>(d_cells), b.cand, b.cand_frame_stride, b.cand_count, n_cells,
-                       n_frames);
+    const dim3 grid(orbx_xcd_grid(n_cells, n_frames));
+    const FastCell *cells = reinterpret_cast<const FastCell *>(d_cells);
+    if (waves_per_cell >= 4)
+        hipLaunchKernelGGL(k_fast_cells_wave<4>, grid, dim3(256), 0, s, src, d_levels, cells, b.cand, b.cand_frame_stride, b.cand_count, n_cells, n_frames);
+    else if (waves_per_cell >= 2)
+        hipLaunchKernelGGL(k_fast_cells_wave<2>, grid, dim3(128), 0, s, src, d_levels, cells, b.cand, b.cand_frame_stride, b.cand_count, n_cells, n_frames);
+    else
+        hipLaunchKernelGGL(k_fast_cells_wave<1>, grid, dim3(64), 0, s, src, d_levels, cells, b.cand, b.cand_frame_stride, b.cand_count, n_cells, n_frames);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1650,6 +1709,7 @@ int orbx_build_blur_tiles(const OrbxLevels &levels, uint16_t *out /* 4 per tile,
 #endif
 namespace oct_wide {
 #define OCT_NT ORBX_OCT_THREADS
+#define OCT_PRIO 1 // the call waits for these few workgroups: their waves go first on a CU they share (orbx_octree.h)
 #include "orbx_octree.h"
 #undef OCT_NT
 } // namespace oct_wide
@@ -1660,7 +1720,13 @@ namespace oct_batch {
 } // namespace oct_batch
 namespace oct_huge { // a call with a few frames and a level of a megapixel or more: 1024 threads share its 10 000+ candidates
 #define OCT_NT 1024
+#define OCT_PYR 1 // passes from a count pyramid instead of candidate sweeps (orbx_octree.h)
+#undef OCT_REG
+#define OCT_REG 1 // 16 waves per workgroup leave 128 VGPRs a thread: candidates are streamed (they are read twice in all), not held
 #include "orbx_octree.h"
+#undef OCT_REG
+#undef OCT_PYR
+#undef OCT_PRIO
 #undef OCT_NT
 } // namespace oct_huge
 
@@ -1696,12 +1762,14 @@ void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLev
         int max_px = 0;
         for (int l = level_begin; l < level_end; ++l) max_px = std::max(max_px, levels.lv[l].w * levels.lv[l].h);
         if (batch) {
-            hipLaunchKernelGGL(oct_batch::k_octree_lds, grid, dim3(ORBX_OCT_THREADS_BATCH), lds_bytes, s, d_levels, b, level_begin);
+            hipLaunchKernelGGL(oct_batch::k_octree_lds, grid, dim3(ORBX_OCT_THREADS_BATCH), lds_bytes, s, d_levels, b, level_begin, (int)lds_bytes);
         } else if (max_px >= ORBX_OCT_HUGE_PIXELS) {
-            (void)orbx_lds_opt_in(reinterpret_cast<const void *>(oct_huge::k_octree_lds), lds_bytes);
-            hipLaunchKernelGGL(oct_huge::k_octree_lds, grid, dim3(1024), lds_bytes, s, d_levels, b, level_begin);
+            // one workgroup per CU anyway: it takes the rest of the CU's LDS for its count pyramid
+            const size_t huge_bytes = 160 * 1024 - 1024;
+            (void)orbx_lds_opt_in(reinterpret_cast<const void *>(oct_huge::k_octree_lds), huge_bytes);
+            hipLaunchKernelGGL(oct_huge::k_octree_lds, grid, dim3(1024), huge_bytes, s, d_levels, b, level_begin, (int)huge_bytes);
         } else {
-            hipLaunchKernelGGL(oct_wide::k_octree_lds, grid, dim3(ORBX_OCT_THREADS), lds_bytes, s, d_levels, b, level_begin);
+            hipLaunchKernelGGL(oct_wide::k_octree_lds, grid, dim3(ORBX_OCT_THREADS), lds_bytes, s, d_levels, b, level_begin, (int)lds_bytes);
         }
     } else {
         // quotas too large for the LDS-resident list: same algorithm with the list in global scratch

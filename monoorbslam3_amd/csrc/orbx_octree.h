@@ -372,7 +372,7 @@ struct OctL {
     int n;
 };
 #define OCT_NORANK 0xFFFFu
-#define OCT_RANK_BY_COUNTING 320 // final-phase keys up to which ranks are counted instead of sorted
+#define OCT_RANK_BY_COUNTING (OCT_NT >= 1024 ? 1024 : 320) // final-phase keys up to which ranks are counted instead of sorted (one thread per key)
 
 #ifndef OCT_UNROLL
 #define OCT_UNROLL 4
@@ -489,16 +489,102 @@ __device__ __forceinline__ void octl_apply(const OctL &c, int cur, int size, int
     *n_expand = E;
 }
 
+#ifdef OCT_PYR
+// ---------------------------------------------------------------------------------------------
+// Passes without a candidate sweep (OCT_PYR builds: a level of a megapixel with 10 000+ candidates in ONE workgroup).
+// What a pass needs from the candidates is only how many of them sit in each child quadrant of the nodes it splits.  The
+// descent code makes a node of depth d the set of candidates with a given (initial node, first d digits), so ONE sweep that
+// counts the candidates per depth-D path, summed four by four up to depth 0, holds every count a pass can ask for as long as
+// it splits nodes above depth D: pyr[off(d) + path], off(d) = n_ini (4^d - 1) / 3, path = initial node * 4^d + digits.
+// Nodes carry their path; the list bookkeeping (ranks, scans, order of the new list) is octl_apply's, the sweep is gone.
+// Once a node of depth D with more than one candidate appears (corners crowded into a small area) the kernel locates every
+// candidate's node from a table of the list's paths and carries on with the sweeping passes.
+// ---------------------------------------------------------------------------------------------
+struct OctPyr {
+    uint32_t *tab;      // the count pyramid; later the table (depth, path) -> list position
+    uint32_t *path[2];  // path of every node of the two list copies
+    uint32_t *xs, *ys;  // a candidate's depth-D path = xs[x] | ys[y]: the node grid is a product grid (see above), so the D
+                        // left/right choices depend on x alone (kept at the even bits, under the initial node's index) and
+                        // the D up/down choices on y alone (odd bits) -- two look-ups per candidate instead of a descent
+    int D, n_ini;
+    __device__ __forceinline__ uint32_t off(int d) const { return (uint32_t)n_ini * (((1u << (2 * d)) - 1u) / 3u); }
+};
+
+__device__ __forceinline__ void octl_apply_pyr(const OctL &c, const OctPyr &py, int cur, int size, int nsplit, int *new_size,
+                                               int *n_expand, int *deep, int *lds, int &par)
+{
+    const int nxt = cur ^ 1;
+    const uint32_t *ncur = cur ? c.node[1] : c.node[0];
+    uint32_t *nnxt = nxt ? c.node[1] : c.node[0];
+    const uint32_t *pcur = cur ? py.path[1] : py.path[0]; // (selected, not indexed: an indexed pointer pair would live in scratch)
+    uint32_t *pnxt = nxt ? py.path[1] : py.path[0];
+    const int len = 4 * nsplit;
+    const int chunk = (len + OCT_NT - 1) / OCT_NT;
+    const int i0 = min((int)threadIdx.x * chunk, len), i1 = min(i0 + chunk, len);
+    int s = 0, e = 0;
+    for (int i = i0; i < i1; ++i) {
+        const uint32_t n = c.cc[4 * c.node_of_rank[i >> 2] + (i & 3)];
+        s += n > 0;
+        e += n > 1;
+    }
+    const int chunk2 = (size + OCT_NT - 1) / OCT_NT;
+    const int j0 = min((int)threadIdx.x * chunk2, size), j1 = min(j0 + chunk2, size);
+    int u = 0;
+    for (int j = j0; j < j1; ++j) u += !(c.rank[j] < (uint32_t)nsplit);
+    int ci, ui, TE, U;
+    block_scan_excl2(s | (e << 16), u, &ci, &ui, &TE, &U, lds, par);
+    ci &= 0xFFFF;
+    const int T = TE & 0xFFFF, E = TE >> 16;
+    int dp = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int parent = c.node_of_rank[i >> 2];
+        const uint32_t n = c.cc[4 * parent + (i & 3)];
+        if (n > 0) {
+            const int pos = T - 1 - ci;
+            const uint32_t d = (ncur[parent] >> 24) + 1;
+            nnxt[pos] = (d << 24) | n;
+            pnxt[pos] = 4 * pcur[parent] + (i & 3);
+            dp |= (int)d >= py.D && n > 1;
+            ++ci;
+        }
+    }
+    for (int j = j0; j < j1; ++j) {
+        if (!(c.rank[j] < (uint32_t)nsplit)) {
+            const int pos = T + ui;
+            nnxt[pos] = ncur[j];
+            pnxt[pos] = pcur[j];
+            ++ui;
+        }
+    }
+    if (dp) *deep = 1; // (cleared by the caller before the pass)
+    __syncthreads(); // the old child counts have been read, the new list is complete
+    const int nsz = T + U;
+    for (int i = threadIdx.x; i < 4 * nsz; i += OCT_NT) {
+        const uint32_t nd = nnxt[i >> 2], d = nd >> 24;
+        // children of a node of depth D are below the pyramid: such a node is split only after the switch to sweeps
+        c.cc[i] = ((int)d < py.D && (nd & 0xFFFFFF) > 1) ? py.tab[py.off((int)d + 1) + 4 * pnxt[i >> 2] + (i & 3)] : 0u;
+    }
+    __syncthreads();
+    *new_size = nsz;
+    *n_expand = E;
+}
+#endif
+
 #ifndef OCT_MIN_WAVES
 #define OCT_MIN_WAVES 1
 #endif
-__global__ __launch_bounds__(OCT_NT, OCT_MIN_WAVES) void k_octree_lds(const OrbxLevels *__restrict__ levels, OrbxBuffers b, int level0)
+__global__ __launch_bounds__(OCT_NT, OCT_MIN_WAVES) void k_octree_lds(const OrbxLevels *__restrict__ levels, OrbxBuffers b, int level0, int dyn_lds_bytes)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int lds[64];
     int par = 0; // which half of `lds` the next scan uses
     __shared__ int s_first;
 
+#ifdef OCT_PRIO
+    // A call with a few frames waits for this workgroup while the other stream's FAST waves share its CU: measured with the
+    // phase stamps, a level-0 quadtree stood still for 49 us -- the run time of the FAST launch beside it -- at default priority.
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const int level = level0 + blockIdx.x, frame = blockIdx.y;
     const OrbxLevel lv = levels->lv[level];
     const int tid = threadIdx.x;
@@ -531,6 +617,29 @@ __global__ __launch_bounds__(OCT_NT, OCT_MIN_WAVES) void k_octree_lds(const Orbx
     c.newpos = c.rank + M;
     c.node_of_rank = c.newpos + M;
     c.childpos = c.node_of_rank + NSC;
+#ifdef OCT_PYR
+    // what the launch gave beyond the list's own arrays: node paths and the count pyramid, as deep as fits (at most 6 digits:
+    // a level of 2000 features is done at depth 4-5)
+    OctPyr py;
+    bool pyr_mode = false;
+    __shared__ int s_deep;
+    {
+        unsigned char *extra = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(c.childpos + 4 * NSC) + 15) & ~(uintptr_t)15);
+        const int nxy = lv.w + lv.h; // candidate coordinates are below the level's size whatever their origin
+        const long left = (long)dyn_lds_bytes - (long)(extra - smem) - 8L * M - 4L * nxy;
+        py.path[0] = reinterpret_cast<uint32_t *>(extra);
+        py.path[1] = py.path[0] + M;
+        py.xs = py.path[1] + M;
+        py.ys = py.xs + lv.w;
+        py.tab = py.ys + lv.h;
+        py.n_ini = lv.n_ini;
+        py.D = 0;
+        for (int d = 6; d >= 2; --d)
+            if ((long)lv.n_ini * (long)(((1u << (2 * d + 2)) - 1u) / 3u) * 4L <= left) { py.D = d; break; }
+        pyr_mode = py.D >= 2;
+        if (tid == 0) s_deep = 0;
+    }
+#endif
 
     // ---- descent code of every candidate + initial nodes (:645-686)
     int cur = 0;
@@ -578,6 +687,103 @@ __global__ __launch_bounds__(OCT_NT, OCT_MIN_WAVES) void k_octree_lds(const Orbx
         }
     };
     __syncthreads();
+    int size;
+#ifdef OCT_PYR
+    // Node of a candidate in the current list: the table (depth, path) -> list position takes the pyramid's place, every
+    // node's position is handed down to the depth-D paths below it (the list's nodes partition the candidates, so a depth-D
+    // path lies under exactly one of them), and a candidate needs ONE look-up.
+    auto path_table = [&]() { // (called with the list complete and every reader of the pyramid past a barrier)
+        const uint32_t *nc = cur ? c.node[1] : c.node[0];
+        const int total = (int)py.off(py.D + 1);
+        for (int i = tid; i < total; i += OCT_NT) py.tab[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        const uint32_t *pc = cur ? py.path[1] : py.path[0];
+        for (int j = tid; j < size; j += OCT_NT) py.tab[py.off((int)(nc[j] >> 24)) + pc[j]] = (uint32_t)j;
+        __syncthreads();
+        for (int d = 1; d <= py.D; ++d) {
+            const int ne = lv.n_ini << (2 * d);
+            const uint32_t *above = py.tab + py.off(d - 1);
+            uint32_t *here = py.tab + py.off(d);
+            for (int e = tid; e < ne; e += OCT_NT)
+                if (here[e] == 0xFFFFFFFFu) here[e] = above[e >> 2];
+            __syncthreads();
+        }
+    };
+    const uint32_t *leaf_of = py.tab + py.off(py.D);
+    auto locate = [&](u64 cd, int ndig, uint32_t *code_out) -> uint32_t { // ... and the descent code with ndig >= D digits
+        const uint32_t idx = descend(cd, ndig, code_out);
+        return leaf_of[(idx << (2 * py.D)) + (*code_out >> (32 - 2 * py.D))];
+    };
+    auto locate_xy = [&](u64 cd) -> uint32_t { // the same from the two path tables (no code: the finish needs none)
+        return leaf_of[py.xs[(uint32_t)cd & 0xFFFF] | py.ys[(uint32_t)(cd >> 16) & 0xFFFF]];
+    };
+    if (pyr_mode) {
+        const int total = (int)py.off(py.D + 1);
+        const uint32_t offD = py.off(py.D);
+        for (int i = tid; i < total; i += OCT_NT) py.tab[i] = 0;
+        for (int x = tid; x < lv.w; x += OCT_NT) { // (the same halvings as `descend`, one axis at a time)
+            const int idx = (int)__umulhi((uint32_t)x, inv_hx);
+            int lo = lv.h_x * idx, hi = (idx == lv.n_ini - 1) ? (lv.w - ORBX_EDGE) : lv.h_x * (idx + 1);
+            uint32_t bits = (uint32_t)idx << (2 * py.D);
+            for (int d = 0; d < py.D; ++d) {
+                const int mid = lo + ((hi - lo) >> 1), q = x >= mid;
+                lo = q ? mid : lo; hi = q ? hi : mid;
+                bits |= (uint32_t)q << (2 * (py.D - 1 - d));
+            }
+            py.xs[x] = bits;
+        }
+        for (int y = tid; y < lv.h; y += OCT_NT) {
+            int lo = 0, hi = lv.region_h;
+            uint32_t bits = 0;
+            for (int d = 0; d < py.D; ++d) {
+                const int mid = lo + ((hi - lo) >> 1), q = y >= mid;
+                lo = q ? mid : lo; hi = q ? hi : mid;
+                bits |= (uint32_t)q << (2 * (py.D - 1 - d) + 1);
+            }
+            py.ys[y] = bits;
+        }
+        __syncthreads();
+        auto count = [&](u64 cd) {
+            atomicAdd(&py.tab[offD + (py.xs[(uint32_t)cd & 0xFFFF] | py.ys[(uint32_t)(cd >> 16) & 0xFFFF])], 1u);
+        };
+#pragma unroll
+        for (int u = 0; u < OCT_REG; ++u) {
+            rn[u] = 0; rc[u] = 0;
+            if (tid + u * OCT_NT < c.n) count(rcand[u]);
+        }
+        for (int p0 = OCT_REG * OCT_NT + tid; p0 < c.n; p0 += OCT_UNROLL * OCT_NT) {
+            u64 cdv[OCT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < OCT_UNROLL; ++u) cdv[u] = c.cand[min(p0 + u * OCT_NT, c.n - 1)];
+#pragma unroll
+            for (int u = 0; u < OCT_UNROLL; ++u)
+                if (p0 + u * OCT_NT < c.n) count(cdv[u]);
+        }
+        __syncthreads();
+        for (int d = py.D - 1; d >= 0; --d) {
+            const int ne = lv.n_ini << (2 * d);
+            const uint32_t *below = py.tab + py.off(d + 1);
+            uint32_t *here = py.tab + py.off(d);
+            for (int e = tid; e < ne; e += OCT_NT) here[e] = below[4 * e] + below[4 * e + 1] + below[4 * e + 2] + below[4 * e + 3];
+            __syncthreads();
+        }
+        const int chunk = (lv.n_ini + OCT_NT - 1) / OCT_NT;
+        const int i0 = min(tid * chunk, lv.n_ini), i1 = min(i0 + chunk, lv.n_ini);
+        int s = 0;
+        for (int i = i0; i < i1; ++i) s += py.tab[i] > 0;
+        int pos = block_scan_excl(s, &size, lds, par);
+        for (int i = i0; i < i1; ++i)
+            if (py.tab[i] > 0) {
+                c.node[0][pos] = py.tab[i]; // depth 0
+                py.path[0][pos] = (uint32_t)i;
+                ++pos;
+            }
+        __syncthreads();
+        for (int i = tid; i < 4 * size; i += OCT_NT) c.cc[i] = py.tab[py.off(1) + 4 * py.path[0][i >> 2] + (i & 3)];
+        __syncthreads();
+    } else
+#endif
+    {
 #pragma unroll
     for (int u = 0; u < OCT_REG; ++u) {
         rn[u] = 0; rc[u] = 0;
@@ -602,7 +808,6 @@ __global__ __launch_bounds__(OCT_NT, OCT_MIN_WAVES) void k_octree_lds(const Orbx
         }
     }
     __syncthreads();
-    int size;
     {
         const int chunk = (lv.n_ini + OCT_NT - 1) / OCT_NT;
         const int i0 = min(tid * chunk, lv.n_ini), i1 = min(i0 + chunk, lv.n_ini);
@@ -641,7 +846,52 @@ __global__ __launch_bounds__(OCT_NT, OCT_MIN_WAVES) void k_octree_lds(const Orbx
         }
         __syncthreads();
     }
+    }
     OCT_MARK(1);
+#ifdef OCT_PYR
+    // the switch to sweeping passes: every candidate finds its node (and its full descent code), the child counts of the
+    // whole list are counted once
+    auto to_sweeps = [&]() {
+        path_table();
+        have = max(depth, py.D);
+        const uint32_t *nc = cur ? c.node[1] : c.node[0];
+        for (int i = tid; i < 4 * size; i += OCT_NT) c.cc[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < OCT_REG; ++u)
+            if (tid + u * OCT_NT < c.n) {
+                rn[u] = locate(rcand[u], have, &rc[u]);
+                atomicAdd(&c.cc[4 * rn[u] + ((rc[u] >> ((30 - 2 * (nc[rn[u]] >> 24)) & 31)) & 3)], 1u);
+            }
+        for (int p = OCT_REG * OCT_NT + tid; p < c.n; p += OCT_NT) {
+            uint32_t code;
+            const uint32_t nd = locate(c.cand[p], have, &code);
+            c.pnode[p] = nd;
+            c.pcode[p] = code;
+            atomicAdd(&c.cc[4 * nd + ((code >> ((30 - 2 * (nc[nd] >> 24)) & 31)) & 3)], 1u);
+        }
+        __syncthreads();
+        pyr_mode = false;
+    };
+    // one pass in whichever form the level is in
+    auto apply = [&](int nsplit, int *n_expand) {
+        if (pyr_mode) {
+            octl_apply_pyr(c, py, cur, size, nsplit, &size, n_expand, &s_deep, lds, par);
+            cur ^= 1; ++applies;
+            if (s_deep) to_sweeps(); // (s_deep is written before the barriers of the pass and never cleared: the switch is final)
+        } else {
+            more_digits();
+            octl_apply(c, cur, size, nsplit, &size, n_expand, lds, par, rn, rc);
+            cur ^= 1; ++applies;
+        }
+    };
+#else
+    auto apply = [&](int nsplit, int *n_expand) {
+        more_digits();
+        octl_apply(c, cur, size, nsplit, &size, n_expand, lds, par, rn, rc);
+        cur ^= 1; ++applies;
+    };
+#endif
 
     // ---- main rounds (:692-751)
     bool finish = false;
@@ -661,9 +911,7 @@ __global__ __launch_bounds__(OCT_NT, OCT_MIN_WAVES) void k_octree_lds(const Orbx
         __syncthreads();
         OCT_MARK(2);
         int n_expand;
-        more_digits();
-        octl_apply(c, cur, size, nsplit, &size, &n_expand, lds, par, rn, rc);
-        cur ^= 1; ++applies;
+        apply(nsplit, &n_expand);
         OCT_MARK(4 + (size << 8));
         if (size > N || size == pre) {
             finish = true;
@@ -752,9 +1000,7 @@ __global__ __launch_bounds__(OCT_NT, OCT_MIN_WAVES) void k_octree_lds(const Orbx
                 __syncthreads();
                 OCT_MARK(7);
                 int ne2;
-                more_digits();
-                octl_apply(c, cur, size, nsplit2, &size, &ne2, lds, par, rn, rc);
-                cur ^= 1; ++applies;
+                apply(nsplit2, &ne2);
                 OCT_MARK(8 + (size << 8));
                 if (size >= N || size == pre2) finish = true;
             }
@@ -765,6 +1011,9 @@ __global__ __launch_bounds__(OCT_NT, OCT_MIN_WAVES) void k_octree_lds(const Orbx
     // ---- strongest point per node (:812-827); the node arrays are dead now and hold the maxima
     u64 *best = reinterpret_cast<u64 *>(c.node[0]);
     __syncthreads();
+#ifdef OCT_PYR
+    if (pyr_mode) path_table(); // no pass has swept the candidates: they find their nodes now
+#endif
     for (int j = tid; j < size; j += OCT_NT) best[j] = 0;
     __syncthreads();
     const uint32_t ncols = (uint32_t)lv.n_cols;
@@ -774,6 +1023,22 @@ __global__ __launch_bounds__(OCT_NT, OCT_MIN_WAVES) void k_octree_lds(const Orbx
                                (y % ORBX_CELL) * ORBX_CELL + x % ORBX_CELL;
         atomicMax(&best[node], ((u64)resp << 32) | (u64)(0xFFFFFFFFu - order));
     };
+#ifdef OCT_PYR
+    if (pyr_mode) {
+#pragma unroll
+        for (int u = 0; u < OCT_REG; ++u)
+            if (tid + u * OCT_NT < c.n) offer(rcand[u], locate_xy(rcand[u]));
+        for (int p0 = OCT_REG * OCT_NT + tid; p0 < c.n; p0 += OCT_UNROLL * OCT_NT) {
+            u64 cdv[OCT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < OCT_UNROLL; ++u) cdv[u] = c.cand[min(p0 + u * OCT_NT, c.n - 1)];
+#pragma unroll
+            for (int u = 0; u < OCT_UNROLL; ++u)
+                if (p0 + u * OCT_NT < c.n) offer(cdv[u], locate_xy(cdv[u]));
+        }
+    } else
+#endif
+    {
 #pragma unroll
     for (int u = 0; u < OCT_REG; ++u)
         if (tid + u * OCT_NT < c.n) offer(rcand[u], rn[u]);
@@ -789,6 +1054,7 @@ __global__ __launch_bounds__(OCT_NT, OCT_MIN_WAVES) void k_octree_lds(const Orbx
 #pragma unroll
         for (int u = 0; u < OCT_UNROLL; ++u)
             if (p0 + u * OCT_NT < c.n) offer(cdv[u], pn[u]);
+    }
     }
     __syncthreads();
     uint2 *sel = b.sel + (size_t)frame * levels->kcap_total + lv.kp_off;

@@ -372,6 +372,25 @@ def test_quadtree_on_crowded_corners(oracle_mod, w, h, nf, n_patches, side):
     _check_frame(ex, orc, img, kps, desc, stages=True)
 
 
+@pytest.mark.parametrize("w,h,nf,n_patches,side,scene", [(1920, 1080, 2000, 10, 60, False), (1920, 1080, 3000, 3, 90, False),
+                                                          (1920, 1080, 2000, 6, 50, True), (1500, 900, 1500, 4, 64, True),
+                                                          (2600, 700, 2500, 8, 40, True)])
+def test_quadtree_of_a_megapixel_level(oracle_mod, w, h, nf, n_patches, side, scene):
+    """A single frame with levels of a megapixel and more: their quadtree runs its passes from a table of candidate counts per
+    descent path (no candidate sweep per pass) and goes back to sweeps when a node below the table's depth still holds several
+    candidates -- noise patches force that, on a flat background from the first passes on, on a scene after a few.  Same key
+    points in the same order as the reference's list (ORBextractor.cc:640-830)."""
+    ex, orc = _mk(oracle_mod, nf, w, h, ini=5 if not scene else 20, mn=2 if not scene else 7)
+    rng = np.random.RandomState(w + nf + side)
+    img = synth.make_frames(1, w, h, seed=777 + side)[0] if scene else np.full((h, w), 128, np.uint8)
+    for _ in range(n_patches):
+        x0, y0 = rng.randint(20, w - 20 - side), rng.randint(20, h - 20 - side)
+        img[y0:y0 + side, x0:x0 + side] = rng.randint(0, 256, (side, side))
+    kps, desc = ex(img)
+    _check_frame(ex, orc, img, kps, desc, stages=False)
+    assert ex.tap_level_counts(0).tolist() == orc.extract(img)[2]
+
+
 def test_batch_device_pointers_and_determinism(oracle_mod):
     """HBM-resident batch API (the bench path): two runs give identical bytes, and they match the oracle"""
     import torch

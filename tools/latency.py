@@ -16,7 +16,11 @@ W = int(sys.argv[1]) if len(sys.argv) > 2 else 1242
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 375
 NF = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 img = synth.make_frames(1, W, H)[0]
-ex = ORBExtractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H)
+variants = {}
+for kv in sys.argv[4:]:  # kernel-choice switches (monoorbslam3_amd/extractor.py VARIANTS), e.g. split_level0=0
+    k, v = kv.split("=")
+    variants[k] = int(v) if v.lstrip("-").isdigit() else v
+ex = ORBExtractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, variants=variants)
 for _ in range(5):
     ex(img)
 t0 = time.perf_counter()

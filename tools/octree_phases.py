@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase time stamps of k_octree_lds for one frame (development build: make -C monoorbslam3_amd/csrc prof).
-Usage on the GPU box: python tools/octree_phases.py [batch [W H]]"""
+Usage on the GPU box: python tools/octree_phases.py [batch [W H [name=value ...]]]"""
 import ctypes as C
 import os
 import shutil
@@ -26,7 +26,11 @@ from monoorbslam3_amd.extractor import ORBExtractor  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1242, 375)
 imgs = synth.make_frames(B, W, H)
-ex = ORBExtractor(2000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
+variants = {}
+for kv in sys.argv[4:]:  # kernel-choice switches, e.g. split_level0=0 (one chain: the quadtree runs with nothing beside it)
+    k, v = kv.split("=")
+    variants[k] = int(v) if v.lstrip("-").isdigit() else v
+ex = ORBExtractor(2000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, variants=variants)
 NAMES = {0: "start", 1: "codes + initial nodes", 2: "ranks", 3: "child counts", 4: "apply -> size", 5: "sort (K keys)", 6: "child counts",
          7: "stop index", 8: "apply -> size", 9: "rounds done", 10: "strongest + out (n cand)"}
 for it in range(3):
