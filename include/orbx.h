@@ -141,7 +141,8 @@ int orbx_tap_sincos(orbx_t *h, const float *angles_deg, int n, float *cos_sin);
 #define ORBX_VAR_ZERO_COPY 8    /* 1 small calls write their records into pinned host memory (default), 0 copy them back */
 #define ORBX_VAR_DESC 9         /* 0 by call size (default), 1 separate blur pass + k_orient_desc, 2 k_blur_desc (blur and
                                  * descriptors in one pass over the raw level, no blurred level in memory) */
-#define ORBX_VAR_FAST_CELL_WAVES 10 /* calls with a few frames: waves that share one 30x30 FAST cell (1, 2 or 4) */
+#define ORBX_VAR_FAST_CELL_GROUP 10 /* calls with a few frames: FAST cells (one wave each) per workgroup -- the group reserves its
+                                     * place in the candidate list with one atomic: 1, 4, 8 (default) or 16 */
 #define ORBX_N_VARIANTS 11
 int orbx_set_variant(orbx_t *h, int which, int value);
 int orbx_get_variant(const orbx_t *h, int which, int *value);

@@ -76,7 +76,7 @@ struct orbx_ctx {
     uint16_t *d_fast_strips; int n_fast_strips, n_fast_strips0; // strips of all levels / of level 0
     int fast_variant;                                           // ORBX_VAR_FAST: 0 = by call size (default), 1 = one wave per cell, 2 = strips
     int zero_copy;                                              // ORBX_VAR_ZERO_COPY
-    int fast_cell_waves;                                        // ORBX_VAR_FAST_CELL_WAVES: waves per cell of the few-frames FAST kernel (1, 2 or 4)
+    int fast_cell_group;                                        // ORBX_VAR_FAST_CELL_GROUP: cells (one wave each) per workgroup of the few-frames FAST kernel: 1, 4, 8 (default) or 16
     int desc_variant;                                           // ORBX_VAR_DESC: 0 = by call size, 1 = blur pass + k_orient_desc, 2 = k_blur_desc (fused)
     uint16_t *d_blur_tiles; int n_blur_tiles;
     // the Gaussian on the matrix pipe: strip list, band tables, per-level record; levels [0, blur_mfma_levels)
@@ -505,7 +505,7 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
     c->n_sub = 1;
     c->zero_copy = 1;
     c->desc_variant = 0;
-    c->fast_cell_waves = 1;
+    c->fast_cell_group = 8;
     if (hipMalloc((void **)&c->d_levels, sizeof(OrbxLevels)) != hipSuccess ||
         hipMalloc((void **)&c->d_umax, sizeof(int) * 16) != hipSuccess ||
         hipMalloc((void **)&c->d_taps, sizeof(int) * 8) != hipSuccess)
@@ -701,7 +701,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         // that the kernels are timed as they run beside the others (orbx_stage_times_in_step_ms)
         InStep ft(c, ORBX_STAGE_FAST, st);
         if (strips) orbx_launch_fast_strips(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, units, n, n_frames);
-        else orbx_launch_fast(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, units, n, n_frames, c->fast_cell_waves);
+        else orbx_launch_fast(st, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, units, n, n_frames, c->fast_cell_group);
     };
     // 7x7 Gaussian of levels [lb, le): on the matrix pipe for the levels that are large enough when the call is a batch
     // (ORBX_VAR_BLUR = 2 forces it for any batch, 0 switches it off), the VALU kernels for the rest
@@ -1174,7 +1174,7 @@ static int *variant_field(orbx_ctx *c, int which, int *lo, int *hi)
     case ORBX_VAR_STREAMS: *lo = 1; *hi = 8; return &c->n_sub;
     case ORBX_VAR_ZERO_COPY: *lo = 0; *hi = 1; return &c->zero_copy;
     case ORBX_VAR_DESC: *lo = 0; *hi = 2; return &c->desc_variant;
-    case ORBX_VAR_FAST_CELL_WAVES: *lo = 1; *hi = 4; return &c->fast_cell_waves;
+    case ORBX_VAR_FAST_CELL_GROUP: *lo = 1; *hi = 16; return &c->fast_cell_group;
     default: return nullptr;
     }
 }

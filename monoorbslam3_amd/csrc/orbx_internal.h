@@ -93,7 +93,7 @@ void orbx_launch_resize2(hipStream_t s, const uint8_t *src, size_t src_fs, int s
                          int d2_pitch, int w2, int h2, const OrbxTap *xtap2, const OrbxTap *ytap2, int n_frames, int *zero_counts);
 void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                       const OrbxLevels &levels, const OrbxBuffers &b, const void *d_cells, int n_cells, int n_frames,
-                      int waves_per_cell);
+                      int cells_per_group);
 int orbx_build_fast_cells(const OrbxLevels &levels, uint16_t *out);
 // strips of up to three cells (one wave each), level-major; levels [level_begin, level_end)
 int orbx_build_fast_strips(const OrbxLevels &levels, int level_begin, int level_end, uint16_t *out);

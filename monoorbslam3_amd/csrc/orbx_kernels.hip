@@ -456,74 +456,80 @@ __device__ __forceinline__ void fastc_load_ring(const uint8_t *t, int d[16])
 }
 struct __attribute__((packed, aligned(1))) UnalignedU64b { unsigned long long v; };
 
+// A wave's LDS instructions execute in issue order: between a producer and a consumer stage of ONE wave the only thing
+// needed is that the compiler keeps that order.
+#define FS_WAVE_ORDER() asm volatile("" ::: "memory")
 #ifdef OCT_PROF
 // development build (make prof): start / end time stamp (100 MHz) and the CU of every cell's workgroup of frame 0 (tools/fast_cell_times.py)
 #define FC_PROF_CELLS 16384
 __device__ unsigned long long g_fc_times[3 * FC_PROF_CELLS];
 unsigned long long *orbx_dev_fast_cell_times_symbol() { unsigned long long *p = nullptr; (void)hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_fc_times)); return p; }
 #endif
-// NW waves per cell (T = 64 NW threads): a call with a few frames is bounded by how long ONE cell takes, and the stages of a
-// cell are data-parallel over its 240 four-pixel groups and its queued pixels -- with two or four waves the compass pass is
-// two / one iteration instead of four and the queue batches run side by side.  The waves of a cell meet at workgroup
-// barriers; queue positions come from a wave scan plus the totals of the waves before (compass) or from one LDS atomic per
-// batch (pair test, keepers): the order of a cell's candidates is free (the quadtree does not depend on it).
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_fast_cells_wave(FastSrc src, const OrbxLevels *__restrict__ levels,
-                                                             const FastCell *__restrict__ cells, u64 *__restrict__ cand,
-                                                             size_t cand_fs, int *__restrict__ cand_count, int n_cells,
-                                                             int n_frames)
+// CPW cells per workgroup, one wave each.  The waves share nothing while they work -- every wave has its own tile, score map
+// and queues, and orders its own LDS traffic (a wave's LDS instructions execute in issue order) -- and meet once, at the end:
+// the keepers of all CPW cells reserve their place in the level's candidate list with ONE atomic.  The reservation is a
+// returning atomic on one address per (frame, level), and such atomics are served one at a time, about 8 ns each: with one
+// per cell the 2304 cells of a 1920x1080 level 0 stood in line for 18 us after 12 us of work, the 1600 cells of level 1
+// for 13 (per-cell time stamps, tools/fast_cell_times.py).
+template <int CPW>
+__global__ __launch_bounds__(64 * CPW) void k_fast_cells_wave(FastSrc src, const OrbxLevels *__restrict__ levels,
+                                                              const FastCell *__restrict__ cells, u64 *__restrict__ cand,
+                                                              size_t cand_fs, int *__restrict__ cand_count, int n_cells,
+                                                              int n_frames)
 {
-    constexpr int T = 64 * NW;
-    constexpr int NIT = (30 * 8 + T - 1) / T;  // compass iterations: 240 (row, group) items
-    constexpr int NLD = (36 * 5 + T - 1) / T;  // eight-byte tile items per thread
-    static_assert(NW == 1 || NW == 2 || NW == 4, "one, two or four waves per cell");
-    __shared__ __align__(16) uint8_t tile[36 * FC_TP];
-    __shared__ __align__(16) uint8_t score[32 * FC_SP];
-    __shared__ uint16_t queue1[ORBX_CELL * ORBX_CELL];
-    // one wave compacts queue 1 in place (a batch is read before it is written, at positions <= the ones just read);
-    // several waves write a second queue
-    __shared__ uint16_t queue2_own[NW > 1 ? ORBX_CELL * ORBX_CELL : 1];
-    uint16_t *queue2 = NW > 1 ? queue2_own : queue1;
-    __shared__ uint32_t keepers[15 * 15];
-    __shared__ int s_nkeep, s_q2n, s_wtot[4];
+    constexpr int T = 64 * CPW;
+    static_assert(CPW >= 1 && CPW <= 16, "at most 16 waves per workgroup");
+    __shared__ __align__(16) uint8_t s_tile[CPW][36 * FC_TP];
+    __shared__ __align__(16) uint8_t s_score[CPW][32 * FC_SP];
+    // queue2 aliases queue1: the 8-pair test compacts in place (a batch is read before it is written, and it is
+    // written at positions <= the ones just read)
+    __shared__ uint16_t s_queue1[CPW][ORBX_CELL * ORBX_CELL];
+    __shared__ uint32_t s_keepers[CPW][15 * 15];
+    __shared__ int s_nkeep[CPW], s_level[CPW], s_base;
 
-    int frame, cell_id;
-    if (!xcd_remap(n_cells, n_frames, &frame, &cell_id)) return;
+    int frame, group;
+    if (!xcd_remap((n_cells + CPW - 1) / CPW, n_frames, &frame, &group)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cell_id = group * CPW + wid;
+    const bool live = cell_id < n_cells; // (a surplus wave of the last group only takes part in the reservation)
 #ifdef OCT_PROF
     const unsigned long long fc_t0 = wall_clock64();
 #endif
-    const FastCell cl = cells[cell_id];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const FastCell cl = cells[min(cell_id, n_cells - 1)];
+    uint8_t *tile = s_tile[wid], *score = s_score[wid];
+    uint16_t *queue1 = s_queue1[wid], *queue2 = queue1;
+    uint32_t *keepers = s_keepers[wid];
     const int level = cl.level;
     const OrbxLevel &lv = levels->lv[level];
+    if (lane == 0) { s_nkeep[wid] = 0; s_level[wid] = live ? level : -1; }
+    if (live) {
     const int x0 = ORBX_EDGE + cl.cx * ORBX_CELL, y0 = ORBX_EDGE + cl.cy * ORBX_CELL;
     const int cw = min(ORBX_CELL, lv.w - ORBX_EDGE - x0), ch = min(ORBX_CELL, lv.h - ORBX_EDGE - y0);
     const int th = ch + 6;
     const int pitch = src.pitch[level];
     const uint8_t *S = src.base[level] + (size_t)frame * src.frame_stride[level] + (size_t)(y0 - 3) * pitch + (x0 - 4);
 
-    for (int i = tid; i < 32 * FC_SP / 16; i += T) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) { s_nkeep = 0; s_q2n = 0; }
+    for (int i = lane; i < 32 * FC_SP / 16; i += 64) reinterpret_cast<uint4 *>(score)[i] = make_uint4(0, 0, 0, 0);
     {
-        // The 36 x 40-byte tile as 5 x th eight-byte items, all of a thread's requested before the first is stored (the
+        // The 36 x 40-byte tile as 5 x th eight-byte items, three per lane, all requested before the first is stored (the
         // index is clamped instead of branching: a surplus lane re-reads the last item).  Items of the last cell column may
         // reach past the end of the image row -- into the row's padding or the next row, never past the frame: the tile's
         // last row is at most h - 17 -- and those bytes are never looked at: the compass test masks the columns beyond the
         // cell and a ring of a cell pixel ends at column w - 17.
         const int n_items = 5 * th;
-        unsigned long long v[NLD];
-        int dst[NLD];
+        unsigned long long v[3];
+        int dst[3];
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int i = min(tid + T * it, n_items - 1);
+        for (int it = 0; it < 3; ++it) {
+            const int i = min(lane + 64 * it, n_items - 1);
             const int ty = i / 5, tx = (i - 5 * ty) * 8;
             dst[it] = ty * FC_TP + tx;
             v[it] = reinterpret_cast<const UnalignedU64b *>(S + (size_t)ty * pitch + tx)->v;
         }
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) *reinterpret_cast<unsigned long long *>(&tile[dst[it]]) = v[it];
+        for (int it = 0; it < 3; ++it) *reinterpret_cast<unsigned long long *>(&tile[dst[it]]) = v[it];
     }
-    __syncthreads();
+    FS_WAVE_ORDER();
     int thr = levels->ini_th;
     for (int pass = 0; pass < 2; ++pass) {
         // ---- compass test: item = (row, run of 4 tile columns 4g..4g+3), g = 1..8.
@@ -531,13 +537,13 @@ __global__ __launch_bounds__(64 * NW) void k_fast_cells_wave(FastSrc src, const 
         //   V - max(min(S,N), min(E,W)) > T   (both pairs hold a darker point)   or
         //   min(max(S,N), max(E,W)) - V > T   (both pairs hold a brighter point).
         // Two pixels per instruction in packed i16; m - (T+1) has its sign bit set iff the pixel fails, and the sign
-        // bytes of the item's four pixels are gathered with one v_perm.  acc collects them: bit 8j + (8 - NIT) + it set =
+        // bytes of the item's four pixels are gathered with one v_perm.  acc collects them: bit 8j + 4 + it set =
         // pixel j of iteration `it` is NOT a candidate.
         const s16x2 T1 = {(short)(thr + 1), (short)(thr + 1)};
         uint32_t acc = 0xFFFFFFFFu;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = it * T + tid;
+        for (int it = 0; it < 4; ++it) {
+            const int i = it * 64 + lane;
             const int r = i >> 3, g = (i & 7) + 1;
             uint32_t w = 0x80808080u; // rows below the cell: no candidates
             if (r < ch) {
@@ -566,10 +572,9 @@ __global__ __launch_bounds__(64 * NW) void k_fast_cells_wave(FastSrc src, const 
         }
         uint32_t mask;
         {
-            constexpr uint32_t ITBITS = ((0xFFu << (8 - NIT)) & 0xFFu) * 0x01010101u; // the NIT result bits of every byte
-            const int g = (tid & 7) + 1;
+            const int g = (lane & 7) + 1;
             const int nvalid = min(max(cw + 4 - 4 * g, 0), 4); // region columns end at tc = 4 + cw
-            const uint32_t vmask = nvalid >= 4 ? ITBITS : (ITBITS & ((1u << (8 * nvalid)) - 1u));
+            const uint32_t vmask = nvalid >= 4 ? 0xF0F0F0F0u : (0xF0F0F0F0u & ((1u << (8 * nvalid)) - 1u));
             mask = ~acc & vmask;
         }
         int q1n;
@@ -581,32 +586,20 @@ __global__ __launch_bounds__(64 * NW) void k_fast_cells_wave(FastSrc src, const 
                 const int y = __shfl_up(incl, o);
                 if (lane >= o) incl += y;
             }
+            q1n = __shfl(incl, 63);
             int slot = incl - cnt;
-            if (NW > 1) { // the waves before this one
-                if (lane == 63) s_wtot[wid] = incl;
-                __syncthreads();
-                q1n = 0;
-#pragma unroll
-                for (int k = 0; k < NW; ++k) {
-                    const int t = s_wtot[k];
-                    if (k < wid) slot += t;
-                    q1n += t;
-                }
-            } else {
-                q1n = __shfl(incl, 63);
-            }
             uint32_t m = mask;
             while (m) {
                 const int b = __ffs(m) - 1;
                 m &= m - 1;
-                const int i = ((b & 7) - (8 - NIT)) * T + tid; // bit 8j + (8 - NIT) + it
+                const int i = ((b & 7) - 4) * 64 + lane; // bit 8j + 4 + it
                 queue1[slot++] = (uint16_t)(((i >> 3) << 8) | (4 * ((i & 7) + 1) + (b >> 3))); // (row, tc)
             }
         }
-        __syncthreads();
+        FS_WAVE_ORDER();
         // ---- exact 8-pair test -> queue 2
         int q2n = 0;
-        for (int i0 = 64 * wid; i0 < q1n; i0 += T) {
+        for (int i0 = 0; i0 < q1n; i0 += 64) {
             const int i = i0 + lane;
             bool ok = false;
             int e = 0;
@@ -618,63 +611,83 @@ __global__ __launch_bounds__(64 * NW) void k_fast_cells_wave(FastSrc src, const 
             }
             const u64 mk = __ballot(ok);
             const int pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-            int at = q2n;
-            if (NW > 1) {
-                if (lane == 0 && mk) at = atomicAdd(&s_q2n, (int)__popcll(mk));
-                at = __builtin_amdgcn_readfirstlane(at);
-            }
-            if (ok) queue2[at + pre] = (uint16_t)e;
+            FS_WAVE_ORDER();
+            if (ok) queue2[q2n + pre] = (uint16_t)e;
             q2n += (int)__popcll(mk);
         }
-        __syncthreads();
-        if (NW > 1) q2n = s_q2n;
+        FS_WAVE_ORDER();
         // ---- exact strength
-        for (int i = tid; i < q2n; i += T) {
+        for (int i = lane; i < q2n; i += 64) {
             const int e = queue2[i], r = e >> 8, tc = e & 255;
             int d[16];
             fastc_load_ring(&tile[(r + 3) * FC_TP + tc], d);
             const int sc = fast_score(d);
             if (sc >= thr) score[(r + 1) * FC_SP + tc - 3] = (uint8_t)sc;
         }
-        __syncthreads();
+        FS_WAVE_ORDER();
         // ---- strict 3x3 NMS (everything outside the cell is 0 in the score map)
-        for (int i = tid; i < q2n; i += T) {
+        for (int i = lane; i < q2n; i += 64) {
             const int e = queue2[i], r = e >> 8, tc = e & 255;
             const uint8_t *sp = &score[(r + 1) * FC_SP + tc - 3];
             const int sc = sp[0];
             if (sc > 0 && sc > sp[-1] && sc > sp[1] && sc > sp[-FC_SP - 1] && sc > sp[-FC_SP] && sc > sp[-FC_SP + 1] &&
                 sc > sp[FC_SP - 1] && sc > sp[FC_SP] && sc > sp[FC_SP + 1])
-                keepers[atomicAdd(&s_nkeep, 1)] = (uint32_t)r | ((uint32_t)(tc - 4) << 8) | ((uint32_t)sc << 16);
+                keepers[atomicAdd(&s_nkeep[wid], 1)] = (uint32_t)r | ((uint32_t)(tc - 4) << 8) | ((uint32_t)sc << 16);
         }
-        __syncthreads();
-        if (s_nkeep > 0 || pass == 1) break;
+        FS_WAVE_ORDER();
+        if (__builtin_amdgcn_readfirstlane(s_nkeep[wid]) > 0 || pass == 1) break;
         thr = levels->min_th; // reference :604-607: nothing at the ini threshold -> redo the cell at the min threshold
-        if (NW > 1) { // (every thread has read the old count: it passed the barrier above after the read of q2n)
-            if (tid == 0) s_q2n = 0;
-        }
     }
-    const int nk = s_nkeep;
+    }
+    FS_WAVE_ORDER();
+    const int nk = __builtin_amdgcn_readfirstlane(s_nkeep[wid]);
 #ifdef OCT_PROF
-    if (frame == 0 && tid == 0) {
-        // global cell number: the launch's cells start at `cells`, the handle's list at level 0 -- (level, cy, cx) is the key
-        const int slot = (cl.level * 4096 + cl.cy * 64 + cl.cx) % FC_PROF_CELLS;
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        g_fc_times[3 * slot] = fc_t0;
-        g_fc_times[3 * slot + 1] = wall_clock64();
-        g_fc_times[3 * slot + 2] = ((unsigned long long)cl.level << 32) | hw;
-    }
+    unsigned long long fc_t1 = wall_clock64();
 #endif
-    if (nk == 0) return;
-    __shared__ int s_base;
-    if (tid == 0) s_base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], nk);
-    __syncthreads();
-    u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + s_base;
-    for (int i = tid; i < nk; i += T) {
+    // ---- one reservation for the cells of the workgroup (all of one level; a group that straddles two levels -- at most
+    // one per level and frame -- lets every wave reserve for itself)
+    int base;
+    if (CPW > 1) {
+        __syncthreads();
+        int before = 0, total = 0;
+        bool same = true;
+        const int lvl0 = s_level[0];
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            const int n = s_nkeep[k];
+            if (k < wid) before += n;
+            total += n;
+            same = same && (s_level[k] == lvl0 || s_level[k] < 0);
+        }
+        if (same) {
+            if (total == 0) return;
+            if (tid == 0) s_base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], total);
+            __syncthreads();
+            base = s_base + before;
+        } else {
+            base = 0;
+            if (lane == 0 && nk > 0) base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], nk);
+            base = __builtin_amdgcn_readfirstlane(base);
+        }
+    } else {
+        base = 0;
+        if (lane == 0 && nk > 0) base = atomicAdd(&cand_count[frame * ORBX_MAX_LEVELS + level], nk);
+        base = __builtin_amdgcn_readfirstlane(base);
+    }
+    u64 *out = cand + (size_t)frame * cand_fs + lv.cand_off + base;
+    for (int i = lane; i < nk; i += 64) {
         const uint32_t e = keepers[i];
         const uint32_t x = cl.cx * ORBX_CELL + ((e >> 8) & 255), y = cl.cy * ORBX_CELL + (e & 255);
         out[i] = (u64)(x | (y << 16)) | ((u64)(e >> 16) << 32);
     }
+#ifdef OCT_PROF
+    if (frame == 0 && lane == 0 && live) {
+        const int slot = (cl.level * 4096 + cl.cy * 64 + cl.cx) % FC_PROF_CELLS; // (level, cy, cx) is the key
+        g_fc_times[3 * slot] = fc_t0;
+        g_fc_times[3 * slot + 1] = wall_clock64();
+        g_fc_times[3 * slot + 2] = fc_t1; // the cell's work done, before the reservation
+    }
+#endif
 }
 
 
@@ -717,9 +730,7 @@ static_assert(4 * ((FS_K * ORBX_CELL + 3) / 4) + 3 < 128, "a pixel entry keeps t
 struct __attribute__((aligned(8))) FastStrip { // 8-byte aligned: one scalar load per strip
     uint16_t level, cy, cx0, ncells;
 };
-// The queues are written and read by the one wave of the workgroup, and a wave's LDS instructions execute in issue
-// order: what is needed between a producer and a consumer stage is only that the compiler keeps that order.
-#define FS_WAVE_ORDER() asm volatile("" ::: "memory")
+// (FS_WAVE_ORDER, above: the queues are written and read by the one wave of the workgroup)
 // the same barrier, leaving a named comment in the ISA: tools/isa_mix.py counts the instructions between "name_begin" and "name_end"
 #define FS_MARK(name) asm volatile("; FSM " name ::: "memory")
 
@@ -1176,7 +1187,7 @@ int orbx_build_fast_cells(const OrbxLevels &levels, uint16_t *out /* 4 per cell,
 
 void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                       const OrbxLevels &levels, const OrbxBuffers &b, const void *d_cells, int n_cells, int n_frames,
-                      int waves_per_cell)
+                      int cells_per_group)
 {
     if (n_cells <= 0) return;
     FastSrc src;
@@ -1185,14 +1196,15 @@ void orbx_launch_fast(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pit
         src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
         src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
     }
-    const dim3 grid(orbx_xcd_grid(n_cells, n_frames));
     const FastCell *cells = reinterpret_cast<const FastCell *>(d_cells);
-    if (waves_per_cell >= 4)
-        hipLaunchKernelGGL(k_fast_cells_wave<4>, grid, dim3(256), 0, s, src, d_levels, cells, b.cand, b.cand_frame_stride, b.cand_count, n_cells, n_frames);
-    else if (waves_per_cell >= 2)
-        hipLaunchKernelGGL(k_fast_cells_wave<2>, grid, dim3(128), 0, s, src, d_levels, cells, b.cand, b.cand_frame_stride, b.cand_count, n_cells, n_frames);
-    else
-        hipLaunchKernelGGL(k_fast_cells_wave<1>, grid, dim3(64), 0, s, src, d_levels, cells, b.cand, b.cand_frame_stride, b.cand_count, n_cells, n_frames);
+#define ORBX_FAST_CELLS_LAUNCH(CPW)                                                                                          \
+    hipLaunchKernelGGL(k_fast_cells_wave<CPW>, dim3(orbx_xcd_grid((n_cells + CPW - 1) / CPW, n_frames)), dim3(64 * CPW), 0, s, \
+                       src, d_levels, cells, b.cand, b.cand_frame_stride, b.cand_count, n_cells, n_frames)
+    if (cells_per_group >= 16) ORBX_FAST_CELLS_LAUNCH(16);
+    else if (cells_per_group >= 8) ORBX_FAST_CELLS_LAUNCH(8);
+    else if (cells_per_group >= 4) ORBX_FAST_CELLS_LAUNCH(4);
+    else ORBX_FAST_CELLS_LAUNCH(1);
+#undef ORBX_FAST_CELLS_LAUNCH
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -28,7 +28,7 @@ VARIANTS = {
     "streams": (7, {}),
     "zero_copy": (8, {}),
     "desc": (9, {"auto": 0, "separate": 1, "fused": 2}),
-    "fast_cell_waves": (10, {}),
+    "fast_cell_group": (10, {}),
 }
 
 

@@ -48,10 +48,15 @@ def _check_frame(ex, orc, img, kps, desc, frame=0, stages=True):
 # 6000 features: per-level quotas too large for the LDS-resident quadtree -> global-scratch kernel
 @pytest.mark.parametrize("w,h,nf", [(1242, 375, 2000), (752, 480, 1000), (640, 200, 500), (1242, 375, 6000),
                                     (1242, 375, 4000)])
-@pytest.mark.parametrize("variant", ["strips", "cells"])
+@pytest.mark.parametrize("variant", ["strips", "cells", "cells/1", "cells/4", "cells/16"])
 def test_single_frame_all_stages(oracle_mod, w, h, nf, variant):
-    # both FAST kernels: per strip (batches) and per cell (few frames)
-    ex, orc = _mk(oracle_mod, nf, w, h, variants={"fast": variant})
+    # both FAST kernels: per strip (batches) and per cell (few frames; cells/N: N cells per workgroup, which reserve their
+    # place in the candidate list together -- 8 by default, 1 = every cell for itself)
+    name, _, group = variant.partition("/")
+    variants = {"fast": name}
+    if group:
+        variants["fast_cell_group"] = int(group)
+    ex, orc = _mk(oracle_mod, nf, w, h, variants=variants)
     img = synth.make_frames(1, w, h, seed=synth.DEFAULT_SEED + w)[0]
     kps, desc = ex(img)
     assert len(kps) > nf // 2
@@ -235,13 +240,14 @@ def test_batch_path_with_other_arguments(oracle_mod, nf, sf, levels, ini, mn, w,
 
 @pytest.mark.parametrize("ini,mn,kind", [(5, 2, "noise"), (2, 1, "noise"), (2, 1, "scene"), (3, 3, "noise"), (40, 1, "scene"),
                                          (254, 200, "noise")])
-@pytest.mark.parametrize("variant", ["strips", "cells"])  # one wave per strip of cells (batches) / one wave per cell (few frames)
+@pytest.mark.parametrize("variant", ["strips", "cells", "cells/16"])  # one wave per strip of cells (batches) / one wave per cell (few frames)
 def test_fast_dense_corners_and_tiny_thresholds(oracle_mod, ini, mn, kind, variant):
     """The FAST kernel's rare paths: i.i.d. noise at low thresholds makes nearly every pixel a corner (more corners per
     strip than its LDS list holds -> the NMS sweeps the score map), thresholds 0..2 make the 6-bit arc test pass pixels
     in both polarities, thresholds near 255 pass nothing.  Candidates, key points and descriptors stay the oracle's."""
     w, h, nf = 500, 300, 1500
-    ex, orc = _mk(oracle_mod, nf, w, h, ini=ini, mn=mn, variants={"fast": variant})
+    name, _, group = variant.partition("/")
+    ex, orc = _mk(oracle_mod, nf, w, h, ini=ini, mn=mn, variants=dict({"fast": name}, **({"fast_cell_group": int(group)} if group else {})))
     if kind == "noise":
         img = np.random.RandomState(ini * 31 + mn).randint(0, 256, (h, w)).astype(np.uint8)
     else:

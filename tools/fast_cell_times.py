@@ -43,20 +43,19 @@ used = out[out[:, 1] > 0]
 t0 = int(used[:, 0].min())
 start = (used[:, 0].astype(np.int64) - t0) / 100.0
 end = (used[:, 1].astype(np.int64) - t0) / 100.0
-level = (used[:, 2] >> np.uint64(32)).astype(int)
-hw = (used[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
-cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
+work = (used[:, 2].astype(np.int64) - t0) / 100.0   # the cell's own work done, before the group's reservation in the candidate list
 print("%d cells; times in us from the first start" % len(used))
-for grp, sel in (("level 0", level == 0), ("levels 1..", level > 0)):
+# the two launches of a split call (level 0 on the side stream, the rest on the main one) are told apart by their start times
+gap = np.sort(start)
+cut = gap[np.argmax(np.diff(gap)) + 1] if len(gap) > 1 and np.diff(gap).max() > 3.0 else None
+groups = (("first launch", start < cut), ("second launch", start >= cut)) if cut is not None else (("the launch", start >= 0),)
+for grp, sel in groups:
     if not sel.any():
         continue
-    s, e = start[sel], end[sel]
-    d = e - s
-    print("%-10s %5d cells: first start %6.1f  last start %6.1f  last end %6.1f | duration median %5.1f  p90 %5.1f  max %5.1f"
-          % (grp, sel.sum(), s.min(), s.max(), e.max(), np.median(d), np.percentile(d, 90), d.max()))
-    order = np.argsort(s)
-    q = [s[order[int(len(order) * f)]] for f in (0.25, 0.5, 0.75, 0.99)]
-    print("           start time of the 25/50/75/99 %% cell: %s" % " ".join("%6.1f" % x for x in q))
+    s, e, w = start[sel], end[sel], work[sel]
+    d = w - s
+    print("%-13s %5d cells: first start %6.1f  last start %6.1f  last work done %6.1f  last end (reserved + written) %6.1f | work per cell median %5.1f  p90 %5.1f  max %5.1f"
+          % (grp, sel.sum(), s.min(), s.max(), w.max(), e.max(), np.median(d), np.percentile(d, 90), d.max()))
 for lvl in (0, 1):  # the quadtree kernels' own stamps (same counter): when the next kernel of each chain really started
     n = int(oct[lvl, 63])
     print("quadtree level %d: start %6.1f  end %6.1f" % (lvl, (int(oct[lvl, 0]) - t0) / 100.0, (int(oct[lvl, 2 * (n - 1)]) - t0) / 100.0))
