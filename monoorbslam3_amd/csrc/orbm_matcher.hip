@@ -726,30 +726,42 @@ __global__ __launch_bounds__(256) void k_window_lists(const orbx_kp *__restrict_
 {
     // pool_total == NULL: list q lives at out + q * cap.  Otherwise the lists are packed back to back into out[0 .. cap):
     // a first sweep counts, the wave reserves its block with one atomic (offs[q]), a second sweep writes.
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (q >= nq) return;
-    if (!q_ok[q]) { if (lane == 0) { counts[q] = -1; if (offs) offs[q] = 0; } return; }
-    const float x = q_xy[2 * q], y = q_xy[2 * q + 1], r = q_r[q];
-    const int min_level = q_min[q], max_level = q_max[q];
+    // The pool reservation is a returning atomic on ONE address, and those are served one at a time (about 8 ns each on this
+    // part: 2000 queries reserving wave by wave stand in line for 16 us, as long as the kernel's own work).  The four waves of
+    // a workgroup therefore reserve together: every wave -- also one without a query or with a query that is switched off --
+    // reaches the two barriers of the pooled form.
+    __shared__ int s_need[4], s_off;
+    const int wid = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wid, lane = threadIdx.x & 63;
+    const bool live = q < nq && q_ok[min(q, nq - 1)];
+    if (!pool_total && !live) { if (q < nq && lane == 0) counts[q] = -1; return; }
+    const int qc = min(q, nq - 1);
+    const float x = q_xy[2 * qc], y = q_xy[2 * qc + 1], r = q_r[qc];
+    const int min_level = q_min[qc], max_level = q_max[qc];
     const int minCX = max(0, orb_floor_f(x - r) / ORBM_GRID), maxCX = min(cols - 1, orb_floor_f(x + r) / ORBM_GRID);
     const int minCY = max(0, orb_floor_f(y - r) / ORBM_GRID), maxCY = min(rows - 1, orb_floor_f(y + r) / ORBM_GRID);
     int pos = 0;
     size_t base = (size_t)q * cap;
     int limit = cap;
-    if (minCX <= maxCX && minCY <= maxCY) {
-        const Desc256 dq = load_desc(q_desc + (size_t)q * 32);
+    const bool window = live && minCX <= maxCX && minCY <= maxCY;
+    {
+        const Desc256 dq = load_desc(q_desc + (size_t)qc * 32);
         const bool check = min_level > 0 || max_level >= 0; // beCheckLevel (Frame.cpp:107)
         for (int sweep = pool_total ? 0 : 1; sweep < 2; ++sweep) {
         if (sweep == 1 && pool_total) {
-            int off = 0;
-            if (lane == 0) off = atomicAdd(pool_total, pos);
-            off = __builtin_amdgcn_readfirstlane(off);
-            if (lane == 0) offs[q] = off;
+            if (lane == 0) s_need[wid] = pos;
+            __syncthreads();
+            const int n0 = s_need[0], n1 = s_need[1], n2 = s_need[2], n3 = s_need[3];
+            if (threadIdx.x == 0) s_off = (n0 + n1 + n2 + n3) ? atomicAdd(pool_total, n0 + n1 + n2 + n3) : 0;
+            __syncthreads();
+            const int off = s_off + (wid > 0 ? n0 : 0) + (wid > 1 ? n1 : 0) + (wid > 2 ? n2 : 0);
+            if (lane == 0 && q < nq) offs[q] = window ? off : 0;
             base = (size_t)off;
             limit = off + pos <= cap ? pos : 0; // a pool that is too small: nothing is written, the host sees total > cap
             if (pos == 0) break;
             pos = 0;
         }
+        if (window)
         for (int cx = minCX; cx <= maxCX; ++cx) {
             const int b = cell_start[cx * rows + minCY], e = cell_start[cx * rows + maxCY + 1];
             for (int t0 = b; t0 < e; t0 += 64) {
@@ -779,8 +791,8 @@ __global__ __launch_bounds__(256) void k_window_lists(const orbx_kp *__restrict_
             }
         }
         }
-    } else if (pool_total && lane == 0) offs[q] = 0;
-    if (lane == 0) counts[q] = pos;
+    }
+    if (lane == 0 && q < nq) counts[q] = live ? pos : -1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -989,54 +1001,56 @@ __global__ __launch_bounds__(BQ_T) void k_bow_queries(BowFv f1, BowFv f2, const 
                                                       int32_t *__restrict__ q_idx, int32_t *__restrict__ c_begin, int32_t *__restrict__ c_len,
                                                       int32_t *__restrict__ q_node, int32_t *__restrict__ n_queries)
 {
+    // The queries in the reference's order -- node by node, a node's features in stored order -- are the usable entries of
+    // side 1's CSR in ENTRY order, so the work is split over the entries, not over the nodes (one thread per node walked a
+    // 2000-feature node alone: 0.6 ms for a frame whose features share one node): a thread finds the node of its entry by
+    // bisection of the offsets, a block-wide prefix sum of the usable flags numbers the queries.
     __shared__ int s_part[BQ_T];
+    __shared__ int s_base;
     const int tid = threadIdx.x;
     const int nn1 = min(*f1.n_nodes, max_nodes), nn2 = *f2.n_nodes;
-    // usable features per node of side 1 that side 2 shares (mask_polarity 1: mask must be set; 0: must be clear)
-    const int per = (nn1 + BQ_T - 1) / BQ_T;
-    int mine = 0;
-    for (int k = 0; k < per; ++k) {
-        const int p1 = tid * per + k;
-        if (p1 >= nn1) break;
+    for (int p1 = tid; p1 < nn1; p1 += BQ_T) { // node of side 2 with the same id (:180-183), per node of side 1
         const uint32_t id = f1.nodes[p1];
-        int lo = 0, hi = nn2; // lower_bound of id among side 2's node ids (:180-183)
+        int lo = 0, hi = nn2;
         while (lo < hi) { const int m = (lo + hi) >> 1; if (f2.nodes[m] < id) lo = m + 1; else hi = m; }
-        const int p2 = lo < nn2 && f2.nodes[lo] == id ? lo : -1;
-        int cnt = 0;
-        if (p2 >= 0)
-            for (int a = f1.off[p1]; a < f1.off[p1 + 1]; ++a) cnt += (mask1[f1.idx[a]] != 0) == (mask_polarity != 0);
-        node_p2[p1] = p2;
-        node_qbegin[p1] = cnt; // the count for now
-        mine += cnt;
+        node_p2[p1] = lo < nn2 && f2.nodes[lo] == id ? lo : -1;
     }
-    s_part[tid] = mine;
-    __syncthreads();
-    for (int off = 1; off < BQ_T; off <<= 1) {
-        const int v = tid >= off ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    int base = s_part[tid] - mine;
-    if (tid == BQ_T - 1) { *n_queries = min(s_part[tid], n1); }
-    for (int k = 0; k < per; ++k) {
-        const int p1 = tid * per + k;
-        if (p1 >= nn1) break;
-        const int cnt = node_qbegin[p1], p2 = node_p2[p1];
-        node_qbegin[p1] = base;
-        if (p2 >= 0) {
-            const int cb = f2.off[p2], cl = f2.off[p2 + 1] - cb;
-            int q = base;
-            for (int a = f1.off[p1]; a < f1.off[p1 + 1]; ++a) {
-                const int i1 = (int)f1.idx[a];
-                if ((mask1[i1] != 0) != (mask_polarity != 0)) continue;
-                if (q < n1) { q_idx[q] = i1; c_begin[q] = cb; c_len[q] = cl; q_node[q] = p1; }
-                ++q;
-            }
+    if (tid == 0) s_base = 0;
+    __syncthreads(); // (node_p2 is read below by other threads of this one workgroup: the barrier orders the global writes for them)
+    const int n_entries = nn1 > 0 ? f1.off[nn1] : 0;
+    for (int a0 = 0; a0 < n_entries; a0 += BQ_T) {
+        const int a = a0 + tid;
+        int p1 = -1, p2 = -1, i1 = 0;
+        bool use = false;
+        if (a < n_entries) {
+            int lo = 0, hi = nn1; // the node whose entry range holds a: the last p with off[p] <= a
+            while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (f1.off[m] <= a) lo = m; else hi = m; }
+            p1 = lo;
+            p2 = node_p2[p1];
+            i1 = (int)f1.idx[a];
+            use = p2 >= 0 && ((mask1[i1] != 0) == (mask_polarity != 0)); // usable features of side 1 that side 2 shares the node of
         }
-        base += cnt;
+        s_part[tid] = use;
+        __syncthreads();
+        for (int off = 1; off < BQ_T; off <<= 1) {
+            const int v = tid >= off ? s_part[tid - off] : 0;
+            __syncthreads();
+            s_part[tid] += v;
+            __syncthreads();
+        }
+        const int q = s_base + s_part[tid] - (int)use;
+        if (a < n_entries) {
+            if (a == f1.off[p1]) node_qbegin[p1] = q; // first query of the node (or where it would be)
+            if (use && q < n1) { q_idx[q] = i1; c_begin[q] = f2.off[p2]; c_len[q] = f2.off[p2 + 1] - f2.off[p2]; q_node[q] = p1; }
+        }
+        __syncthreads();
+        if (tid == BQ_T - 1) s_base += s_part[tid];
+        __syncthreads();
     }
-    if (tid == 0) node_qbegin[nn1] = 0x7fffffff; // (never read as a begin: the resolve kernel ends a node at the next begin or n_queries)
+    if (tid == 0) {
+        *n_queries = min(s_base, n1);
+        node_qbegin[nn1] = 0x7fffffff; // (never read as a begin: the resolve kernel ends a node at the next begin or n_queries)
+    }
 }
 
 // the K smallest keys of every query's list with the query count on the device (k_topk_lists reads it from the host)

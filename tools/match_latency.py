@@ -59,16 +59,22 @@ for bits, label in ((0, "dense: one node, 2000x2000 pairs"), (4, "16 nodes (~125
     d = dict(desc1=up(a), kps1=kp(k1r), kf_mp_ok=up(ok), fv1=dev_fv(fv1), desc2=up(b), kps2=kp(k2r), frame_mp=up(mp0), fv2=dev_fv(fv2),
              result=torch.zeros(8, dtype=torch.int32, device=dev), has_mp1=up(1 - ok), has_mp2=up(np.zeros(n, np.uint8)),
              matches12=torch.zeros(n, dtype=torch.int32, device=dev))
-    st = torch.cuda.current_stream().cuda_stream
+    # a stream of its own: torch's default stream has handle 0, which the C ABI reads as "the handle's own stream" -- events
+    # recorded on the default stream would then bracket nothing
+    ts = torch.cuda.Stream()
+    st = ts.cuda_stream
+    assert st != 0
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     tb, tt = [], []
     for _ in range(12):
         d["frame_mp"].fill_(-1)
-        e0.record()
-        m.SearchByBowDevice(d, n, n, stream=st)
-        e1.record()
-        m.SearchForTriangulationDevice(d, n, n, stream=st)
-        e2.record()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(ts):
+            e0.record()
+            m.SearchByBowDevice(d, n, n, stream=st)
+            e1.record()
+            m.SearchForTriangulationDevice(d, n, n, stream=st)
+            e2.record()
         torch.cuda.synchronize()
         tb.append(e0.elapsed_time(e1)); tt.append(e1.elapsed_time(e2))
     r = d["result"].cpu().numpy()
