@@ -1719,26 +1719,38 @@ int orbx_build_blur_tiles(const OrbxLevels &levels, uint16_t *out /* 4 per tile,
 #ifndef ORBX_OCT_HUGE_PIXELS
 #define ORBX_OCT_HUGE_PIXELS 1200000 // level size from which a call with a few frames gives the level 1024 threads (1920 x 1080: levels 0 and 1)
 #endif
+// (every build names its parameters: the header's defaults would otherwise leak from one inclusion into the next)
 namespace oct_wide {
 #define OCT_NT ORBX_OCT_THREADS
+#define OCT_REG 8
+#define OCT_MIN_WAVES 1
 #define OCT_PRIO 1 // the call waits for these few workgroups: their waves go first on a CU they share (orbx_octree.h)
 #include "orbx_octree.h"
+#undef OCT_PRIO
+#undef OCT_MIN_WAVES
+#undef OCT_REG
 #undef OCT_NT
 } // namespace oct_wide
 namespace oct_batch {
 #define OCT_NT ORBX_OCT_THREADS_BATCH
+#define OCT_REG 8
+#define OCT_MIN_WAVES 4 // four 256-thread workgroups per CU: the register allocator stays at 128 VGPRs (133 without the bound: three workgroups, 0.23 -> 0.27 ms)
 #include "orbx_octree.h"
+#undef OCT_MIN_WAVES
+#undef OCT_REG
 #undef OCT_NT
 } // namespace oct_batch
 namespace oct_huge { // a call with a few frames and a level of a megapixel or more: 1024 threads share its 10 000+ candidates
 #define OCT_NT 1024
 #define OCT_PYR 1 // passes from a count pyramid instead of candidate sweeps (orbx_octree.h)
-#undef OCT_REG
+#define OCT_PRIO 1
 #define OCT_REG 1 // 16 waves per workgroup leave 128 VGPRs a thread: candidates are streamed (they are read twice in all), not held
+#define OCT_MIN_WAVES 1
 #include "orbx_octree.h"
+#undef OCT_MIN_WAVES
 #undef OCT_REG
-#undef OCT_PYR
 #undef OCT_PRIO
+#undef OCT_PYR
 #undef OCT_NT
 } // namespace oct_huge
 
