@@ -1,0 +1,59 @@
+"""Register / scratch budgets of the kernels whose occupancy the measured numbers depend on, read from the gfx950 ISA that
+hipcc emits for the shipped sources (no GPU needed).  A few more VGPRs are invisible in a diff and cost a whole workgroup per CU:
+the batch quadtree went from four to three workgroups per CU (0.23 -> 0.27 ms per 512 frames) on a 125 -> 133 VGPR step."""
+import hashlib
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "monoorbslam3_amd", "csrc")
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "--offload-arch=gfx950", "-mllvm",
+         "-amdgpu-mfma-vgpr-form=1", "--cuda-device-only", "-S"]
+
+# kernel (substring of the mangled name) -> (max VGPRs, max scratch bytes, why)
+BUDGET = {
+    "k_fast_strip": (96, 0, "5 waves per SIMD (512 / 5 = 102); LDS allows 18 workgroups per CU"),
+    "k_blur_descILi256": (102, 0, "amdgpu_waves_per_eu 5"),
+    "k_blur_descILi257": (102, 0, "amdgpu_waves_per_eu 5"),
+    "oct_batch12k_octree_lds": (128, 16, "four 256-thread workgroups per CU"),
+    "oct_huge12k_octree_lds": (128, 0, "16 waves per workgroup: 128 VGPRs is all a thread can have; spills stalled the level for 30 us"),
+    "k_fast_cells_waveILi8E": (128, 0, "8 waves per workgroup, several workgroups per CU"),
+    "k_orientILb0E": (64, 0, "8 waves per SIMD"),
+    "k_blur_mfmaILi256": (96, 0, "5 waves per SIMD"),
+}
+
+
+def _isa():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    out_dir = os.path.join(ROOT, "build", "isa")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "orbx_kernels_%s.s" % h.hexdigest()[:16])
+    if not os.path.exists(out):
+        subprocess.run([hipcc] + FLAGS + ["-o", out, os.path.join(CSRC, "orbx_kernels.hip")], check=True, cwd=CSRC,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def test_occupancy_critical_kernels_stay_within_their_register_budgets():
+    s = _isa()
+    found = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", s, re.S):
+        name, body = m.group(1), m.group(2)
+        vg = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        sc = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        for key in BUDGET:
+            if key in name:
+                found[key] = (vg, sc)
+    assert set(found) == set(BUDGET), "kernels renamed? missing: %s" % sorted(set(BUDGET) - set(found))
+    over = {k: (found[k], BUDGET[k]) for k in BUDGET if found[k][0] > BUDGET[k][0] or found[k][1] > BUDGET[k][1]}
+    assert not over, "over budget (got (vgpr, scratch), budget (vgpr, scratch, why)): %s" % over
