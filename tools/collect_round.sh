@@ -23,6 +23,10 @@ python3 tools/match_latency.py 2>&1 | grep -v amdgpu.ids > $O/match_latency.txt;
 python3 tools/ba_latency.py 2>&1 | grep -v amdgpu.ids > $O/ba_latency.txt; python3 tools/bow_timing.py 2>&1 | grep -v amdgpu.ids > $O/bow_timing.txt; echo "ba / bow done"
 python3 tools/octree_phases.py 1 2>&1 | grep -v amdgpu.ids > $O/octree_phases.txt || true
 python3 tools/octree_phases.py 1 1920 1080 2>&1 | grep -v amdgpu.ids > $O/octree_phases_1080.txt || true
+{ python3 tools/fast_cell_times.py 1920 1080; python3 tools/fast_cell_times.py 1242 375; python3 tools/fast_cell_times.py 1920 1080 fast_cell_group=1; } 2>&1 | grep -v amdgpu.ids > $O/fast_cell_times.txt || true
+bash tools/frame_timeline_host.sh 1920 1080 2000 > $O/frame_timeline_1080.txt 2>&1 || true
+bash tools/frame_timeline_host.sh 1242 375 2000 > $O/frame_timeline_kitti.txt 2>&1 || true
+bash tools/kernel_stats_match.sh > $O/kernel_stats_match.txt 2>&1 || true; echo "single-frame probes done"
 bash tools/ta_breakdown.sh > $O/tcp.log 2>&1; cp gpurun_out/ta_breakdown.txt $O/tcp_counters.txt; echo "tcp done"
 for m in valu_ops3 fp4_hamming; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/microbench/$m.hip -o /tmp/$m && /tmp/$m > $O/$m.txt 2>&1; done; echo "microbench done"
 cp gpurun_out/prof/*_counter_collection.csv gpurun_out/prof/kernel_stats.csv gpurun_out/prof/bench_under_rocprof.json $O/

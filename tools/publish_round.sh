@@ -17,6 +17,10 @@ cp $R/bow_timing.txt profiles/${T}_bow_timing.txt
 cp $R/octree_phases.txt profiles/${T}_octree_phases.txt
 cp $R/octree_phases_1080.txt profiles/${T}_octree_phases_1080.txt
 cp $R/tcp_counters.txt profiles/${T}_tcp_counters.txt
+cp $R/fast_cell_times.txt profiles/${T}_fast_cell_times.txt
+cp $R/frame_timeline_1080.txt profiles/${T}_frame_timeline_1080.txt
+cp $R/frame_timeline_kitti.txt profiles/${T}_frame_timeline_kitti.txt
+cp $R/kernel_stats_match.txt profiles/${T}_kernel_stats_match.txt
 cp $R/step_timeline.txt profiles/${T}_step_timeline.txt
 cp $R/fast_mix.json profiles/fast_mix.json
 cp $R/valu_ops3.txt profiles/${T}_valu_ops3.txt
