@@ -110,6 +110,13 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_imgs, int n_frames, in
 int orbx_stream_wait_fast(orbx_t *h, void *stream);
 /* Block until everything enqueued on the handle's stream has finished. */
 int orbx_synchronize(orbx_t *h);
+/* Optional, for a caller whose frames live in a long-lived buffer (a capture ring, a cv::Mat that is reused): page-lock that
+ * buffer once (hipHostRegister) so that orbx_extract's copy of the frame is a plain DMA that does not block the calling thread
+ * -- the launches that follow are then issued while the frame is still on its way (1920x1080: the 52 us in which a pageable
+ * frame blocks the host).  The range must stay allocated until orbx_host_unregister; registering is slow (milliseconds): once per
+ * buffer, never per frame.  No reference counterpart. */
+int orbx_host_register(void *ptr, size_t bytes);
+int orbx_host_unregister(void *ptr);
 
 /* ---- stage taps: copy intermediate results of the LAST extract call to host
  * memory (parity tests compare every stage with the oracle). ---- */

@@ -54,6 +54,8 @@ def lib():
         "orbx_extract_batch": (i32, [vp, vp, i32, i32, i32, i32, sz, vp, vp, i32, vp]),
         "orbx_extract_batch_device": (i32, [vp, vp, i32, i32, i32, i32, sz, vp, vp, i32, vp, vp]),
         "orbx_synchronize": (i32, [vp]),
+        "orbx_host_register": (i32, [vp, sz]),
+        "orbx_host_unregister": (i32, [vp]),
         "orbx_stream_wait_fast": (i32, [vp, vp]),
         "orbx_tap_level": (i32, [vp, i32, i32, i32, vp, sz]),
         "orbx_tap_candidates": (i32, [vp, i32, i32, vp, vp, vp, i32, C.POINTER(i32)]),

@@ -1200,6 +1200,19 @@ extern "C" int orbx_get_variant(const orbx_t *c, int which, int *value)
     return ORBX_OK;
 }
 
+extern "C" int orbx_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(ORBX_E_ARG, "null argument");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return ORBX_OK;
+}
+extern "C" int orbx_host_unregister(void *ptr)
+{
+    if (!ptr) return fail(ORBX_E_ARG, "null argument");
+    HIP_TRY(hipHostUnregister(ptr));
+    return ORBX_OK;
+}
+
 extern "C" const char *orbx_last_error(void) { return g_err.c_str(); }
 extern "C" const char *orbx_version(void) { return "orbx 0.1 (gfx950)"; }
 

@@ -185,6 +185,13 @@ class ORBExtractor:
     def synchronize(self):
         _lib.check(self._L.orbx_synchronize(self._h))
 
+    def host_register(self, array):
+        """Page-lock a long-lived frame buffer (orbx_host_register): later calls copy frames out of it without blocking."""
+        _lib.check(self._L.orbx_host_register(_vp(array), array.nbytes))
+
+    def host_unregister(self, array):
+        _lib.check(self._L.orbx_host_unregister(_vp(array)))
+
     # -- stage taps (parity tests) -----------------------------------------------
     def tap_level(self, frame, level, w, h, blurred=False):
         lw, lh = self.level_size(w, h, level)

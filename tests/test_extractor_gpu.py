@@ -163,6 +163,24 @@ def test_uhd_frame(oracle_mod, nf):
     assert kps["x"].max() > 3700 and kps["y"].max() > 2000
 
 
+def test_frames_from_a_page_locked_buffer(oracle_mod):
+    """orbx_host_register: the frame's copy becomes an asynchronous DMA, the launches are issued while it runs -- same records,
+    also when the buffer's contents change between calls (every call waits for its own copy before it returns)."""
+    w, h, nf = 752, 480, 1000
+    ex, orc = _mk(oracle_mod, nf, w, h)
+    buf = np.empty((h, w), np.uint8)
+    ex.host_register(buf)
+    try:
+        for seed in (31, 32, 33):
+            buf[:] = synth.make_frames(1, w, h, seed=seed)[0]
+            kps, desc = ex(buf)
+            _check_frame(ex, orc, buf.copy(), kps, desc, stages=False)
+    finally:
+        ex.host_unregister(buf)
+    kps, desc = ex(buf)   # pageable again
+    _check_frame(ex, orc, buf, kps, desc, stages=False)
+
+
 def test_odd_sizes_and_strides(oracle_mod):
     """widths that are not multiples of 4 (blur / resize edge groups), tall images (nIni = 1), tiny top levels"""
     for (w, h, nf) in ((333, 251, 300), (405, 607, 500), (130, 97, 100)):

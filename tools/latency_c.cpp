@@ -1,10 +1,11 @@
 // Host-to-host latency of orbx_extract as a C++ caller sees it (no Python in the loop).
-//   usage: latency_c frame.bin W H [n_features] [reps] [which=value ...]     (frame.bin: W*H bytes, e.g. written by
+//   usage: latency_c frame.bin W H [n_features] [reps] [pinned] [which=value ...]     (frame.bin: W*H bytes, e.g. written by
 //   tools/latency_c.sh; which=value: orbx_set_variant(handle, which, value), the ORBX_VAR_* numbers of include/orbx.h)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string>
 #include <algorithm>
 #include "../include/orbx.h"
 
@@ -21,6 +22,10 @@ int main(int argc, char **argv)
     cfg.max_width = w; cfg.max_height = h; cfg.max_batch = 1; cfg.device = 0;
     orbx_t *ex = nullptr;
     if (orbx_create(&cfg, &ex)) { fprintf(stderr, "orbx_create: %s\n", orbx_last_error()); return 1; }
+    bool pinned = false;
+    for (int a = 6; a < argc; ++a)
+        if (std::string(argv[a]) == "pinned") { pinned = true; for (int b = a; b + 1 < argc; ++b) argv[b] = argv[b + 1]; --argc; break; }
+    if (pinned && orbx_host_register(img.data(), img.size())) { fprintf(stderr, "orbx_host_register: %s\n", orbx_last_error()); return 1; }
     for (int a = 6; a < argc; ++a) {
         int which = 0, value = 0;
         if (sscanf(argv[a], "%d=%d", &which, &value) != 2 || orbx_set_variant(ex, which, value)) { fprintf(stderr, "bad switch %s: %s\n", argv[a], orbx_last_error()); return 2; }
@@ -39,8 +44,10 @@ int main(int argc, char **argv)
     }
     std::sort(us.begin(), us.end());
     for (int a = 6; a < argc; ++a) printf("[%s] ", argv[a]);
+    if (pinned) printf("[frame in page-locked memory] ");
     printf("%dx%d nf=%d: orbx_extract host-to-host median %.1f us  p10 %.1f  p90 %.1f  (%d key points, %d calls)\n", w, h, nf,
            us[reps / 2], us[reps / 10], us[reps * 9 / 10], n, reps);
+    if (pinned) orbx_host_unregister(img.data());
     orbx_destroy(ex);
     return 0;
 }
