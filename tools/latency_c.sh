@@ -10,3 +10,8 @@ from monoorbslam3_amd import synth
 synth.make_frames(1, $1, $2)[0].tofile('/tmp/frame_$1x$2.bin')"
   tools/bin/latency_c /tmp/frame_$1x$2.bin $1 $2 $3
 done
+# the same with the frame in a page-locked buffer (orbx_host_register): the copy no longer blocks the calling thread
+for shape in "1242 375 2000" "752 480 1000" "1920 1080 2000"; do
+  set -- $shape
+  tools/bin/latency_c /tmp/frame_$1x$2.bin $1 $2 $3 200 pinned
+done
