@@ -94,7 +94,9 @@ int orbx_extract_batch(orbx_t *h, const uint8_t *imgs, int n_frames, int width, 
 
 /* Same, but every pointer is DEVICE memory (inputs already resident in HBM, the
  * bench path) and the work is enqueued on `stream` (a hipStream_t, NULL = the
- * handle's own stream) without a host synchronisation.  There is no host-visible
+ * handle's own stream) without a host synchronisation.  The handle's own stream is a non-blocking one: it does NOT order
+ * itself behind the legacy default stream, so a caller that filled the buffers on the default stream (handle 0 -- which is
+ * also what NULL looks like) synchronises first or passes a stream of its own.  There is no host-visible
  * status for a frame that found more key points than `cap` (the host-pointer calls
  * return ORBX_E_CAPACITY): d_n_out[f] then holds the FULL count, > cap, and only the
  * first cap records are written -- a consumer must use min(d_n_out[f], cap), as every

@@ -22,10 +22,16 @@ def test_rccl_gather_paths_world1():
     import torch.distributed as dist
     from monoorbslam3_amd import dist as D
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    for attempt in range(5):  # a port that was free a moment ago may have been taken (another run's store in TIME_WAIT): pick again
+        os.environ["MASTER_PORT"] = str(_free_port())
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            break
+        except (RuntimeError, ValueError):
+            if attempt == 4:
+                raise
     try:
         b, cap = 5, 12
         rng = np.random.RandomState(1)
