@@ -22,8 +22,8 @@ from monoorbslam3_amd import _lib, synth  # noqa: E402
 from monoorbslam3_amd.extractor import ORBExtractor  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-N_SHAPES = int(sys.argv[2]) if len(sys.argv) > 2 else None   # corner density of the synthetic frames (bench.py's density sweep: 50 / 150)
-W, H = 1242, 375
+N_SHAPES = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else None   # corner density of the synthetic frames (bench.py's density sweep: 50 / 150)
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1242, 375)   # (other shapes: counts only, the ISA mix file stays KITTI's)
 base = synth.make_frames(32, W, H, seed=synth.DEFAULT_SEED, n_shapes=N_SHAPES)          # the bench's batch: 32 distinct frames + per-copy noise
 frames = torch.from_numpy(base).cuda().repeat((B + 31) // 32, 1, 1)[:B].contiguous()
 g = torch.Generator(device="cpu").manual_seed(1234)
@@ -53,5 +53,5 @@ print("per strip: %.2f tile loads, %.1f compass steps, %.2f 16-point batches (%.
       % (res["tile_loads"] / res["strips"], res["compass_steps"] / res["strips"], res["arc_batches"] / res["strips"],
          res["items"] / max(res["arc_batches"], 1), res["score_batches"] / res["strips"], res["pixels"] / max(res["score_batches"], 1)))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-if N_SHAPES is None:
+if N_SHAPES is None and (W, H) == (1242, 375):
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "fast_stage_counts.json"), "w"))
