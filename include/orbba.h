@@ -122,8 +122,8 @@ typedef struct orbba_pose_result {
 
 int orbba_pose_optimize_batch(const orbba_pose_problem *p, orbba_pose_result *r, int device);
 
-/* The same with every array of both structs in DEVICE memory (chi2 must be given), enqueued on `stream` (hipStream_t)
- * without a copy or a wait: the last step of the tracking chain extract -> frame record -> SearchByProjection -> pose
+/* The same with every array of both structs in DEVICE memory (chi2 must be given), enqueued on `stream` (hipStream_t; NULL: orbx.h, "Streams" --
+ * no handle here: stream 0 itself) without a copy or a wait: the last step of the tracking chain extract -> frame record -> SearchByProjection -> pose
  * (Tracking.cpp:289-336) when the steps before it left their results on the device. */
 int orbba_pose_optimize_batch_device(const orbba_pose_problem *p, orbba_pose_result *r, void *stream);
 /* poseOptimize's edges (Optimize.cpp:468-490) from a device-resident frame: for every key point i, in index order, whose
@@ -131,7 +131,7 @@ int orbba_pose_optimize_batch_device(const orbba_pose_problem *p, orbba_pose_res
  * d_q_points[3q..] (float, mp->getPos()), the measurement kp.pt of d_kps[i] (orbx_kp records, undistorted) and
  * invSigma2 = 1.f / kp.size / kp.size (:479).  d_edge_off receives {0, n_edges} (one frame); d_points / d_edge_z /
  * d_edge_inv_sigma2 need room for n2 edges; d_edge_kp (may be NULL) receives i per edge -- the vecIndices of :464 that the
- * caller uses to drop the outliers from the frame (:531-537).  Enqueued on `stream`.
+ * caller uses to drop the outliers from the frame (:531-537).  Enqueued on `stream` (NULL: orbx.h, "Streams").
  * d_frame_mp must hold indices of ONE query set: when two searches filled it (Tracking.cpp:289-336 runs frame -> frame and then
  * map points -> frame on the same frame_mp), give both searches one shared index space -- concatenated query arrays with
  * q_ok masks selecting each search's part -- and pass the concatenated d_q_points here. */

@@ -53,7 +53,7 @@ int orbd_shard_capacity(int n_frames, int world);
  * d_desc [n_frames][cap][32]; n_frames and cap MUST be the same on every rank -- pass orbd_shard_capacity, not
  * orbd_shard_count, when the batch does not divide evenly: mismatched sizes would hang the exchange).  On the root the three *_all buffers
  * (device, world x the local sizes, rank-major) receive them; other ranks may pass NULL.  Enqueued on `stream`
- * (hipStream_t, NULL = the default stream); no host synchronisation. */
+ * (hipStream_t; NULL: orbx.h, "Streams" -- no handle stream here: stream 0 itself); no host synchronisation. */
 int orbd_gather_records(orbd_t *c, int root, int n_frames, int cap, const int32_t *d_n, const orbx_kp *d_kp,
                         const uint8_t *d_desc, int32_t *d_n_all, orbx_kp *d_kp_all, uint8_t *d_desc_all, void *stream);
 /* The same to every rank (ncclAllGather on each of the three arrays). */

@@ -45,7 +45,7 @@ void orbf_destroy(orbf_t *h);
 /* GRID_COLS / GRID_ROWS of Frame.cpp:32-40; n_cells = cols * rows, cell id = cx * rows + cy (grid[cx][cy]) */
 int orbf_grid_dims(const orbf_t *h, int *cols, int *rows);
 
-/* Device pointers, enqueued on `stream` (hipStream_t; NULL = the handle's stream).
+/* Device pointers, enqueued on `stream` (hipStream_t; NULL: orbx.h, "Streams").
  *   d_kp_raw  [n_frames][cap]  in/out: orbx_extract_batch_device's records; `size` is scaled in place (:24-26)
  *   d_n       [n_frames]       key-point counts
  *   d_kp_un   [n_frames][cap]  out: copy of raw with pt undistorted (:28)

@@ -53,7 +53,7 @@ typedef struct orbm_fv {
 /* ORBMatcher::DescriptorDistance (modules/ORB/ORBMatcher.cpp:17-31) for all pairs:
  * out[i*nb + j] = popcount(a[i] ^ b[j]), 0..256.  Host pointers. */
 int orbm_hamming_matrix(orbm_t *h, const uint8_t *a, int na, const uint8_t *b, int nb, uint16_t *out);
-/* same with device pointers, enqueued on `stream` (hipStream_t, NULL = handle's stream) */
+/* same with device pointers, enqueued on `stream` (hipStream_t; NULL: orbx.h, "Streams") */
 int orbm_hamming_matrix_device(orbm_t *h, const uint8_t *d_a, int na, const uint8_t *d_b, int nb, uint16_t *d_out,
                                void *stream);
 
@@ -156,7 +156,7 @@ int orbm_search_fuse(orbm_t *h, const uint8_t *q_desc, const float *q_xy, const 
  * squared distance to the centre exceeds 5.991 * d_sigma2[octave] (the fuse, ORBMatcher.cpp:566-567).
  * d_lists[q * cap + p] = distance << 22 | key-point index for the p-th hit in the reference's list order (cx outer, cy
  * inner, ascending index inside a cell), p < cap; d_counts[q] = the full list length (may exceed cap), -1 for a query
- * that is off.  Every pointer is device memory; enqueued on `stream` (NULL = the handle's).  This is the primitive under
+ * that is off.  Every pointer is device memory; enqueued on `stream` (NULL: orbx.h, "Streams").  This is the primitive under
  * the four window searches above, which wrap it with one staging copy each way when called with host pointers. */
 int orbm_window_lists_device(orbm_t *h, const void *d_kps, const uint8_t *d_desc, const int32_t *d_cell_start,
                              const int32_t *d_cell_items, int grid_cols, int grid_rows, const uint8_t *d_q_desc,
@@ -176,9 +176,11 @@ int orbm_window_lists_device(orbm_t *h, const void *d_kps, const uint8_t *d_desc
  * node: every node is resolved by its own workgroup with the fixed point of the projection searches below, on the 8 closest
  * initially-free candidates per query (a query whose list is used up rescans its node on the device).  Rotation histogram
  * (the reference's 1/30 factor) and ComputeThreeMaxima on the device as well.
- * d_result (int32 x 8, device): [0] matches, [1] = 1 if a node holds more than 4096 features on a side (that node is skipped:
- * use the host entry point), [2] the most sweeps a node needed, [3] matches before the rotation filter.
- * One call in flight per handle (the scratch is the handle's).  Enqueued on `stream` (NULL = the handle's); no host wait. */
+ * d_result (int32 x 8, device): [0] matches, [1] = 1 if a shared node holds more than 4096 features on a side -- found before
+ * anything is written: NOTHING was changed then (frame_mp as passed, matches12 all -1, no match counted), as the projection
+ * searches below guarantee on overflow, so the host entry point can take over on the same arrays --, [2] the most sweeps a
+ * node needed, [3] matches before the rotation filter.
+ * One call in flight per handle (the scratch is the handle's).  Enqueued on `stream` (NULL: orbx.h, "Streams"); no host wait. */
 int orbm_search_by_bow_device(orbm_t *h, float nn_ratio, int check_orientation, const uint8_t *d_desc1, const void *d_kps1,
                               const uint8_t *d_kf_mp_ok, int n1, const uint32_t *d_fv1_nodes, const int32_t *d_fv1_off,
                               const uint32_t *d_fv1_idx, const int32_t *d_n_fv1, const uint8_t *d_desc2, const void *d_kps2,
@@ -204,7 +206,7 @@ int orbm_search_for_triangulation_device(orbm_t *h, int check_orientation, const
  * no bound).  d_result (int32 x 8, device): [0] matches (the return value), [1] = 1 if the lists did not fit the pool --
  * then nothing was changed and the call is to be repeated with a larger list_cap --, [2] sweeps of the fixed point,
  * [3] window-list entries; map points -> frame: [4] numOutViewAndBad, [5] fail1, [6] fail2 (:353-354).
- * nq + n2 <= 38400.  Enqueued on `stream` (NULL = the handle's); no host synchronisation -- with two provisos: the packed
+ * nq + n2 <= 38400.  Enqueued on `stream` (NULL: orbx.h, "Streams"); no host synchronisation -- with two provisos: the packed
  * lists live in the handle's scratch, so ONE call may be in flight per handle (use a handle per thread / per stream), and the
  * first call that needs a larger scratch (nq * list_cap grew) reallocates it, which waits for the device once.  When the lists
  * overflow the pool ([1] = 1) d_frame_mp is left as it was: a chain that goes on to orbba_pose_edges_device then optimises the

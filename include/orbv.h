@@ -50,7 +50,8 @@ int orbv_info(const orbv_t *h, int *k, int *L, int *scoring, int *weighting, int
 /* copies the parsed tree back (for checking a loader): any pointer may be NULL */
 int orbv_nodes(const orbv_t *h, int32_t *parent, uint8_t *is_leaf, uint8_t *desc, double *weight);
 
-/* transform(feature, word_id, weight, &nid, levelsup) (:1218-1259) for n descriptors.  Device pointers. */
+/* transform(feature, word_id, weight, &nid, levelsup) (:1218-1259) for n descriptors.  Device pointers, enqueued on `stream`
+ * (hipStream_t; NULL: orbx.h, "Streams"). */
 int orbv_transform_features_device(orbv_t *h, const uint8_t *d_desc, int n, int levelsup, uint32_t *d_word,
                                    uint32_t *d_node, double *d_weight, void *stream);
 
@@ -60,7 +61,8 @@ int orbv_transform_features_device(orbv_t *h, const uint8_t *d_desc, int n, int 
  *   d_bow_ids / d_bow_vals [n_frames][cap], d_n_words [n_frames]          BowVector, ascending word id
  *   d_fv_nodes [n_frames][cap], d_fv_off [n_frames][cap + 1], d_fv_idx [n_frames][cap], d_n_fv [n_frames]
  *                                                                        FeatureVector as CSR, ascending node id,
- *                                                                        feature indices ascending inside a node */
+ *                                                                        feature indices ascending inside a node
+ * Enqueued on `stream` (NULL: orbx.h, "Streams"); no host synchronisation. */
 int orbv_transform_device(orbv_t *h, int n_frames, const uint8_t *d_desc, const int32_t *d_n, int cap, int levelsup,
                           uint32_t *d_bow_ids, double *d_bow_vals, int32_t *d_n_words, uint32_t *d_fv_nodes,
                           int32_t *d_fv_off, uint32_t *d_fv_idx, int32_t *d_n_fv, void *stream);

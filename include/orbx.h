@@ -11,6 +11,17 @@
  * of the last failure on the calling thread is in orbx_last_error().
  * There is no CPU fallback: without a HIP device the calls fail with
  * ORBX_E_NO_DEVICE.
+ *
+ * Streams -- ONE rule for every `void *stream` argument of orbx.h, orbm.h, orbf.h, orbv.h, orbba.h and orbd.h:
+ * it is a hipStream_t, and NULL means "ordered with the legacy default stream", exactly as a NULL stream does in the HIP
+ * runtime itself.  An entry point that takes a handle runs a NULL-stream call on the handle's own stream, which is created
+ * BLOCKING (hipStreamDefault): it waits for everything enqueued earlier on the null stream (hipMemcpy, kernels launched
+ * with stream 0, torch's default stream) and null-stream work enqueued after the call waits for it.  An entry point without
+ * a handle (orbba_*_device, orbd_*) runs a NULL-stream call on stream 0 itself.  Either way a caller that fills its device
+ * buffers on the null stream, calls with NULL and reads the results on the null stream needs no synchronisation of its own
+ * (tests/cpp/null_stream.cpp).  A caller that works on a NON-BLOCKING stream of its own (hipStreamNonBlocking, any
+ * torch.cuda.Stream) passes that stream: nothing orders a non-blocking stream with NULL.  The library's internal side
+ * streams are forked from and joined into the stream of the call with events; the caller sees one in-order stream.
  */
 #ifndef ORBX_H
 #define ORBX_H
@@ -93,10 +104,8 @@ int orbx_extract_batch(orbx_t *h, const uint8_t *imgs, int n_frames, int width, 
                        int32_t *n_out);
 
 /* Same, but every pointer is DEVICE memory (inputs already resident in HBM, the
- * bench path) and the work is enqueued on `stream` (a hipStream_t, NULL = the
- * handle's own stream) without a host synchronisation.  The handle's own stream is a non-blocking one: it does NOT order
- * itself behind the legacy default stream, so a caller that filled the buffers on the default stream (handle 0 -- which is
- * also what NULL looks like) synchronises first or passes a stream of its own.  There is no host-visible
+ * bench path) and the work is enqueued on `stream` (NULL: see "Streams" at the top of this header) without a host
+ * synchronisation.  There is no host-visible
  * status for a frame that found more key points than `cap` (the host-pointer calls
  * return ORBX_E_CAPACITY): d_n_out[f] then holds the FULL count, > cap, and only the
  * first cap records are written -- a consumer must use min(d_n_out[f], cap), as every
@@ -110,7 +119,7 @@ int orbx_extract_batch_device(orbx_t *h, const uint8_t *d_imgs, int n_frames, in
  * saturates the vector ALUs; the quadtree and the orientation that follow are latency-bound and leave them mostly idle, so
  * ALU-heavy work of the caller -- bench.py: the Hamming match of the previous batch -- costs least when it starts there. */
 int orbx_stream_wait_fast(orbx_t *h, void *stream);
-/* Block until everything enqueued on the handle's stream has finished. */
+/* Block until everything enqueued on the handle's stream (host-pointer calls, NULL-stream device calls) has finished. */
 int orbx_synchronize(orbx_t *h);
 /* Optional, for a caller whose frames live in a long-lived buffer (a capture ring, a cv::Mat that is reused): page-lock that
  * buffer once (hipHostRegister) so that orbx_extract's copy of the frame is a plain DMA that does not block the calling thread
@@ -145,7 +154,7 @@ int orbx_tap_sincos(orbx_t *h, const float *angles_deg, int n, float *cos_sin);
 #define ORBX_VAR_RESIZE2 3      /* 1 by call size (default: two levels per launch below 24 frames), 0 never, 2 always */
 #define ORBX_VAR_SIDE_BLUR 4    /* blur pass on a side stream: 1 beside FAST (default), 2 beside the quadtree, 3 beside the orientation, 0 in line */
 #define ORBX_VAR_EARLY_FAST 5   /* level 0's FAST beside the pyramid: -1 by pyramid kernel (default), 0 no, 1 yes, 2 and its blur */
-#define ORBX_VAR_SPLIT_LEVEL0 6 /* synchronous calls with a few frames: first level of the main chain (default 1), 0 = one chain */
+#define ORBX_VAR_SPLIT_LEVEL0 6 /* synchronous calls with a few frames: first level of the main chain, 1 .. n_levels - 1 (default 1), 0 = one chain */
 #define ORBX_VAR_STREAMS 7      /* frame ranges of a batch on 1..8 internal streams (default 1) */
 #define ORBX_VAR_ZERO_COPY 8    /* 1 small calls write their records into pinned host memory (default), 0 copy them back */
 #define ORBX_VAR_DESC 9         /* 0 by call size (default), 1 separate blur pass + k_orient_desc, 2 k_blur_desc (blur and
@@ -167,7 +176,10 @@ int orbx_get_variant(const orbx_t *h, int which, int *value);
 /* enable = 1: every later extract call records HIP events around each stage, with every kernel on ONE stream (isolated
  * stage times).  enable = 2: the call keeps its streams (FAST, blur and the caller's other work overlap as in production) and
  * events on each stage's own launch stream bracket its launches: orbx_stage_times_in_step_ms then gives every stage's time as it
- * runs beside the others. */
+ * runs beside the others.  Mode 2 times calls that run as ONE frame range (ORBX_VAR_STREAMS = 1, else ORBX_E_UNSUPPORTED from
+ * the query below); a synchronous call with a few frames that takes the split order (ORBX_VAR_SPLIT_LEVEL0) brackets only its FAST,
+ * blur, orientation and descriptor launches -- resize and quadtree read 0 there.  The orientation bracket includes k_desc_bins;
+ * the descriptor bracket opens behind the wait for a side-stream blur. */
 int orbx_set_stage_timing(orbx_t *h, int enable);
 /* timing mode 2: per stage, the sum over the last extract call's launch groups of that stage (FAST: one or two, level 0 may
  * start early on the side stream) of the time between the events around each group.  Synchronises on those events. */

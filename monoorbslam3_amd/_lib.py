@@ -83,6 +83,20 @@ def check(rc):
         raise OrbxError(rc, lib().orbx_last_error().decode("utf-8", "replace"))
 
 
+def stream_arg(stream=None):
+    """The `stream` argument of a *_device entry point for a wrapper call.  An explicit stream (raw hipStream_t as int) is
+    passed through.  None follows torch's CURRENT stream when torch is loaded and the GPU is initialised -- inside
+    `with torch.cuda.stream(s):` the call is enqueued on s, like the tensor operations around it -- and is NULL otherwise,
+    which the C ABI runs on stream 0 (include/orbx.h, "Streams"); torch's default stream IS stream 0."""
+    if stream is not None:
+        return stream
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_initialized():
+        return torch.cuda.current_stream().cuda_stream or None
+    return None
+
+
 def kernels_sha16():
     """First 16 hex digits of the sha256 over the kernel sources (csrc/*.hip, *.h): ties a profile to the code it measured."""
     import glob

@@ -33,6 +33,7 @@ struct orbf_ctx {
     OrbfCam cam{};
     float *d_scale = nullptr;
     hipStream_t stream = nullptr;
+    bool null_pending = false; // a device call was enqueued on stream 0 (NULL): destroy waits for it too
     int32_t *d_cell_of = nullptr, *d_tmp = nullptr;
     size_t scratch_items = 0;
     // host-convenience staging
@@ -190,7 +191,7 @@ extern "C" int orbf_create(const orbf_camera *cam, int device, orbf_t **out)
         delete c;
         return orbx_set_error(ORBX_E_ARG, "image too large for the grid kernel (more than 7679 cells)");
     }
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault); // blocking: ordered with the null stream (include/orbx.h, "Streams")
     if (e == hipSuccess && cam->size_scale) {
         const size_t bytes = (size_t)cam->width * cam->height * 4;
         e = hipMalloc(&c->d_scale, bytes);
@@ -210,6 +211,7 @@ extern "C" void orbf_destroy(orbf_t *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->null_pending) (void)hipStreamSynchronize((hipStream_t)0);
     for (void *p : {(void *)c->d_scale, (void *)c->d_cell_of, (void *)c->d_tmp, (void *)c->d_raw, (void *)c->d_un,
                     (void *)c->d_start, (void *)c->d_items, (void *)c->d_n})
         if (p) (void)hipFree(p);
@@ -233,7 +235,8 @@ extern "C" int orbf_frame_post_device(orbf_t *c, int n_frames, orbx_kp *d_kp_raw
     if (n_frames < 0 || cap <= 0) return orbx_set_error(ORBX_E_ARG, "n_frames must be >= 0 and cap positive");
     if (n_frames == 0) return ORBX_OK;
     F_TRY(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    if (!stream) c->null_pending = true;
     const size_t need = (size_t)n_frames * cap;
     if (need > c->scratch_items) { // scratch grows geometrically; nothing may be in flight on the old one
         F_TRY(hipDeviceSynchronize());

@@ -995,11 +995,13 @@ __global__ void k_projection_levels(const int32_t *__restrict__ lv, int n, int h
 // `bestIdx2 > 0`, :484).
 // ---------------------------------------------------------------------------------------------
 #define BQ_T 1024
+#define BR_MAX_NODE 4096 // features of one node on either side the resolve kernel keeps state for in LDS (a dense single node: 2000)
 struct BowFv { const uint32_t *nodes; const int32_t *off; const uint32_t *idx; const int32_t *n_nodes; }; // a FeatureVector as orbv leaves it
 __global__ __launch_bounds__(BQ_T) void k_bow_queries(BowFv f1, BowFv f2, const uint8_t *__restrict__ mask1, int mask_polarity, int n1,
                                                       int max_nodes, int32_t *__restrict__ node_p2, int32_t *__restrict__ node_qbegin,
                                                       int32_t *__restrict__ q_idx, int32_t *__restrict__ c_begin, int32_t *__restrict__ c_len,
-                                                      int32_t *__restrict__ q_node, int32_t *__restrict__ n_queries)
+                                                      int32_t *__restrict__ q_node, int32_t *__restrict__ n_queries,
+                                                      int32_t *__restrict__ result)
 {
     // The queries in the reference's order -- node by node, a node's features in stored order -- are the usable entries of
     // side 1's CSR in ENTRY order, so the work is split over the entries, not over the nodes (one thread per node walked a
@@ -1047,8 +1049,24 @@ __global__ __launch_bounds__(BQ_T) void k_bow_queries(BowFv f1, BowFv f2, const 
         if (tid == BQ_T - 1) s_base += s_part[tid];
         __syncthreads();
     }
+    // A shared node with more features on either side than k_bow_resolve keeps state for (BR_MAX_NODE) cannot be resolved on the
+    // device.  It is found HERE, before anything is written: the call then reports result[1] = 1 with no query at all, so that
+    // k_topk_lists_n, k_bow_resolve and k_bow_finish have nothing to do and frame_mp / matches12 stay exactly as the caller
+    // passed them -- the host entry point can still reproduce the reference's loop on them (the guarantee the projection
+    // searches give on overflow).  Same node extents as k_bow_resolve computes.
+    const int total = min(s_base, n1);
+    int too_big = 0;
+    for (int p1 = tid; p1 < nn1; p1 += BQ_T) {
+        const int p2 = node_p2[p1];
+        if (p2 < 0) continue;
+        const int qb = node_qbegin[p1];
+        const int qe = min(p1 + 1 < nn1 ? node_qbegin[p1 + 1] : total, total);
+        if (qe - qb > BR_MAX_NODE || f2.off[p2 + 1] - f2.off[p2] > BR_MAX_NODE) too_big = 1;
+    }
+    too_big = __syncthreads_or(too_big);
     if (tid == 0) {
-        *n_queries = min(s_base, n1);
+        *n_queries = too_big ? 0 : total;
+        if (too_big) result[1] = 1;
         node_qbegin[nn1] = 0x7fffffff; // (never read as a begin: the resolve kernel ends a node at the next begin or n_queries)
     }
 }
@@ -1095,7 +1113,6 @@ __global__ __launch_bounds__(256) void k_topk_lists_n(const uint8_t *__restrict_
 
 #define BR_T 256
 #define BR_TOPK 8
-#define BR_MAX_NODE 4096 // features of one node on either side the resolve kernel keeps state for in LDS (a dense single node: 2000)
 template <int MODE>
 __global__ __launch_bounds__(BR_T) void k_bow_resolve(BowFv f1, BowFv f2, int max_nodes, const int32_t *__restrict__ node_p2,
                                                       const int32_t *__restrict__ node_qbegin, const int32_t *__restrict__ n_queries,
@@ -1118,7 +1135,7 @@ __global__ __launch_bounds__(BR_T) void k_bow_resolve(BowFv f1, BowFv f2, int ma
         const int nq = qe - qb;
         if (nq <= 0) continue;
         const int cb = f2.off[p2], nc = f2.off[p2 + 1] - cb;
-        if (nq > BR_MAX_NODE || nc > BR_MAX_NODE) { if (tid == 0) atomicExch(&result[1], 1); continue; } // reported, nothing done for the node
+        if (nq > BR_MAX_NODE || nc > BR_MAX_NODE) continue; // (never taken: k_bow_queries leaves no query at all when a node is this large)
         __syncthreads(); // (the previous node's state is no longer read)
         // initially free candidates: SearchByBow -- no map point yet (:150); triangulation -- no map point on side 2 (:466)
         for (int t = tid; t < nc; t += BR_T) {
@@ -1236,6 +1253,7 @@ __global__ __launch_bounds__(256) void k_bow_finish(int check_orientation, const
 struct orbm_ctx {
     int device;
     hipStream_t stream;
+    bool null_pending = false; // a device call was enqueued on stream 0 (NULL): destroy waits for it too
     DevBuf a, b, out, q_idx, c_begin, c_len, out_begin, c_idx, row_ok, col_ok, bidx, bbest, bsecond;
     DevBuf w_in, w_out, w_grid; // window searches: staged inputs, lists, CSR grid + scratch
     PinBuf h_in, h_out;
@@ -1255,7 +1273,7 @@ extern "C" int orbm_create(int device, orbm_t **out)
     if (device >= ndev) return orbx_set_error(ORBX_E_ARG, "device ordinal out of range");
     orbm_ctx *c = new orbm_ctx();
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess) { // blocking: ordered with the null stream (include/orbx.h, "Streams")
         delete c;
         return orbx_set_error(ORBX_E_NO_DEVICE, "stream creation failed");
     }
@@ -1276,6 +1294,7 @@ extern "C" void orbm_destroy(orbm_t *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->null_pending) (void)hipStreamSynchronize((hipStream_t)0);
     DevBuf *bufs[] = {&c->a, &c->b, &c->out, &c->q_idx, &c->c_begin, &c->c_len, &c->out_begin, &c->c_idx,
                       &c->row_ok, &c->col_ok, &c->bidx, &c->bbest, &c->bsecond, &c->w_in, &c->w_out, &c->w_grid};
     for (DevBuf *d : bufs) d->release();
@@ -1289,7 +1308,8 @@ extern "C" int orbm_hamming_matrix_device(orbm_t *c, const uint8_t *d_a, int na,
 {
     if (!c || !d_a || !d_b || !d_out || na < 0 || nb < 0) return orbx_set_error(ORBX_E_ARG, "bad argument");
     if (na == 0 || nb == 0) return ORBX_OK;
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    if (!stream) c->null_pending = true;
     dim3 grid((nb + 63) / 64, (na + 63) / 64);
     hipLaunchKernelGGL(k_hamming_matrix, grid, dim3(256), 0, s, d_a, na, d_b, nb, d_out);
     M_TRY(hipGetLastError());
@@ -1307,7 +1327,7 @@ extern "C" int orbm_hamming_matrix(orbm_t *c, const uint8_t *a, int na, const ui
     M_TRY(hipMemcpyAsync(c->a.p, a, (size_t)na * 32, hipMemcpyHostToDevice, c->stream));
     M_TRY(hipMemcpyAsync(c->b.p, b, (size_t)nb * 32, hipMemcpyHostToDevice, c->stream));
     int rc = orbm_hamming_matrix_device(c, (const uint8_t *)c->a.p, na, (const uint8_t *)c->b.p, nb, (uint16_t *)c->out.p,
-                                        nullptr);
+                                        c->stream);
     if (rc) return rc;
     M_TRY(hipMemcpyAsync(out, c->out.p, (size_t)na * nb * 2, hipMemcpyDeviceToHost, c->stream));
     M_TRY(hipStreamSynchronize(c->stream));
@@ -1323,7 +1343,8 @@ extern "C" int orbm_best2_device(orbm_t *c, int n_pairs, const uint8_t *d_a, siz
         return orbx_set_error(ORBX_E_ARG, "bad argument");
     if (nb_max >= (1 << 23)) return orbx_set_error(ORBX_E_UNSUPPORTED, "more than 2^23 candidates per problem");
     if (na_max == 0) return ORBX_OK;
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    if (!stream) c->null_pending = true;
     // the matrix-pipe kernel takes every problem without a candidate mask and at most BM_MAX_CAND (8160) candidates --
     // 16 * tile + register must stay below the 4096 free low bits of its keys; anything else runs k_best2;
     // ORBM_VAR_BEST2 = 2 keeps everything on the VALU kernel (the parity twin), 1 takes the i8 matrix kernel
@@ -1370,7 +1391,7 @@ extern "C" int orbm_best2(orbm_t *c, const uint8_t *a, int na, const uint8_t *b,
     if (col_ok && nb) { M_TRY(c->col_ok.need(nb)); M_TRY(hipMemcpyAsync(c->col_ok.p, col_ok, nb, hipMemcpyHostToDevice, s)); d_col = (const uint8_t *)c->col_ok.p; }
     int rc = orbm_best2_device(c, 1, (const uint8_t *)c->a.p, na, nullptr, na, (const uint8_t *)c->b.p, std::max(nb, 1),
                                nullptr, nb, d_row, d_col, (int32_t *)c->bidx.p, (uint16_t *)c->bbest.p,
-                               (uint16_t *)c->bsecond.p, nullptr);
+                               (uint16_t *)c->bsecond.p, c->stream);
     if (rc) return rc;
     M_TRY(hipMemcpyAsync(best_idx, c->bidx.p, (size_t)na * 4, hipMemcpyDeviceToHost, s));
     M_TRY(hipMemcpyAsync(best, c->bbest.p, (size_t)na * 2, hipMemcpyDeviceToHost, s));
@@ -1513,7 +1534,8 @@ extern "C" int orbm_distinctive_descriptors_device(orbm_t *c, const uint8_t *d_d
     if (n_groups < 0) return orbx_set_error(ORBX_E_ARG, "negative group count");
     if (n_groups == 0) return ORBX_OK;
     M_TRY(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    if (!stream) c->null_pending = true;
     hipLaunchKernelGGL(k_medoid, dim3(n_groups), dim3(64), 0, s, d_desc, d_off, n_groups, d_best_idx);
     M_TRY(hipGetLastError());
     return ORBX_OK;
@@ -2174,7 +2196,8 @@ static int projection_device(orbm_ctx *c, int mode, float nn_ratio, int check_or
     const size_t lds = ((size_t)n2 + (size_t)nq) * 4;
     if (lds > 150 * 1024) return orbx_set_error(ORBX_E_UNSUPPORTED, "nq + n2 above 38400: the greedy pass keeps both in LDS");
     M_TRY(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    if (!stream) c->null_pending = true;
     // scratch: [total, pad x3][counts nq][offs nq][lo nq][hi nq][pool nq * list_cap]
     const size_t pool_cap = (size_t)nq * list_cap, head = 16 + (size_t)nq * 16;
     M_TRY(c->w_out.need(head + pool_cap * 4 + 16));
@@ -2234,7 +2257,8 @@ static int bow_device(orbm_ctx *c, int mode, float nn_ratio, int check_orientati
         return orbx_set_error(ORBX_E_ARG, "null argument");
     if (n1 < 0 || n2 < 0) return orbx_set_error(ORBX_E_ARG, "bad size");
     M_TRY(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    if (!stream) c->null_pending = true;
     M_TRY(hipMemsetAsync(d_result, 0, 32, s));
     if (mode == 1 && n1 > 0) M_TRY(hipMemsetAsync(d_matches12, 0xFF, sizeof(int32_t) * (size_t)n1, s)); // -1 (:457)
     if (n1 == 0 || n2 == 0) return ORBX_OK;
@@ -2248,7 +2272,7 @@ static int bow_device(orbm_ctx *c, int mode, float nn_ratio, int check_orientati
     M_TRY(hipMemsetAsync(n_queries, 0, sizeof(int32_t) * 33, s));
     const BowFv f1 = {d_fv1_nodes, d_fv1_off, d_fv1_idx, d_n_fv1}, f2 = {d_fv2_nodes, d_fv2_off, d_fv2_idx, d_n_fv2};
     hipLaunchKernelGGL(k_bow_queries, dim3(1), dim3(BQ_T), 0, s, f1, f2, d_mask1, mode == 0 ? 1 : 0, n1, n1, node_p2, node_qbegin, q_idx, c_begin,
-                       c_len, q_node, n_queries);
+                       c_len, q_node, n_queries, d_result);
     hipLaunchKernelGGL(k_topk_lists_n<BR_TOPK>, dim3((n1 + 3) / 4), dim3(256), 0, s, d_desc1, d_desc2, q_idx, c_begin, c_len, n_queries,
                        reinterpret_cast<const int32_t *>(d_fv2_idx), mode == 0 ? d_frame_mp : nullptr, d_busy2, topk);
     const int grid = std::min(n1, 1024);
@@ -2295,7 +2319,8 @@ extern "C" int orbm_window_lists_device(orbm_t *c, const void *d_kps, const uint
         !d_q_max_level || !d_q_ok || !d_counts || !d_lists || grid_cols < 1 || grid_rows < 1 || cap < 1 || nq < 0)
         return orbx_set_error(ORBX_E_ARG, "bad argument");
     if (nq == 0) return ORBX_OK;
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    if (!stream) c->null_pending = true;
     hipLaunchKernelGGL(k_window_lists, dim3((nq + 3) / 4), dim3(256), 0, s, (const orbx_kp *)d_kps, d_desc, d_cell_start,
                        d_cell_items, grid_cols, grid_rows, d_q_desc, d_q_xy, d_q_radius, d_q_min_level, d_q_max_level, d_q_ok,
                        nq, strict ? 1 : 0, d_sigma2, cap, d_counts, d_lists, nullptr, nullptr);

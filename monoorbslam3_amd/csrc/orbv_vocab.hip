@@ -48,6 +48,7 @@ struct orbv_ctx {
     VocDev dev{};
     void *d_first = nullptr, *d_pk_id = nullptr, *d_pk_desc = nullptr, *d_word_id = nullptr, *d_weight = nullptr;
     hipStream_t stream = nullptr;
+    bool null_pending = false; // a device call was enqueued on stream 0 (NULL): destroy waits for it too
     // per-feature scratch of the batch transform
     uint32_t *s_word = nullptr, *s_node = nullptr;
     double *s_w = nullptr;
@@ -282,7 +283,7 @@ static int upload(orbv_ctx *c)
     V_TRY(hipMemcpy(c->d_weight, c->weight.data(), (size_t)n * 8, hipMemcpyHostToDevice));
     c->dev = VocDev{(const int32_t *)c->d_first, (const uint32_t *)c->d_pk_id, (const uint4 *)c->d_pk_desc,
                     (const uint32_t *)c->d_word_id, (const double *)c->d_weight, c->L, c->n_words, c->scoring, c->weighting};
-    V_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    V_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamDefault)); // blocking: ordered with the null stream (include/orbx.h, "Streams")
     return ORBX_OK;
 }
 
@@ -399,6 +400,7 @@ extern "C" void orbv_destroy(orbv_t *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->null_pending) (void)hipStreamSynchronize((hipStream_t)0);
     for (void *p : {c->d_first, c->d_pk_id, c->d_pk_desc, c->d_word_id, c->d_weight, (void *)c->s_word, (void *)c->s_node,
                     (void *)c->s_w, c->h_desc, c->h_bow_ids, c->h_bow_vals, c->h_fv_nodes, c->h_fv_off, c->h_fv_idx, c->h_counts})
         if (p) (void)hipFree(p);
@@ -443,7 +445,8 @@ extern "C" int orbv_transform_features_device(orbv_t *c, const uint8_t *d_desc, 
     if (c->n_words == 0) return orbx_set_error(ORBX_E_ARG, "empty vocabulary");
     if (n == 0) return ORBX_OK;
     V_TRY(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    if (!stream) c->null_pending = true;
     hipLaunchKernelGGL(k_voc_descend, dim3((n + 255) / 256, 1), dim3(256), 0, s, c->dev, d_desc, (const int32_t *)nullptr, n,
                        n, levelsup, d_word, d_node, d_weight);
     V_TRY(hipGetLastError());
@@ -465,7 +468,8 @@ extern "C" int orbv_transform_device(orbv_t *c, int n_frames, const uint8_t *d_d
     if (check_levelsup(levelsup)) return ORBX_E_ARG;
     if (n_frames == 0) return ORBX_OK;
     V_TRY(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    if (!stream) c->null_pending = true;
     const size_t need = (size_t)n_frames * cap;
     if (need > c->s_items) {
         V_TRY(hipDeviceSynchronize());

@@ -61,6 +61,7 @@ struct orbx_ctx {
     size_t l0_stage_pitch; // staging copy of level 0 for the host-pointer API
     // device state
     hipStream_t stream;
+    bool null_pending = false; // a device call was enqueued on stream 0 (NULL) since the last host-side wait
     OrbxBuffers buf;
     OrbxLevels *d_levels;
     OrbxTap *d_xtap[ORBX_MAX_LEVELS], *d_ytap[ORBX_MAX_LEVELS];
@@ -126,6 +127,15 @@ struct orbx_ctx {
 // ------------------------------------------------------------------------------------------------
 // tables -- reference ORBExtractor.cpp:424-475
 // ------------------------------------------------------------------------------------------------
+// Host-side wait for everything enqueued through the handle: its own stream and, when a device call was given a NULL stream,
+// stream 0 (include/orbx.h, "Streams").
+static hipError_t sync_handle(orbx_ctx *c)
+{
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && c->null_pending) { e = hipStreamSynchronize((hipStream_t)0); c->null_pending = false; }
+    return e;
+}
+
 static void compute_quotas(orbx_ctx *c, int n_features)
 {
     // :443-452.  pow(float,int) is the double overload; the quotient is rounded once to float.
@@ -474,7 +484,10 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
     c->cur_w = c->cur_h = -1;
     auto cleanup = [&](int code) { orbx_destroy(c); return code; };
     if (hipSetDevice(dev) != hipSuccess) return cleanup(fail(ORBX_E_NO_DEVICE, "hipSetDevice failed"));
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+    // The handle's own stream is a BLOCKING stream (hipStreamDefault): it is what a NULL stream argument means, and it must be
+    // ordered with the legacy default stream in both directions (include/orbx.h, "Streams").  The internal side / sub-streams
+    // below are forked from and joined into the stream of the call with events and stay non-blocking.
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess)
         return cleanup(fail(ORBX_E_NO_DEVICE, "hipStreamCreate failed"));
     for (int i = 0; i <= ORBX_N_STAGES; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return cleanup(fail(ORBX_E_NO_DEVICE, "hipEventCreate failed"));
@@ -543,7 +556,7 @@ extern "C" void orbx_destroy(orbx_t *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)sync_handle(c);
     OrbxBuffers &b = c->buf;
     void *ptrs[] = {b.img_arena, b.cand, b.pnode, b.pcode, b.cand_count, b.bnd0, b.bnd1, b.cnt0, b.cnt1, b.rank, b.node_of_rank,
                     b.newpos, b.childcnt, b.childpos, b.best, b.sel, b.kp_ang, b.sel_count, b.sel_prefix, c->d_slot_level, c->d_levels, c->d_umax, c->d_taps,
@@ -733,11 +746,11 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         if (fl > 0) orbx_launch_desc_bins(s, c->d_levels, b, c->bd_tab, fl, bk, c->bd_bk_stride, items, cap, d_n, n_frames);
         orbx_launch_orient_desc(s, d_l0, l0_fs, l0_pitch, c->d_levels, LV, b, c->d_umax, d_kp, d_desc, cap, d_n, n_frames,
                                 fl < L ? blur_done : nullptr, fl, in2 ? c->ev_in[ORBX_STAGE_ORIENT][1] : (t ? c->ev[ORBX_STAGE_ORIENT + 1] : nullptr),
-                                fl > 0 ? items : nullptr);
+                                fl > 0 ? items : nullptr, in2 ? c->ev_in[ORBX_STAGE_DESC][0] : nullptr);
         if (fl > 0)
             orbx_launch_desc_fused(s, d_l0, l0_fs, l0_pitch, LV, b, c->bd_tab, fl, c->d_bd_blocks, c->n_bd_blocks, c->d_bd_band_h, c->d_band_v,
                                    bk, c->bd_bk_stride, items, c->taps, d_kp, d_desc, cap, n_frames);
-        // the descriptor bracket opens at the orientation bracket's closing event (orbx_stage_times_in_step_ms)
+        // (the descriptor bracket was opened by the launcher, behind its wait for the side stream's blur)
         if (in2) { (void)hipEventRecord(c->ev_in[ORBX_STAGE_DESC][1], s); c->ev_in_n[ORBX_STAGE_DESC] = 1; }
     };
     // Level 0 needs no pyramid, so its FAST can start on the side stream beside the resizes.  That pays next to k_resize (no LDS,
@@ -884,7 +897,9 @@ extern "C" int orbx_extract_batch_device(orbx_t *c, const uint8_t *d_imgs, int n
     if (n_frames < 1 || width < 1 || height < 1 || stride < width || cap < 1) return fail(ORBX_E_ARG, "bad size");
     int rc = ensure_geometry(c, width, height, n_frames, 0);
     if (rc) return rc;
-    return enqueue_batch(c, stream ? (hipStream_t)stream : c->stream, d_imgs, frame_stride, stride, n_frames, d_kp,
+    // a NULL stream argument is stream 0 itself (include/orbx.h, "Streams"); the handle remembers it for its host-side waits
+    if (!stream) c->null_pending = true;
+    return enqueue_batch(c, (hipStream_t)stream, d_imgs, frame_stride, stride, n_frames, d_kp,
                          d_desc, cap, d_n, false);
 }
 
@@ -892,7 +907,7 @@ extern "C" int orbx_synchronize(orbx_t *c)
 {
     if (!c) return fail(ORBX_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_handle(c));
     return ORBX_OK;
 }
 
@@ -1020,7 +1035,7 @@ extern "C" int orbx_tap_level(orbx_t *c, int frame, int level, int blurred, uint
     const OrbxLevel &v = c->levels.lv[level];
     if (out_bytes < (size_t)v.w * v.h) return fail(ORBX_E_CAPACITY, "buffer too small");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_handle(c));
     if (blurred && level < c->last_fused_levels) {
         // the last call described this level with k_blur_desc, which keeps the blurred rows in LDS only: the blur pass makes
         // the copy now (all frames of the call, so that later taps find it), on the raw level that is still in place
@@ -1048,7 +1063,7 @@ extern "C" int orbx_tap_candidates(orbx_t *c, int frame, int level, uint16_t *xs
     if (frame < 0 || frame >= c->last_frames || level < 0 || level >= c->levels.n_levels)
         return fail(ORBX_E_ARG, "frame/level out of range");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_handle(c));
     int n = 0;
     HIP_TRY(hipMemcpy(&n, c->buf.cand_count + frame * ORBX_MAX_LEVELS + level, sizeof(int), hipMemcpyDeviceToHost));
     *n_out = n;
@@ -1069,7 +1084,7 @@ extern "C" int orbx_tap_level_counts(orbx_t *c, int frame, int32_t *counts)
     if (!c || !counts || c->cur_w < 0 || !c->last_l0) return fail(ORBX_E_ARG, "no extract call yet");
     if (frame < 0 || frame >= c->last_frames) return fail(ORBX_E_ARG, "frame out of range");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_handle(c));
     HIP_TRY(hipMemcpy(counts, c->buf.sel_count + frame * ORBX_MAX_LEVELS, sizeof(int) * c->levels.n_levels,
                       hipMemcpyDeviceToHost));
     return ORBX_OK;
@@ -1125,13 +1140,14 @@ extern "C" int orbx_stage_times_in_step_ms(orbx_t *c, float *ms)
 {
     if (!c || !ms) return fail(ORBX_E_ARG, "null argument");
     if (c->timing != 2 || c->ev_in_n[ORBX_STAGE_FAST] < 1) return fail(ORBX_E_ARG, "no extract call in timing mode 2 yet");
+    // a batch split over internal streams re-records the same events once per frame range: only the last range would be timed
+    if (c->n_sub > 1) return fail(ORBX_E_UNSUPPORTED, "in-step stage times need ORBX_VAR_STREAMS = 1");
     HIP_TRY(hipSetDevice(c->device));
     for (int st = 0; st < ORBX_N_STAGES; ++st) {
         ms[st] = 0.f;
         for (int i = 0; i < c->ev_in_n[st]; ++i) {
             float t = 0.f;
-            // the descriptor bracket opens where the orientation bracket closes
-            hipEvent_t e0 = st == ORBX_STAGE_DESC ? c->ev_in[ORBX_STAGE_ORIENT][1] : c->ev_in[st][2 * i];
+            hipEvent_t e0 = c->ev_in[st][2 * i];
             HIP_TRY(hipEventSynchronize(c->ev_in[st][2 * i + 1]));
             HIP_TRY(hipEventElapsedTime(&t, e0, c->ev_in[st][2 * i + 1]));
             ms[st] += t;
@@ -1186,6 +1202,12 @@ extern "C" int orbx_set_variant(orbx_t *c, int which, int value)
     int *f = variant_field(c, which, &lo, &hi);
     if (!f) return fail(ORBX_E_ARG, "unknown variant switch");
     if (value < lo || value > hi) return fail(ORBX_E_ARG, "variant value out of range");
+    // only the instantiated group sizes (orbx_get_variant must report what runs, not a value the launcher rounds down)
+    if (which == ORBX_VAR_FAST_CELL_GROUP && value != 1 && value != 4 && value != 8 && value != 16)
+        return fail(ORBX_E_ARG, "FAST cell group must be 1, 4, 8 or 16");
+    // the first level of the main chain lies inside the pyramid: 0 (one chain) .. n_levels - 1
+    if (which == ORBX_VAR_SPLIT_LEVEL0 && value > c->cfg.n_levels - 1)
+        return fail(ORBX_E_ARG, "split level must be below the handle's n_levels");
     *f = value;
     return ORBX_OK;
 }
@@ -1210,6 +1232,30 @@ extern "C" int orbx_host_unregister(void *ptr)
 {
     if (!ptr) return fail(ORBX_E_ARG, "null argument");
     HIP_TRY(hipHostUnregister(ptr));
+    return ORBX_OK;
+}
+
+// Planning query for tests and tools, no device needed: which quadtree build orbx_launch_octree would take for levels
+// [level_begin, level_end) of a call with n_frames frames of w0 x h0 under `cfg` (quotas of n_features, or of `requota` when
+// that is > 0: orbx_create_requota's handle), and with how much dynamic LDS.  out[0] = kind (0 batch, 1 wide, 2 huge then wide,
+// 3 list in global scratch), out[1] = the list arrays' LDS bytes, out[2] = bytes the 1024-thread build is launched with,
+// out[3] = first level of the range that does NOT take the 1024-thread build.
+extern "C" int orbx_dev_octree_plan(const orbx_cfg *cfg, int requota, int w0, int h0, int n_frames, int level_begin, int level_end,
+                                    int64_t *out)
+{
+    if (!cfg || !out || cfg->n_levels < 1 || cfg->n_levels > ORBX_MAX_LEVELS || cfg->n_features < 1 || !(cfg->scale_factor > 1.0f))
+        return fail(ORBX_E_ARG, "bad argument");
+    if (level_begin < 0 || level_end > cfg->n_levels || level_end <= level_begin || n_frames < 1) return fail(ORBX_E_ARG, "bad level range");
+    orbx_ctx *c = new orbx_ctx();
+    c->cfg = *cfg;
+    compute_tables(c);
+    if (requota > 0) compute_quotas(c, requota);
+    Geometry g;
+    int rc = compute_geometry(c, w0, h0, &g);
+    delete c;
+    if (rc) return rc;
+    const OrbxOctPlan p = orbx_octree_plan(g.levels, n_frames, level_begin, level_end);
+    out[0] = p.kind; out[1] = (int64_t)p.lds_bytes; out[2] = (int64_t)p.huge_bytes; out[3] = p.huge_end;
     return ORBX_OK;
 }
 
@@ -1248,7 +1294,7 @@ extern "C" int orbx_dev_octree_phases(orbx_t *c, unsigned long long *out, int n_
 {
     if (!c || !out) return fail(ORBX_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_handle(c));
     HIP_TRY(hipMemcpy(out, c->buf.best, sizeof(unsigned long long) * 64 * n_levels, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }

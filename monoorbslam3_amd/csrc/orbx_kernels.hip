@@ -1770,32 +1770,65 @@ size_t orbx_octree_lds_bytes(const OrbxLevels &levels)
     return need;
 }
 
+// Which build of the quadtree serves levels [level_begin, level_end) of a call and with how much dynamic LDS -- host logic only
+// (tests/test_abi.py sweeps it across the LDS boundaries through orbx_dev_octree_plan, no GPU needed).
+//   kind 0: oct_batch::k_octree_lds (256 threads; resident batches)      kind 1: oct_wide::k_octree_lds (512 threads)
+//   kind 2: oct_huge::k_octree_lds (1024 threads, count pyramid) for levels [level_begin, huge_end), kind 1 for the rest
+//   kind 3: oct_wide::k_octree (node list in global scratch: quotas too large for the LDS-resident list)
+OrbxOctPlan orbx_octree_plan(const OrbxLevels &levels, int n_frames, int level_begin, int level_end)
+{
+    OrbxOctPlan p;
+    p.lds_bytes = orbx_octree_lds_bytes(levels); // the largest level's, whatever the range: one configuration
+    p.huge_end = level_begin;
+    p.huge_bytes = 0;
+    bool small_nodes = true; // 16-bit list positions
+    for (int l = 0; l < levels.n_levels; ++l) small_nodes = small_nodes && levels.lv[l].node_cap < 65535;
+    if (p.lds_bytes > ORBX_OCT_LDS_LIMIT || !small_nodes) { p.kind = 3; return p; }
+    // a resident batch has more workgroups than the chip holds at once: narrower workgroups, more of them per CU
+    if ((size_t)n_frames * (size_t)levels.n_levels > 512) { p.kind = 0; return p; }
+    p.kind = 1;
+    // A level of a megapixel or more in a call with a few frames: 1024 threads and the rest of the CU's LDS for the count
+    // pyramid.  The list arrays are laid out for lds_bytes, so the build is only taken when they fit what it is launched with
+    // (they always did for the default quotas; a 2N re-quota of a large-quota handle can exceed it: the 512-thread build then).
+    int lh = level_begin;
+    while (lh < level_end && levels.lv[lh].w * levels.lv[lh].h >= ORBX_OCT_HUGE_PIXELS) ++lh;
+    if (lh > level_begin && p.lds_bytes <= ORBX_OCT_HUGE_LDS) {
+        p.kind = 2;
+        p.huge_bytes = ORBX_OCT_HUGE_LDS;
+        // One launch for the whole range while every workgroup finds a CU of its own (the small levels then run beside the
+        // large ones: a single frame waits for the longest level, not for the sum).  With more workgroups than CUs a
+        // 1024-thread, whole-LDS workgroup per small level would queue behind the others: those levels go to the 512-thread
+        // build in a second launch.
+        p.huge_end = (size_t)(level_end - level_begin) * (size_t)n_frames > (size_t)ORBX_N_CUS ? lh : level_end;
+    }
+    return p;
+}
+
 void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLevels &levels, const OrbxBuffers &b,
                         int n_frames, size_t sort_lds_bytes, int level_begin, int level_end)
 {
     if (level_end <= level_begin) return;
+    const OrbxOctPlan p = orbx_octree_plan(levels, n_frames, level_begin, level_end);
+    const int lds = (int)p.lds_bytes;
     dim3 grid(level_end - level_begin, n_frames);
-    const size_t lds_bytes = orbx_octree_lds_bytes(levels); // the largest level's, whatever the range: one configuration
-    bool small_nodes = true; // 16-bit list positions
-    for (int l = 0; l < levels.n_levels; ++l) small_nodes = small_nodes && levels.lv[l].node_cap < 65535;
-    // a resident batch has more workgroups than the chip holds at once: narrower workgroups, more of them per CU
-    const bool batch = (size_t)n_frames * (size_t)levels.n_levels > 512;
-    if (lds_bytes <= 160 * 1024 - 256 && small_nodes) {
-        const void *fn = batch ? reinterpret_cast<const void *>(oct_batch::k_octree_lds) : reinterpret_cast<const void *>(oct_wide::k_octree_lds);
-        (void)orbx_lds_opt_in(fn, lds_bytes); // per device; a refusal shows as the launch error the caller checks
-        int max_px = 0;
-        for (int l = level_begin; l < level_end; ++l) max_px = std::max(max_px, levels.lv[l].w * levels.lv[l].h);
-        if (batch) {
-            hipLaunchKernelGGL(oct_batch::k_octree_lds, grid, dim3(ORBX_OCT_THREADS_BATCH), lds_bytes, s, d_levels, b, level_begin, (int)lds_bytes);
-        } else if (max_px >= ORBX_OCT_HUGE_PIXELS) {
-            // one workgroup per CU anyway: it takes the rest of the CU's LDS for its count pyramid
-            const size_t huge_bytes = 160 * 1024 - 1024;
-            (void)orbx_lds_opt_in(reinterpret_cast<const void *>(oct_huge::k_octree_lds), huge_bytes);
-            hipLaunchKernelGGL(oct_huge::k_octree_lds, grid, dim3(1024), huge_bytes, s, d_levels, b, level_begin, (int)huge_bytes);
-        } else {
-            hipLaunchKernelGGL(oct_wide::k_octree_lds, grid, dim3(ORBX_OCT_THREADS), lds_bytes, s, d_levels, b, level_begin, (int)lds_bytes);
-        }
-    } else {
+    switch (p.kind) {
+    case 0:
+        (void)orbx_lds_opt_in(reinterpret_cast<const void *>(oct_batch::k_octree_lds), p.lds_bytes); // per device; a refusal shows as the launch error the caller checks
+        hipLaunchKernelGGL(oct_batch::k_octree_lds, grid, dim3(ORBX_OCT_THREADS_BATCH), p.lds_bytes, s, d_levels, b, level_begin, lds);
+        break;
+    case 2:
+        (void)orbx_lds_opt_in(reinterpret_cast<const void *>(oct_huge::k_octree_lds), p.huge_bytes);
+        hipLaunchKernelGGL(oct_huge::k_octree_lds, dim3(p.huge_end - level_begin, n_frames), dim3(1024), p.huge_bytes, s, d_levels, b,
+                           level_begin, (int)p.huge_bytes);
+        if (p.huge_end == level_end) break;
+        grid = dim3(level_end - p.huge_end, n_frames);
+        level_begin = p.huge_end;
+        [[fallthrough]];
+    case 1:
+        (void)orbx_lds_opt_in(reinterpret_cast<const void *>(oct_wide::k_octree_lds), p.lds_bytes);
+        hipLaunchKernelGGL(oct_wide::k_octree_lds, grid, dim3(ORBX_OCT_THREADS), p.lds_bytes, s, d_levels, b, level_begin, lds);
+        break;
+    default:
         // quotas too large for the LDS-resident list: same algorithm with the list in global scratch
         hipLaunchKernelGGL(oct_wide::k_octree, grid, dim3(ORBX_OCT_THREADS), sort_lds_bytes, s, d_levels, b, level_begin);
     }
@@ -2125,7 +2158,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(DescTab tab, OrbxBuffers b,
 void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
                              uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done, int desc_level_min,
-                             hipEvent_t after_orient, void *d_items)
+                             hipEvent_t after_orient, void *d_items, hipEvent_t desc_open)
 {
     const int pf_o = (levels.kcap_total + OR_KP - 1) / OR_KP;
     OrientLevels tab;
@@ -2147,8 +2180,11 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
                            b, n_frames, reinterpret_cast<float4 *>(item_levels ? d_items : nullptr), item_levels);
     }
     if (after_orient) (void)hipEventRecord(after_orient, s); // stage timing: orientation | descriptors
+    if (desc_level_min < levels.n_levels && blur_done) (void)hipStreamWaitEvent(s, blur_done, 0); // the blurred levels come from a side stream
+    // in-step stage timing: the descriptor bracket opens BEHIND the wait for the side stream's blur, so that blur time the
+    // wait exposes is not booked on the descriptors
+    if (desc_open) (void)hipEventRecord(desc_open, s);
     if (desc_level_min >= levels.n_levels) return; // every level is described by k_blur_desc (orbx_launch_desc_fused)
-    if (blur_done) (void)hipStreamWaitEvent(s, blur_done, 0); // the blurred levels come from a side stream
     DescTab dt;
     dt.n_levels = levels.n_levels; dt.kcap_total = levels.kcap_total; dt.pad[0] = dt.pad[1] = 0;
     for (int l = 0; l < ORBX_MAX_LEVELS; ++l) {

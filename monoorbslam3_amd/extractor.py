@@ -176,7 +176,7 @@ class ORBExtractor:
                              d_n_ptr, stream=None):
         """Everything already in HBM (raw device pointers as ints); enqueues without synchronising."""
         _lib.check(self._L.orbx_extract_batch_device(self._h, d_imgs_ptr, n_frames, w, h, stride, frame_stride,
-                                                     d_kp_ptr, d_desc_ptr, cap, d_n_ptr, stream))
+                                                     d_kp_ptr, d_desc_ptr, cap, d_n_ptr, _lib.stream_arg(stream)))
 
     def stream_wait_fast(self, stream):
         """`stream` (raw hipStream_t as int) waits for the FAST stage of the last enqueued batch (orbx_stream_wait_fast)."""

@@ -84,4 +84,4 @@ class FramePost:
     def post_device(self, n_frames, d_kp_raw, d_n, cap, d_kp_un, d_cell_start, d_cell_items, stream=None):
         """Batch on device pointers (ints); see include/orbf.h."""
         _lib.check(_L().orbf_frame_post_device(self._h, n_frames, d_kp_raw, d_n, cap, d_kp_un, d_cell_start,
-                                               d_cell_items, stream))
+                                               d_cell_items, _lib.stream_arg(stream)))

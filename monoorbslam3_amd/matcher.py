@@ -279,8 +279,7 @@ class ORBMatcher:
         q_level i32 (octave / predicted level), q_angle f32 (frame only), q_ok u8, kps2 (undistorted records, u8 [*,28]),
         desc2 u8 [*,32], cell_start i32, cell_items i32, frame_mp i32 [n2] (in/out), result i32 [8] (out).  Enqueues on
         `stream`; nothing is copied or synchronised (orbm_search_by_projection_{frame,points}_device)."""
-        import torch
-        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        st = _lib.stream_arg(stream)
         p = lambda k: d[k].data_ptr()  # noqa: E731
         if mode == "frame":
             _lib.check(self._L.orbm_search_by_projection_frame_device(
@@ -300,7 +299,7 @@ class ORBMatcher:
         _lib.check(self._hd._L.orbm_search_by_bow_device(
             self._hd._h, self.nn_ratio, int(self.be_check_orientation), p(d["desc1"]), p(d["kps1"]), p(d["kf_mp_ok"]), n1,
             p(d["fv1"][0]), p(d["fv1"][1]), p(d["fv1"][2]), p(d["fv1"][3]), p(d["desc2"]), p(d["kps2"]), p(d["frame_mp"]), n2,
-            p(d["fv2"][0]), p(d["fv2"][1]), p(d["fv2"][2]), p(d["fv2"][3]), p(d["result"]), stream))
+            p(d["fv2"][0]), p(d["fv2"][1]), p(d["fv2"][2]), p(d["fv2"][3]), p(d["result"]), _lib.stream_arg(stream)))
 
     def SearchForTriangulationDevice(self, d, n1, n2, stream=None):
         """orbm_search_for_triangulation_device: d = dict(desc1, kps1, has_mp1, fv1, desc2, kps2, has_mp2, fv2, matches12, result)."""
@@ -308,7 +307,7 @@ class ORBMatcher:
         _lib.check(self._hd._L.orbm_search_for_triangulation_device(
             self._hd._h, int(self.be_check_orientation), p(d["desc1"]), p(d["kps1"]), p(d["has_mp1"]), n1, p(d["fv1"][0]), p(d["fv1"][1]),
             p(d["fv1"][2]), p(d["fv1"][3]), p(d["desc2"]), p(d["kps2"]), p(d["has_mp2"]), n2, p(d["fv2"][0]), p(d["fv2"][1]),
-            p(d["fv2"][2]), p(d["fv2"][3]), p(d["matches12"]), p(d["result"]), stream))
+            p(d["fv2"][2]), p(d["fv2"][3]), p(d["matches12"]), p(d["result"]), _lib.stream_arg(stream)))
 
     def SearchFuse(self, q_desc, q_xy, q_radius, q_level, q_ok, kps, desc, img_w, img_h, sigma2):
         """Per-point core of the fuse: (best_idx, best_dist, n_found); the observation rewiring stays with the caller."""

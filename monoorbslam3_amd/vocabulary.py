@@ -98,9 +98,9 @@ class ORBVocabulary:
         return bi[: nw.value], bv[: nw.value], (fn[: nf.value], fo[: nf.value + 1], fi[: fo[nf.value]])
 
     def transform_features_device(self, d_desc, n, levelsup, d_word, d_node, d_weight, stream=None):
-        _lib.check(_L().orbv_transform_features_device(self._h, d_desc, n, levelsup, d_word, d_node, d_weight, stream))
+        _lib.check(_L().orbv_transform_features_device(self._h, d_desc, n, levelsup, d_word, d_node, d_weight, _lib.stream_arg(stream)))
 
     def transform_device(self, n_frames, d_desc, d_n, cap, levelsup, d_bow_ids, d_bow_vals, d_n_words, d_fv_nodes, d_fv_off,
                          d_fv_idx, d_n_fv, stream=None):
         _lib.check(_L().orbv_transform_device(self._h, n_frames, d_desc, d_n, cap, levelsup, d_bow_ids, d_bow_vals,
-                                              d_n_words, d_fv_nodes, d_fv_off, d_fv_idx, d_n_fv, stream))
+                                              d_n_words, d_fv_nodes, d_fv_off, d_fv_idx, d_n_fv, _lib.stream_arg(stream)))

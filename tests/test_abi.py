@@ -139,3 +139,50 @@ def test_issue_class_pricing_of_the_fast_floor():
     assert kind("global_load_dwordx2 v[2:3], v[0:1], off") == "vmem"
     cheap, slow = m.classify("v_xor_b32_e32 v1, v2, v3")[1], m.classify("v_perm_b32 v1, v2, v3, v4")[1]
     assert 700 < cheap < 1100 and 450 < slow < 650 and m.CHEAP > 1.4 * m.SLOW
+
+
+def test_quadtree_build_choice_across_the_lds_boundaries(built):
+    """orbx_launch_octree's host logic (orbx_dev_octree_plan, no device): the 1024-thread count-pyramid build is only taken
+    when the node-list arrays -- laid out for the largest level's quota -- fit the LDS it is launched with; between that size and
+    the limit of the LDS-resident list the 512-thread build serves, above it the global-scratch build.  Quotas are swept across both
+    boundaries at 1920x1080 (levels 0 and 1 are above the megapixel threshold)."""
+    L = C.CDLL(built.LIB_PATH)
+    fn = L.orbx_dev_octree_plan
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(built.OrbxCfg), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+    HUGE, LIMIT = 160 * 1024 - 1024, 160 * 1024 - 256
+
+    def plan(nf, frames=1, lb=0, le=8, requota=0, w=1920, h=1080):
+        cfg = built.OrbxCfg(nf, 1.2, 8, 20, 7, w, h, frames, 0, -1)
+        out = (C.c_int64 * 4)()
+        rc = fn(C.byref(cfg), requota, w, h, frames, lb, le, out)
+        assert rc in (0, -4)   # -4: a per-level quota above 7680 is refused (orbx_create refuses it the same way)
+        return tuple(out) if rc == 0 else None
+
+    kinds = {}
+    prev_lds = 0
+    for nf in sorted(set(range(500, 14000, 100)) | set(range(10300, 10700, 2))):   # (the 512-thread window is 21 quotas wide)
+        got = plan(nf)
+        if got is None:   # level 0's quota above 4096: its sort keys no longer fit the global-scratch build's LDS either
+            assert nf > 12000
+            break
+        kind, lds, huge, hend = got
+        assert lds >= prev_lds  # grows with the quota
+        prev_lds = lds
+        kinds.setdefault(kind, []).append(lds)
+        if kind == 2:      # the list arrays fit what the build is launched with, and it is launched with the stated size
+            assert lds <= huge == HUGE and hend == 8
+        elif kind == 1:    # too large for the count-pyramid build's launch size, still LDS-resident
+            assert HUGE < lds <= LIMIT
+        else:
+            assert kind == 3 and lds > LIMIT
+    assert set(kinds) == {1, 2, 3}, "the sweep must cross both boundaries: %s" % {k: (min(v), max(v)) for k, v in kinds.items()}
+    # the default tracker quota and its 2N initial extractor take the count-pyramid build for a single frame
+    assert plan(1000)[0] == 2 and plan(1000, requota=2000)[0] == 2
+    # more workgroups than CUs: only the megapixel levels keep the whole-CU build, the small ones go to the 512-thread build
+    kind, _, _, hend = plan(1000, frames=40)
+    assert kind == 2 and hend == 2
+    assert plan(1000, frames=8)[3] == 8
+    # a range without a megapixel level (the main chain of a split call at 1242x375), and a resident batch
+    assert plan(2000, w=1242, h=375)[0] == 1 and plan(2000, frames=512, w=1242, h=375)[0] == 0
+    assert plan(1000, lb=2, le=8)[0] == 1

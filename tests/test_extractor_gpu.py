@@ -373,7 +373,6 @@ def test_one_pass_descriptors_edge_cases(oracle_mod):
     kp = torch.zeros((1, cap + 8, 28), dtype=torch.uint8, device="cuda")
     de = torch.full((1, cap + 8, 32), 0xEE, dtype=torch.uint8, device="cuda")
     n = torch.zeros(1, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
     ex.extract_batch_device(d_img.data_ptr(), 1, w, h, w, w * h, kp.data_ptr(), de.data_ptr(), cap, n.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert int(n[0]) == len(okps)
@@ -430,7 +429,6 @@ def test_batch_device_pointers_and_determinism(oracle_mod):
         d_kp = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
         d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
         d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
         ex.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
         ex.synchronize()
         outs.append((d_n.cpu().numpy(), d_kp.cpu().numpy(), d_desc.cpu().numpy()))
@@ -539,7 +537,6 @@ def test_full_bench_batch_sampled_parity_and_checksum(oracle_mod):
         d_kp = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
         d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
         d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
         ex.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
         ex.synchronize()
         n, kp, desc = d_n.cpu().numpy(), d_kp.cpu().numpy(), d_desc.cpu().numpy()

@@ -306,7 +306,6 @@ def test_best2_device_many_problems(oracle_mod, variant):
         d_bd = torch.full((n_pairs, a_stride), -7, dtype=torch.int16, device=dev)
         d_sd = torch.full((n_pairs, a_stride), -7, dtype=torch.int16, device=dev)
         st = torch.cuda.current_stream().cuda_stream
-        torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
         _lib.check(L.orbm_best2_device(mh._h, n_pairs, dA.data_ptr(), a_stride, dna.data_ptr(), a_stride, dB.data_ptr(),
                                        b_stride, dnb.data_ptr(), b_stride, drow.data_ptr() if masks else None,
                                        dcol.data_ptr() if masks is True else None, d_bi.data_ptr(), d_bd.data_ptr(),
@@ -437,7 +436,6 @@ def test_search_by_bow_and_triangulation_on_the_device(oracle_mod, check_ori):
         # -- SearchByBow
         n_ref, mp_ref = oracle_mod.search_by_bow(ratio, check_ori, a, ang1, ok, fv1, b, ang2, mp0, fv2)
         n_host, mp_host = m.SearchByBow(a, ang1, ok, fv1, b, ang2, mp0, fv2)
-        torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
         m.SearchByBowDevice(d, n1, n2, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         res = d["result"].cpu().numpy()
@@ -447,7 +445,6 @@ def test_search_by_bow_and_triangulation_on_the_device(oracle_mod, check_ori):
         assert n_ref > 0
         # -- SearchForTriangulation
         n_ref, m_ref = oracle_mod.search_for_triangulation(check_ori, a, ang1, h1, fv1, b, ang2, h2, fv2)
-        torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
         m.SearchForTriangulationDevice(d, n1, n2, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         res = d["result"].cpu().numpy()
@@ -461,13 +458,44 @@ def test_search_by_bow_and_triangulation_on_the_device(oracle_mod, check_ori):
     db = dict(desc1=up(a), kps1=kp(kb), kf_mp_ok=up(np.ones(big, np.uint8)), fv1=_dev_fv(fvb, torch, dev, big), desc2=up(b), kps2=kp(kb),
               frame_mp=torch.full((big,), -1, dtype=torch.int32, device=dev), fv2=_dev_fv(synth.feature_vector_by_prefix(b, 0), torch, dev, big),
               result=torch.zeros(8, dtype=torch.int32, device=dev))
-    torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
     m.SearchByBowDevice(db, big, big, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert db["result"].cpu().numpy()[1] == 1 and db["result"].cpu().numpy()[0] == 0 and (db["frame_mp"].cpu().numpy() == -1).all()
+    # ... and NOTHING of the call may have been written when one node is too large among small ones that could have been
+    # resolved: frame_mp comes back exactly as passed (some slots taken), so the host entry point can take over on it (orbm.h)
+    big2 = 4400 + 600
+    rng2 = np.random.RandomState(777)
+    a2 = rng2.randint(0, 256, (big2, 32)).astype(np.uint8)
+    b2 = a2 ^ np.packbits(rng2.uniform(size=(big2, 256)) < 0.08, axis=1, bitorder="little")   # b2[i] is a noisy a2[i]
+    node = np.r_[np.zeros(4400, np.uint8), (1 + np.arange(600) % 15).astype(np.uint8)]     # 4400 features of either side in node 0
+    a2[:, 0] = (a2[:, 0] & 0xF0) | node                                                       # (4 prefix bits), 600 over 15 nodes
+    b2[:, 0] = (b2[:, 0] & 0xF0) | node
+    mp_in = np.full(big2, -1, np.int32)
+    mp_in[::7] = 5
+    kb2 = np.zeros(big2, KP_DTYPE)
+    db2 = dict(desc1=up(a2), kps1=kp(kb2), kf_mp_ok=up(np.ones(big2, np.uint8)), fv1=_dev_fv(synth.feature_vector_by_prefix(a2, 4), torch, dev, big2),
+               desc2=up(b2), kps2=kp(kb2), frame_mp=up(mp_in), fv2=_dev_fv(synth.feature_vector_by_prefix(b2, 4), torch, dev, big2),
+               result=torch.zeros(8, dtype=torch.int32, device=dev), has_mp1=up(np.zeros(big2, np.uint8)), has_mp2=up(np.zeros(big2, np.uint8)),
+               matches12=torch.full((big2,), 7, dtype=torch.int32, device=dev))
+    m.SearchByBowDevice(db2, big2, big2)
+    r2 = db2["result"].cpu().numpy()
+    assert r2[1] == 1 and r2[0] == 0 and r2[3] == 0 and np.array_equal(db2["frame_mp"].cpu().numpy(), mp_in)
+    m.SearchForTriangulationDevice(db2, big2, big2)
+    r2 = db2["result"].cpu().numpy()
+    assert r2[1] == 1 and r2[0] == 0 and (db2["matches12"].cpu().numpy() == -1).all()
+    # the same data with the large node just inside the limit resolves (the small nodes do find matches)
+    keep = np.r_[0:4000, 4400:big2]
+    a3, b3, n3 = a2[keep], b2[keep], len(keep)
+    db3 = dict(desc1=up(a3), kps1=kp(kb2[:n3]), kf_mp_ok=up(np.ones(n3, np.uint8)), fv1=_dev_fv(synth.feature_vector_by_prefix(a3, 4), torch, dev, n3),
+               desc2=up(b3), kps2=kp(kb2[:n3]), frame_mp=torch.full((n3,), -1, dtype=torch.int32, device=dev),
+               fv2=_dev_fv(synth.feature_vector_by_prefix(b3, 4), torch, dev, n3), result=torch.zeros(8, dtype=torch.int32, device=dev))
+    m.SearchByBowDevice(db3, n3, n3)
+    r3 = db3["result"].cpu().numpy()
+    n_ref3, mp_ref3 = oracle_mod.search_by_bow(ratio, check_ori, a3, np.zeros(n3, np.float32), np.ones(n3, np.uint8), synth.feature_vector_by_prefix(a3, 4),
+                                               b3, np.zeros(n3, np.float32), np.full(n3, -1, np.int32), synth.feature_vector_by_prefix(b3, 4))
+    assert r3[1] == 0 and r3[0] == n_ref3 > 100 and np.array_equal(db3["frame_mp"].cpu().numpy(), mp_ref3)
     # nothing to do: empty sides leave frame_mp alone and report no match
     d["result"].fill_(9)
-    torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
     m.SearchByBowDevice(d, 0, n2, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert d["result"].cpu().numpy()[0] == 0
@@ -523,13 +551,10 @@ def test_window_lists_on_a_device_resident_frame_record(oracle_mod):
     d_desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
     d_n = torch.zeros((1,), dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
     ex.extract_batch_device(img.data_ptr(), 1, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), st)
-    torch.cuda.synchronize()  # st is torch's default stream = NULL = "the handle's own stream" to the C ABI: order by hand
     fp = FramePost(w, h, 458.654, 457.296, 367.215, 248.375, dist=(-0.2834, 0.0739, 1.9e-4, 1.8e-5))
     d_start = torch.zeros((1, fp.n_cells + 1), dtype=torch.int32, device=dev)
     d_items = torch.zeros((1, cap), dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
     fp.post_device(1, d_kp.data_ptr(), d_n.data_ptr(), cap, d_un.data_ptr(), d_start.data_ptr(), d_items.data_ptr(), st)
     torch.cuda.synchronize()
     n = int(d_n[0])
@@ -557,7 +582,6 @@ def test_window_lists_on_a_device_resident_frame_record(oracle_mod):
     for strict, gate in ((0, False), (1, False), (1, True)):
         d_cnt = torch.full((nq,), -9, dtype=torch.int32, device=dev)
         d_lst = torch.zeros((nq, LCAP), dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
         _lib.check(L.orbm_window_lists_device(mh._h, d_un.data_ptr(), d_desc.data_ptr(), d_start.data_ptr(), d_items.data_ptr(),
                                               cols, rows, dq.data_ptr(), dxy.data_ptr(), dr.data_ptr(), dmin.data_ptr(),
                                               dmax.data_ptr(), dok.data_ptr(), nq, strict, ds2.data_ptr() if gate else None,
@@ -638,13 +662,10 @@ def _device_record(w, h, nf, seed):
     d_desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
     d_n = torch.zeros((1,), dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
     ex.extract_batch_device(img.data_ptr(), 1, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), st)
-    torch.cuda.synchronize()  # st is torch's default stream = NULL = "the handle's own stream" to the C ABI: order by hand
     fp = FramePost(w, h, 458.654, 457.296, 367.215, 248.375, dist=(-0.2834, 0.0739, 1.9e-4, 1.8e-5))
     d_start = torch.zeros((1, fp.n_cells + 1), dtype=torch.int32, device=dev)
     d_items = torch.zeros((1, cap), dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
     fp.post_device(1, d_kp.data_ptr(), d_n.data_ptr(), cap, d_un.data_ptr(), d_start.data_ptr(), d_items.data_ptr(), st)
     torch.cuda.synchronize()
     n = int(d_n[0])

@@ -206,3 +206,18 @@ def test_cpp_frame_records_end_to_end(oracle_mod, tmp_path):
     r_n, _ = oracle_mod.search_by_bow(0.7, True, d1, k1["angle"], np.ones(len(k1), np.uint8), fv1, d2, k2["angle"],
                                       np.full(len(k2), -1, np.int32), fv2)
     assert n_bow == r_n and n_bow > 30
+
+
+def test_cpp_caller_on_the_null_stream(tmp_path):
+    """include/orbx.h "Streams": a C++ caller that fills on stream 0, calls *_device(..., NULL) and reads on stream 0 needs no
+    synchronisation of its own -- one handle behind fills still in flight, and two handles chained
+    (tests/cpp/null_stream.cpp; expected values from a popcount loop in that file)."""
+    exe = str(tmp_path / "null_stream")
+    lib = os.path.join(ROOT, "monoorbslam3_amd", "lib")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "null_stream.cpp"), "-o", exe,
+                           "-L", lib, "-lorbx", "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe], text=True, capture_output=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "null stream ok" in out.stdout

@@ -63,7 +63,19 @@ def test_track_one_frame_against_ground_truth():
     assert good[out["inlier"]].mean() > 0.95
 
 
-def test_tracking_chain_stays_on_the_device():
+def _chain_stream(torch, dev, kind):
+    """"explicit": a torch stream of the test's own (non-blocking), made current.  "null": None -- the wrappers pass NULL."""
+    if kind == "null":
+        return None
+    chain = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(chain)
+    assert chain.cuda_stream != 0
+    return chain.cuda_stream
+
+
+@pytest.mark.parametrize("stream_kind", ["explicit", "null"])
+def test_tracking_chain_stays_on_the_device(stream_kind):
     """Tracking.cpp:289-336 with no host hop: orbx_extract_batch_device -> orbf_frame_post_device ->
     orbm_search_by_projection_points_device -> orbba_pose_edges_device -> orbba_pose_optimize_batch_device, one stream,
     nothing copied or waited for in between; the pose, the inlier flags and the matches must equal what the same steps
@@ -103,13 +115,10 @@ def test_tracking_chain_stays_on_the_device():
     d_n = torch.zeros((1,), dtype=torch.int32, device=dev)
     d_start = torch.zeros((1, post.n_cells + 1), dtype=torch.int32, device=dev)
     d_items = torch.zeros((1, capk), dtype=torch.int32, device=dev)
-    # ONE explicit stream for the whole chain: the C ABI reads a NULL stream as "the handle's own stream", and torch's
-    # default stream is NULL -- four handles on four private streams would not be ordered against each other
-    chain = torch.cuda.Stream(device=dev)
-    torch.cuda.synchronize()
-    torch.cuda.set_stream(chain)
-    st = chain.cuda_stream
-    assert st != 0
+    # ONE stream for the whole chain: a non-blocking stream of the caller's, or NULL -- which every entry point, with or
+    # without a handle, runs on stream 0 (include/orbx.h, "Streams"), torch's default stream: the fills above, the four
+    # handles' kernels and the reads below are then in order with no wait in between
+    st = _chain_stream(torch, dev, stream_kind)
     ex.extract_batch_device(img.data_ptr(), 1, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), capk, d_n.data_ptr(), st)
     post.post_device(1, d_kp.data_ptr(), d_n.data_ptr(), capk, d_un.data_ptr(), d_start.data_ptr(), d_items.data_ptr(), st)
     # the key-point count is needed as a host integer by the next two calls' signatures: capk (slots past the count hold
@@ -158,7 +167,8 @@ def test_tracking_chain_stays_on_the_device():
     assert np.abs(t_out.cpu().numpy()[0] - t_true).max() < 0.02
 
 
-def test_bow_branch_stays_on_the_device():
+@pytest.mark.parametrize("stream_kind", ["explicit", "null"])
+def test_bow_branch_stays_on_the_device(stream_kind):
     """Tracking.cpp:255-273 (the branch without a motion model) with no host hop: orbx_extract_batch_device of the key frame
     and the frame in one batch -> orbv_transform_device (computeBow, levelsup 4) -> orbm_search_by_bow_device, one stream, the
     first wait at the very end.  frame_mp and the match count equal the host entry point's on the records and FeatureVectors
@@ -182,10 +192,7 @@ def test_bow_branch_stays_on_the_device():
     kf_ok = torch.ones(cap, dtype=torch.uint8, device=dev)          # every key-frame feature has a live map point
     frame_mp = torch.full((cap,), -1, dtype=torch.int32, device=dev)
     result = z((8,), torch.int32)
-    chain = torch.cuda.Stream(device=dev)
-    torch.cuda.synchronize()
-    torch.cuda.set_stream(chain)
-    st = chain.cuda_stream
+    st = _chain_stream(torch, dev, stream_kind)
     ex.extract_batch_device(img.data_ptr(), 2, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), st)
     voc.transform_device(2, d_desc.data_ptr(), d_n.data_ptr(), cap, 4, bow_ids.data_ptr(), bow_vals.data_ptr(), n_words.data_ptr(),
                          fv_nodes.data_ptr(), fv_off.data_ptr(), fv_idx.data_ptr(), n_fv.data_ptr(), st)

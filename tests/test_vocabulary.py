@@ -251,7 +251,6 @@ def test_transform_features_device(oracle_mod):
     node = torch.zeros(3000, dtype=torch.int32, device="cuda")
     w = torch.zeros(3000, dtype=torch.float64, device="cuda")
     for levelsup in (3, 1):
-        torch.cuda.synchronize()  # (the fills above ran on torch's stream; a NULL stream argument means the handle's own, non-blocking stream)
         V.transform_features_device(d.data_ptr(), 3000, levelsup, word.data_ptr(), node.data_ptr(), w.data_ptr(),
                                     torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
