@@ -183,10 +183,12 @@ def main():
     ap.add_argument("--no-match", action="store_true", help="time extraction only")
     ap.add_argument("--no-density-sweep", action="store_true",
                     help="skip the extra (untimed) extraction runs on frames with about a tenth and a third of the headline workload's corner density")
-    ap.add_argument("--match-placement", default="eager", choices=["after-fast", "eager"],
-                    help="when the match of a batch starts: behind the next batch's FAST stage, beside its latency-bound stages "
-                         "(measured: 190.0 k frames/s against 191.5 k eager -- FAST is stretched by the blur and the resize chain beside it, not by "
-                         "the match), or as soon as its own batch is extracted (default)")
+    ap.add_argument("--match-placement", default=None, choices=["after-fast", "eager"],
+                    help="when the match of a batch starts: behind the next batch's FAST stage (orbx_stream_wait_fast), beside its "
+                         "latency-bound quadtree / k_desc_bins / orientation (default; with --best2-resident 1: 2.18 ms per step, "
+                         "two kernels in flight 35-38 %% of the step), or as soon as its own batch is extracted, beside the next "
+                         "batch's pyramid (eager: 2.33 ms; profiles/r05_overlap.md).  One frame per step (config 4) always takes eager: "
+                         "its match reads the previous step's records, which the next extraction overwrites")
     ap.add_argument("--records", action="store_true",
                     help="also build complete frame records per step: undistortion + grid (orbf) and bag of words on a "
                          "synthetic ORBvoc-sized vocabulary (orbv); not the headline configuration")
@@ -200,6 +202,11 @@ def main():
                     help="kernel-choice switch of the extractor handle (orbx_set_variant; names in monoorbslam3_amd/extractor.py "
                          "VARIANTS, e.g. --variant side_blur=2 --variant desc=separate); repeatable")
     ap.add_argument("--best2", default="fp4", choices=["fp4", "i8", "valu"], help="dense best / second-best kernel (orbm_set_variant)")
+    ap.add_argument("--best2-resident", type=int, default=None, choices=[0, 1, 2],
+                    help="k_best2_fp4 as this many workgroups per CU walking the query blocks (ORBM_VAR_BEST2_RESIDENT): the match then "
+                         "holds a fixed share of every CU -- half the registers, 37 KB of LDS at 1 -- and the extraction's kernels "
+                         "beside it always find room; 0 = one workgroup per block of queries.  Default: 1 with --match-placement "
+                         "after-fast, 0 with eager")
     ap.add_argument("--gather", default="torch", choices=["torch", "c-abi"],
                     help="N > 1: the record gather through torch.distributed (default) or through the library's own RCCL "
                          "entry point orbd_gather_records (include/orbd.h)")
@@ -211,6 +218,8 @@ def main():
     args.width = args.width or dw
     args.height = args.height or dh
     args.batch = args.batch or db
+    if args.match_placement is None or args.batch == 1:
+        args.match_placement = "after-fast" if args.batch > 1 else "eager"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -274,6 +283,9 @@ def main():
     d_sd = [torch.zeros((B, cap), dtype=torch.int16, device=dev) for _ in range(NBUF)]
     mh = MatcherHandle(device=local_rank)
     mh.set_variant("best2", args.best2)
+    if args.best2_resident is None:
+        args.best2_resident = 1 if (args.match_placement == "after-fast" and args.best2 == "fp4" and not args.no_match) else 0
+    mh.set_variant("best2_resident", args.best2_resident)
     ML = _mlib()
     rec = None
     if args.records:  # SURVEY 8f rows 2 and 3 chained behind the extraction, all on device buffers
@@ -329,11 +341,15 @@ def main():
                                         cap, None, None, d_bidx[i].data_ptr() + 4 * (B - 1) * cap,
                                         d_bd[i].data_ptr() + 2 * (B - 1) * cap, d_sd[i].data_ptr() + 2 * (B - 1) * cap, st))
 
-    # The match of batch k is ALU-bound like FAST; the quadtree and the orientation are latency-bound.  --match-placement
-    # after-fast therefore starts it not when its batch is extracted (beside the next batch's resize + FAST) but behind the
-    # FAST stage of the NEXT batch (orbx_stream_wait_fast), beside that batch's quadtree / orientation / descriptors; a step
-    # is then still one extraction + one match, the match belonging to the batch before, and flush() -- inside the timed
-    # region -- runs the last one.  Measured: no gain (190.0 k against 191.5 k frames/s), so the default stays eager.
+    # The match of batch k is ALU- and matrix-pipe-bound; the quadtree, k_desc_bins and the orientation of an extraction are
+    # latency-bound and leave those units mostly idle.  --match-placement after-fast (default) therefore starts the match not when
+    # its batch is extracted (beside the next batch's pyramid: both stretch) but behind the FAST stage of the NEXT batch
+    # (orbx_stream_wait_fast), and as a grid of ONE workgroup per CU (ORBM_VAR_BEST2_RESIDENT): it then holds half of every CU's
+    # registers and 37 KB of its LDS for as long as it runs, and the quadtree (two of its four workgroups per CU), k_desc_bins and
+    # k_orient (four of its eight waves per SIMD) run beside it.  A step is still one extraction + one match, the match belonging
+    # to the batch before; flush() -- inside the timed region -- runs the last one.  Round 4 measured this placement with the
+    # match at full occupancy (no gain: whichever kernel came first kept the other out); with the fixed share the step goes
+    # from 2.33 to 2.18 ms.
     pending = [None]
     lagged = args.match_placement == "after-fast" and not args.no_match
 
@@ -685,6 +701,7 @@ def main():
                    "baseline_config": args.config,
                    "frames_per_gpu_per_step": B, "width": W, "height": H, "n_features": NF,
                    "match": not args.no_match, "records": bool(args.records),
+                   "match_placement": None if args.no_match else args.match_placement, "best2_resident": args.best2_resident,
                    "parallelism": ("frames sharded %d per GPU per step over %d GPU(s), one gather of the fixed-capacity records "
                                    "to rank 0 per step" % (B, world)) if world > 1 else
                                   "%d resident frame(s) on one GPU, no collective" % B},

@@ -39,6 +39,9 @@ void orbm_destroy(orbm_t *h);
  * environment variables of earlier builds.  Unknown switch / value out of range: ORBX_E_ARG. */
 #define ORBM_VAR_BEST2 0   /* dense best / second-best: 0 FP4 matrix path k_best2_fp4 (default), 1 i8 matrix path k_best2_mfma, 2 VALU k_best2 */
 #define ORBM_VAR_WINDOW 1  /* window searches of the host entry points: 0 grid and lists on the device (default), 1 host grid */
+#define ORBM_VAR_BEST2_RESIDENT 2 /* k_best2_fp4's grid: 0 one workgroup per (problem, 512 queries) (default); 1 or 2: that many
+                                   * workgroups per CU walk the blocks, so the kernel holds a fixed share of every CU (half of the
+                                   * registers and 37 KB of LDS per workgroup) -- for a caller that runs it beside other kernels */
 int orbm_set_variant(orbm_t *h, int which, int value);
 
 /* DBoW2::FeatureVector (thirdParty/DBoW2/DBoW2/FeatureVector.h) flattened to CSR:

@@ -401,19 +401,33 @@ __device__ __forceinline__ bm_v16f bf_mfma(bm_v4i a, bm_v4i b, bm_v16f c)
     const bm_v8i A = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 4, 4, 0, 0, 0, 0); // scales 0: the unscaled form
 }
+template <bool RESIDENT> // true: a fixed grid walks the query blocks (ORBM_VAR_BEST2_RESIDENT); false: one workgroup per block
 __global__ __launch_bounds__(BF_WAVES * 64, 4) void k_best2_fp4(const uint8_t *__restrict__ a, size_t a_stride,
                                                              const int32_t *__restrict__ na_p, int na_max,
                                                              const uint8_t *__restrict__ b, size_t b_stride,
                                                              const int32_t *__restrict__ nb_p, int nb_max,
                                                              const uint8_t *__restrict__ row_ok,
                                                              int32_t *__restrict__ best_idx, uint16_t *__restrict__ best,
-                                                             uint16_t *__restrict__ second)
+                                                             uint16_t *__restrict__ second, int blocks_x, int n_blocks)
 {
-    __shared__ __align__(16) uint8_t sb[2][BF_TC * BF_ROWB];
-    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
+    // (256 candidates per stage for the walking form, half the barriers at its half occupancy, was measured: 0.427 ms alone and
+    // 2.20 ms per step either way)
+    constexpr int TC = BF_TC;
+    __shared__ __align__(16) uint8_t sb[2][TC * BF_ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // One workgroup per (problem, block of 512 queries) -- or, ORBM_VAR_BEST2_RESIDENT, a grid of a fixed number of workgroups
+    // per CU that walk the blocks: the kernel then never holds more than that share of a CU's registers and LDS, whatever else
+    // is in flight (a caller that runs it beside latency-bound kernels leaves them the rest).
+    // (The walking form keeps its few loop-carried values in scratch between blocks -- four dwords stored before and reloaded
+    // after a block's 63 tiles; the one-block form is the kernel as it always was, no scratch.)
+    int vb = blockIdx.x;
+    // (s_setprio 1 / 3 for the walking form, so that it finishes sooner beside the latency-bound kernels: 2.25 / 2.22 ms per step
+    // against 2.19 without)
+    do {
+    const int p = __builtin_amdgcn_readfirstlane(vb / blocks_x); // (uniform: kept in scalar registers, the kernel has no vector register to spare)
     const int na = na_p ? min(na_p[p], na_max) : na_max, nb = nb_p ? min(nb_p[p], nb_max) : nb_max;
-    const int row0 = blockIdx.x * (BF_WAVES * 64) + wave * 64;
+    const int row0 = __builtin_amdgcn_readfirstlane((vb - p * blocks_x) * (BF_WAVES * 64) + wave * 64);
     const uint8_t *A = a + (size_t)p * a_stride * 32;
     const uint8_t *B = b + (size_t)p * b_stride * 32;
 
@@ -454,14 +468,14 @@ __global__ __launch_bounds__(BF_WAVES * 64, 4) void k_best2_fp4(const uint8_t *_
     // every wave): 0.33-0.35 ms per 512 problems against 0.305.)
     const int sr = tid >> 3, st = tid & 7;
     auto stage = [&](int step, int buf) {
-        uint32_t w[BF_TC / (BF_WAVES * 8)];
+        uint32_t w[TC / (BF_WAVES * 8)];
 #pragma unroll
-        for (int q = 0; q < BF_TC / (BF_WAVES * 8); ++q) {
-            const int j = step * BF_TC + (BF_WAVES * 8) * q + sr;
+        for (int q = 0; q < TC / (BF_WAVES * 8); ++q) {
+            const int j = step * TC + (BF_WAVES * 8) * q + sr;
             w[q] = j < nb ? reinterpret_cast<const uint32_t *>(B + (size_t)j * 32)[st] : 0u;
         }
 #pragma unroll
-        for (int q = 0; q < BF_TC / (BF_WAVES * 8); ++q) {
+        for (int q = 0; q < TC / (BF_WAVES * 8); ++q) {
             const uint32_t M = 0x22222222u;
             uint4 o;
             o.x = (w[q] << 1) & M; o.y = w[q] & M; o.z = (w[q] >> 1) & M; o.w = (w[q] >> 2) & M;
@@ -498,13 +512,13 @@ __global__ __launch_bounds__(BF_WAVES * 64, 4) void k_best2_fp4(const uint8_t *_
             }
         }
     };
-    const int n_steps = (nb + BF_TC - 1) / BF_TC, n_full = nb >> 5;
+    const int n_steps = (nb + TC - 1) / TC, n_full = nb >> 5;
     if (n_steps > 0) stage(0, 0);
     __syncthreads();
     for (int s = 0; s < n_steps; ++s) {
         const int buf = s & 1;
         if (s + 1 < n_steps) stage(s + 1, buf ^ 1);
-        const int t0 = (BF_TC / 32) * s, nt = min(n_full - t0, BF_TC / 32);
+        const int t0 = (TC / 32) * s, nt = min(n_full - t0, TC / 32);
         for (int tl = 0; tl < nt; ++tl) do_tile(buf, tl, t0 + tl, 32, false);
         if (s + 1 == n_steps && (nb & 31)) do_tile(buf, n_full - t0, n_full, nb & 31, true);
         __syncthreads();
@@ -542,6 +556,8 @@ __global__ __launch_bounds__(BF_WAVES * 64, 4) void k_best2_fp4(const uint8_t *_
             second[orow] = live ? (uint16_t)min(ss, 256u) : (uint16_t)256;
         }
     }
+    vb += gridDim.x; // (the stage loop ends on a barrier: the next block may write the staging buffers at once)
+    } while (RESIDENT && vb < n_blocks);
 }
 
 // distances for explicit candidate lists; one wave per query
@@ -1259,6 +1275,8 @@ struct orbm_ctx {
     PinBuf h_in, h_out;
     int window_on_device = 1;   // ORBM_VAR_WINDOW = 1 keeps the host grid (the parity twin of the device lists)
     int best2_variant = 0;      // ORBM_VAR_BEST2: 0 = fp4, 1 = i8, 2 = valu
+    int best2_resident = 0;     // ORBM_VAR_BEST2_RESIDENT: k_best2_fp4 as a grid of this many workgroups per CU (0 = one per block of queries)
+    int n_cus = 256;            // the device's CU count (set at create)
     size_t window_last_total = 0; // candidates the previous window search returned (sizes the first copy-out)
 };
 
@@ -1277,6 +1295,7 @@ extern "C" int orbm_create(int device, orbm_t **out)
         delete c;
         return orbx_set_error(ORBX_E_NO_DEVICE, "stream creation failed");
     }
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cus = cus; }
     *out = c;
     return ORBX_OK;
 }
@@ -1286,6 +1305,7 @@ extern "C" int orbm_set_variant(orbm_t *c, int which, int value)
     if (!c) return orbx_set_error(ORBX_E_ARG, "null handle");
     if (which == ORBM_VAR_BEST2 && value >= 0 && value <= 2) { c->best2_variant = value; return ORBX_OK; }
     if (which == ORBM_VAR_WINDOW && (value == 0 || value == 1)) { c->window_on_device = !value; return ORBX_OK; }
+    if (which == ORBM_VAR_BEST2_RESIDENT && value >= 0 && value <= 2) { c->best2_resident = value; return ORBX_OK; }
     return orbx_set_error(ORBX_E_ARG, "unknown matcher variant switch or value out of range");
 }
 
@@ -1351,9 +1371,17 @@ extern "C" int orbm_best2_device(orbm_t *c, int n_pairs, const uint8_t *d_a, siz
     const int variant = c->best2_variant == 0 ? 2 : c->best2_variant == 1 ? 1 : 0; // 2 = fp4, 1 = i8, 0 = valu
     const bool use_mfma = variant != 0;
     if (variant == 2 && !d_col_ok && nb_max <= BM_MAX_CAND) {
-        dim3 grid((na_max + BF_WAVES * 64 - 1) / (BF_WAVES * 64), n_pairs);
-        hipLaunchKernelGGL(k_best2_fp4, grid, dim3(BF_WAVES * 64), 0, s, d_a, a_stride, d_na, na_max, d_b, b_stride, d_nb,
-                           nb_max, d_row_ok, d_best_idx, d_best, d_second);
+        const int blocks_x = (na_max + BF_WAVES * 64 - 1) / (BF_WAVES * 64);
+        const long long n_blocks = (long long)blocks_x * n_pairs;
+        if (n_blocks > 0x7fffffff) return orbx_set_error(ORBX_E_UNSUPPORTED, "too many problems for one launch");
+        const long long resident = (long long)c->best2_resident * c->n_cus;
+        const int grid = (int)(c->best2_resident > 0 ? std::min(n_blocks, resident) : n_blocks);
+        if (c->best2_resident > 0)
+            hipLaunchKernelGGL(k_best2_fp4<true>, dim3(grid), dim3(BF_WAVES * 64), 0, s, d_a, a_stride, d_na, na_max, d_b, b_stride, d_nb,
+                               nb_max, d_row_ok, d_best_idx, d_best, d_second, blocks_x, (int)n_blocks);
+        else
+            hipLaunchKernelGGL(k_best2_fp4<false>, dim3(grid), dim3(BF_WAVES * 64), 0, s, d_a, a_stride, d_na, na_max, d_b, b_stride, d_nb,
+                               nb_max, d_row_ok, d_best_idx, d_best, d_second, blocks_x, (int)n_blocks);
         M_TRY(hipGetLastError());
         return ORBX_OK;
     }

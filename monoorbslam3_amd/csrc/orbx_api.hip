@@ -766,7 +766,10 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     // cross-stream waits cost throughput -- 4.5 k against 7.0 k single-frame steps per second)
     const bool split = latency && early && slot == 8 && !strips && c->split_level0;
     const int bslot = split ? 7 : slot;
-    if (!split) HIP_TRY(hipMemsetAsync(b.cand_count, 0, sizeof(int) * ORBX_MAX_LEVELS * n_frames, s));
+    // the candidate counters are cleared by the first pyramid launch (one stream operation less ahead of every batch) unless
+    // FAST starts before or without it: level 0's early launch, or a one-level pyramid
+    const bool zero_in_resize = !split && !early && L > 1;
+    if (!split && !zero_in_resize) HIP_TRY(hipMemsetAsync(b.cand_count, 0, sizeof(int) * ORBX_MAX_LEVELS * n_frames, s));
     if (split) {
         // The host needs 2-3 us per launch, about what a small resize takes on the device: the chain the call waits for
         // (resize x7 -> FAST -> quadtree of levels 1..) is issued first and back to back, the two side chains (level 0;
@@ -821,12 +824,16 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         if (early_fast > 1) // level 0 needs no pyramid for its blur either
             launch_blur(c->side[slot], 0, 1);
     }
+    // (Measured and dropped, round 5: the pyramid's last levels -- a chain of small launches, 0.11 ms for a fifth of level 1's
+    // pixels -- and their FAST on the side stream beside FAST of the large levels: resize 0.34 -> 0.18-0.30 ms in step, FAST
+    // 0.70 -> 0.76-0.77, step 2.21 against 2.18 ms for every split level 3..6; profiles/NEGATIVES.md.)
     {
         InStep rt(c, ORBX_STAGE_RESIZE, s);
-        for (int l = 1; l < L;) l = launch_resize(s, l, nullptr) + 1;
+        for (int l = 1; l < L;) l = launch_resize(s, l, l == 1 && zero_in_resize ? b.cand_count : nullptr) + 1;
     }
     if (t) HIP_TRY(hipEventRecord(c->ev[1], s));
-    const bool side = !t && c->side_blur && slot >= 0;
+    // (nothing to fork when k_blur_desc describes every level: no blur pass, and no event pair in the stream between the pyramid and FAST)
+    const bool side = !t && c->side_blur && slot >= 0 && fl < L;
     auto fork_blur = [&]() -> int { // the blur only needs the pyramid: side stream, joined before the descriptor kernel
         HIP_TRY(hipEventRecord(c->ev_pyr[bslot], s));
         HIP_TRY(hipStreamWaitEvent(c->side[bslot], c->ev_pyr[bslot], 0));

@@ -1848,8 +1848,13 @@ struct OrientLevels { // what k_orient needs of every level, passed by value so 
     int kp_off[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS];
     unsigned long long raw_off[ORBX_MAX_LEVELS];
 };
+#ifdef OR_NUM_VGPR // experiment (tools/build_variant.sh): a register ceiling, so that more waves fit beside a co-resident kernel
+#define OR_VGPR_ATTR __attribute__((amdgpu_num_vgpr(OR_NUM_VGPR)))
+#else
+#define OR_VGPR_ATTR
+#endif
 template <bool WITH_ANGLE> // true (calls with a few frames): the lane that holds the moments also does k_angle's work -- one launch less
-__global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ l0, size_t l0_fs, int l0_pitch,
+__global__ __launch_bounds__(256) OR_VGPR_ATTR void k_orient(const uint8_t *__restrict__ l0, size_t l0_fs, int l0_pitch,
                                                 const OrbxLevels *__restrict__ levels, OrientLevels tab, OrbxBuffers b,
                                                 const int *__restrict__ u_max, int per_frame, int n_frames,
                                                 const uint4 *__restrict__ items, int item_levels)

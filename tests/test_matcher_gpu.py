@@ -266,7 +266,14 @@ def test_distinctive_descriptors(oracle_mod):
         ORBMatcher.ComputeDistinctiveDescriptors(np.zeros((1025, 32), np.uint8), np.array([0, 1025], np.int32))
 
 
-@pytest.mark.parametrize("variant", ["fp4", "i8", "valu"])
+def _set_best2(mh, variant):
+    """"fp4" | "i8" | "valu", or "fp4-resident<k>": the FP4 kernel as k workgroups per CU walking the query blocks"""
+    kernel, _, res = variant.partition("-resident")
+    mh.set_variant("best2", kernel)
+    mh.set_variant("best2_resident", int(res) if res else 0)
+
+
+@pytest.mark.parametrize("variant", ["fp4", "i8", "valu", "fp4-resident1"])
 def test_best2_device_many_problems(oracle_mod, variant):
     """orbm_best2_device the way bench.py drives it: several (A, B) problems in one launch, per-problem counts below
     the strides, device pointers, through each of the three kernels that ship (ORBM_VAR_BEST2: the FP4 matrix path, the i8
@@ -299,7 +306,7 @@ def test_best2_device_many_problems(oracle_mod, variant):
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
     dA, dB, dna, dnb, drow, dcol = t(A), t(B), t(na), t(nb), t(row_ok), t(col_ok)
     mh = MatcherHandle(device=0)
-    mh.set_variant("best2", variant)
+    _set_best2(mh, variant)
     L = _mlib()
     for masks in (False, True, "rows"):
         d_bi = torch.full((n_pairs, a_stride), -7, dtype=torch.int32, device=dev)
@@ -327,7 +334,40 @@ def test_best2_device_many_problems(oracle_mod, variant):
     assert bi[1, 0] == -1 and bd[1, 0] == 256  # a 256-distance candidate never beats the initial 256
 
 
-@pytest.mark.parametrize("variant", ["fp4", "i8", "valu"])
+@pytest.mark.parametrize("resident", [1, 2])
+def test_best2_resident_grid_walks_every_block(oracle_mod, resident):
+    """ORBM_VAR_BEST2_RESIDENT: k_best2_fp4 as 1 or 2 workgroups per CU that walk the (problem, 512-query block) list -- more
+    blocks than the grid holds (700 problems of up to 2 blocks each against 256 or 512 workgroups), ragged counts, so that
+    workgroups take two or three blocks of different problems one after the other; every row equals the oracle's scan."""
+    import torch
+    from monoorbslam3_amd import _lib
+    from monoorbslam3_amd.matcher import MatcherHandle, _mlib
+    rng = np.random.RandomState(77 + resident)
+    n_pairs, a_stride, b_stride = 700, 600, 160
+    na = rng.randint(0, a_stride + 1, n_pairs).astype(np.int32)
+    nb = rng.randint(0, b_stride + 1, n_pairs).astype(np.int32)
+    na[:3], nb[:3] = (a_stride, 0, 513), (b_stride, 40, 0)
+    A = rng.randint(0, 256, (n_pairs, a_stride, 32)).astype(np.uint8)
+    B = rng.randint(0, 256, (n_pairs, b_stride, 32)).astype(np.uint8)
+    B[:, :32] = A[:, 7:39] ^ np.packbits(rng.uniform(size=(n_pairs, 32, 256)) < 0.05, axis=2, bitorder="little")
+    dev = torch.device("cuda", 0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    dA, dB, dna, dnb = t(A), t(B), t(na), t(nb)
+    mh = MatcherHandle(device=0)
+    _set_best2(mh, "fp4-resident%d" % resident)
+    d_bi = torch.full((n_pairs, a_stride), -7, dtype=torch.int32, device=dev)
+    d_bd = torch.full((n_pairs, a_stride), -7, dtype=torch.int16, device=dev)
+    d_sd = torch.full((n_pairs, a_stride), -7, dtype=torch.int16, device=dev)
+    _lib.check(_mlib().orbm_best2_device(mh._h, n_pairs, dA.data_ptr(), a_stride, dna.data_ptr(), a_stride, dB.data_ptr(), b_stride,
+                                         dnb.data_ptr(), b_stride, None, None, d_bi.data_ptr(), d_bd.data_ptr(), d_sd.data_ptr(), None))
+    bi, bd, sd = d_bi.cpu().numpy(), d_bd.cpu().numpy().view(np.uint16), d_sd.cpu().numpy().view(np.uint16)
+    for p in range(n_pairs):
+        r_bi, r_bd, r_sd = oracle_mod.best2(A[p, :na[p]], B[p, :nb[p]])
+        assert np.array_equal(bi[p, :na[p]], r_bi) and np.array_equal(bd[p, :na[p]], r_bd) and np.array_equal(sd[p, :na[p]], r_sd), p
+        assert (bi[p, na[p]:] == -1).all() and (bd[p, na[p]:] == 256).all() and (sd[p, na[p]:] == 256).all()
+
+
+@pytest.mark.parametrize("variant", ["fp4", "i8", "valu", "fp4-resident2"])
 def test_best2_dense_2000x2000_every_kernel(oracle_mod, variant):
     """BASELINE config 3's shape (2000 x 2000 256-bit descriptors, no masks) through each dense best / second-best kernel:
     index, best and second distance of every row equal the oracle's scan."""
@@ -335,7 +375,7 @@ def test_best2_dense_2000x2000_every_kernel(oracle_mod, variant):
     a, b, _ = synth.make_descriptor_pair(2000, seed=77)
     b[1234] = b[77]  # a duplicate candidate: the first index wins
     mh = MatcherHandle()
-    mh.set_variant("best2", variant)
+    _set_best2(mh, variant)
     bi, bd, sd = ORBMatcher.best2(a, b, handle=mh)
     r_bi, r_bd, r_sd = oracle_mod.best2(a, b)
     assert np.array_equal(bi, r_bi) and np.array_equal(bd, r_bd) and np.array_equal(sd, r_sd)
