@@ -146,18 +146,28 @@ def stub_run(args, rank, world):
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        time.sleep(1e-3)
+        time.sleep(1e-3 * (1 + rank))  # (rank r sleeps r + 1 ms per step: the per-rank times of `scaling_diag` must tell them apart)
+    t_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    diag = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the same keys as the real run's `scaling_diag` (per-rank time before the barrier, gather time, world as the backend reports it)
+        mine = torch.tensor([t_local / args.steps * 1e3], dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [round(float(x.item()), 4) for x in every]
+        diag = {"ms_per_step_per_rank": per_rank, "ms_per_step_rank_min": min(per_rank), "ms_per_step_rank_max": max(per_rank),
+                "gather_ms_mean": None, "gather_ms_max": None, "gather_timed_by": "no gather in the stub step",
+                "world": dist.get_world_size(), "world_c_abi": None, "backend": "gloo", "gather": None}
     if rank == 0:
         print(json.dumps({"metric": baseline_metric(), "value": round(world * (args.batch or 1) * args.steps / dt, 2), "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "stub",
+                          "higher_is_better": True, "scaling": "weak", "scaling_diag": diag, "vs_baseline": None, "dtype": "u8", "data": "stub",
                           "config": {"workload": "launcher rehearsal: the step is a 1 ms sleep, nothing is measured"}}), flush=True)
     if world > 1:
         dist.barrier()
@@ -351,6 +361,7 @@ def main():
     # match at full occupancy (no gain: whichever kernel came first kept the other out); with the fixed share the step goes
     # from 2.33 to 2.18 ms.
     pending = [None]
+    gather_evs = []  # N > 1: (start, end) events around every gather of the timed region, on the gather's stream
     lagged = args.match_placement == "after-fast" and not args.no_match
 
     def launch_match(i):
@@ -390,7 +401,10 @@ def main():
             launch_match(i)
         if world > 1:
             cstream.wait_event(ev_extracted[i])
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            gather_evs.append((g0, g1))
             with torch.cuda.stream(cstream):
+                g0.record(cstream)
                 if xc is not None:
                     xc.gather(d_n[i], d_kp[i], d_desc[i], root=0, stream=cstream.cuda_stream, out=xc_out[i] if rank == 0 else None)
                 elif args.backend == "nccl":
@@ -398,27 +412,47 @@ def main():
                 else:  # rehearsal on a 1-GPU box: host copies through gloo
                     gather_records_to_root(d_n[i].to(coll_dev), d_kp[i].to(coll_dev), d_desc[i].to(coll_dev),
                                            recv[i] if rank == 0 else None)
+                g1.record(cstream)
                 ev_gathered[i].record(cstream)
 
     def sync():
+        """drain this rank, then meet the others; returns the time at which THIS rank's own work was done"""
         flush()
         torch.cuda.synchronize()
+        t_local = time.perf_counter()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        return t_local
 
     for _ in range(args.warmup):
         step()
     sync()
+    gather_evs.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    sync()
+    t_local = sync() - t0
     dt = time.perf_counter() - t0
+    scaling_diag = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # What a scaling curve needs to be read: every rank's own time for its K steps (before the barrier -- a slow rank shows
+        # here, a slow collective does not), the gather's device time by events on its stream, and the world size as the
+        # collective library reports it.
+        mine = torch.tensor([t_local / args.steps * 1e3], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [round(float(x.item()), 4) for x in every]
+        g_ms = [a.elapsed_time(b2) for a, b2 in gather_evs] if gather_evs else []
+        scaling_diag = {"ms_per_step_per_rank": per_rank, "ms_per_step_rank_min": min(per_rank), "ms_per_step_rank_max": max(per_rank),
+                        "gather_ms_mean": round(sum(g_ms) / len(g_ms), 4) if g_ms else None,
+                        "gather_ms_max": round(max(g_ms), 4) if g_ms else None,
+                        "gather_timed_by": "HIP events on the gather's own stream (rank 0's side of the exchange)",
+                        "world": dist.get_world_size(), "world_c_abi": xc.world_reported() if xc is not None else None,
+                        "backend": args.backend, "gather": args.gather}
     fps = world * B * args.steps / dt
 
     # ---- PCIe-inclusive rate (SURVEY 8d "report both"; never `value`): the same steps, but every batch arrives from
@@ -689,6 +723,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
+        "scaling_diag": scaling_diag,
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",

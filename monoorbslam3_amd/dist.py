@@ -127,6 +127,10 @@ class RecordExchange:
         _lib.check(L.orbd_create(rank, world, idb, device, C.byref(self._h)))
         self.rank, self.world = rank, world
 
+    def world_reported(self):
+        """the communicator's size as RCCL reports it (orbd_world)"""
+        return int(self._L.orbd_world(self._h))
+
     @staticmethod
     def unique_id():
         import ctypes as C

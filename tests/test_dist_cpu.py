@@ -158,7 +158,15 @@ def test_bench_launches_its_own_ranks_from_a_plain_shell():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["data"] == "stub"
-    assert out["ms_per_step"] >= 1.0  # four 1 ms sleeps between the barriers, the slower rank counts
+    assert out["ms_per_step"] >= 2.0  # rank r sleeps r + 1 ms per step between the barriers, the slower rank counts
+    # what a scaling curve needs to be read (`scaling_diag`, the same keys as a real N > 1 run prints): every rank's own time
+    # before the barrier -- rank 1's about twice rank 0's here --, the gather's time, the world size as the backend reports it
+    diag = out["scaling_diag"]
+    assert set(diag) >= {"ms_per_step_per_rank", "ms_per_step_rank_min", "ms_per_step_rank_max", "gather_ms_mean", "gather_ms_max",
+                         "world", "world_c_abi", "backend", "gather"}
+    assert diag["world"] == 2 and len(diag["ms_per_step_per_rank"]) == 2
+    assert diag["ms_per_step_per_rank"][1] > 1.5 * diag["ms_per_step_per_rank"][0] >= 1.5
+    assert diag["ms_per_step_rank_max"] == max(diag["ms_per_step_per_rank"]) <= out["ms_per_step"] + 0.5
     # a mismatch between --gpus and an existing WORLD_SIZE is an error, not a silent single-rank run
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-step"], capture_output=True, text=True,

@@ -218,3 +218,82 @@ def test_bow_branch_stays_on_the_device(stream_kind):
     print("BoW branch on the device: result", res.tolist(), "host matches", n_host, "key points", n.tolist(), "nodes", nf.tolist())
     assert res[1] == 0 and res[0] == n_host and n_host > 100
     assert np.array_equal(got[:n[1]], mp_host) and np.all(got[n[1]:] == -1)
+
+
+def test_two_searches_share_one_index_space_before_the_pose_edges():
+    """include/orbba.h (orbba_pose_edges_device): Tracking.cpp:289-336 runs frame -> frame SearchByProjection and then map points ->
+    frame on the SAME frame_mp.  On the device both searches get one shared index space -- concatenated query arrays, q_ok masks
+    selecting each search's part -- so that frame_mp holds indices into ONE d_q_points array when the edges are built.
+    Device chain: orbx_extract_batch_device -> orbf_frame_post_device -> orbm_search_by_projection_frame_device (first half of the
+    queries) -> orbm_search_by_projection_points_device (second half) -> orbba_pose_edges_device, NULL stream throughout; against
+    the same two searches through the host entry points and the edges listed by hand from their frame_mp."""
+    import torch
+    from monoorbslam3_amd import ba
+    from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
+    from monoorbslam3_amd.frame import FramePost
+    from monoorbslam3_amd.matcher import ORBMatcher
+    dev = torch.device("cuda", 0)
+    w, h, Z = 752, 480, 10.0
+    fx = fy = 460.0
+    cx, cy = 376.0, 240.0
+    canvas = synth.make_canvas(w + 80, h + 60, seed=515)
+    dx, dy = 7, 5
+    f1 = np.ascontiguousarray(canvas[30:30 + h, 40:40 + w])
+    f2 = np.ascontiguousarray(canvas[30 + dy:30 + dy + h, 40 + dx:40 + dx + w])
+    ex = ORBExtractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    post = FramePost(w, h, fx, fy, cx, cy)
+    k1, d1 = ex(f1)
+    _, k1u, _, _ = post(k1)
+    nq = len(k1u)
+    Pw = np.stack([(k1u["x"] - cx) * Z / fx, (k1u["y"] - cy) * Z / fy, np.full(nq, Z)], 1).astype(np.float32)
+    q_xy = np.stack([k1u["x"] - dx, k1u["y"] - dy], 1).astype(np.float32)   # where view 2 sees them
+    q_level = k1u["octave"].astype(np.int32)
+    q_angle = k1u["angle"].astype(np.float32)
+    q_radius = (7.0 * 1.2 ** q_level).astype(np.float32)
+    # one index space, two searches: even queries are "last frame" features (frame -> frame), odd ones local map points
+    ok_frame = (np.arange(nq) % 2 == 0).astype(np.uint8)
+    ok_points = (np.arange(nq) % 2 == 1).astype(np.uint8)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    capk = ex.max_keypoints(w, h)
+    img = t(f2[None])
+    d_kp = torch.zeros((1, capk, 28), dtype=torch.uint8, device=dev)
+    d_un = torch.zeros((1, capk, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((1, capk, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+    d_start = torch.zeros((1, post.n_cells + 1), dtype=torch.int32, device=dev)
+    d_items = torch.zeros((1, capk), dtype=torch.int32, device=dev)
+    ex.extract_batch_device(img.data_ptr(), 1, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), capk, d_n.data_ptr())
+    post.post_device(1, d_kp.data_ptr(), d_n.data_ptr(), capk, d_un.data_ptr(), d_start.data_ptr(), d_items.data_ptr())
+    frame_mp = torch.full((capk,), -1, dtype=torch.int32, device=dev)
+    common = dict(q_desc=t(d1), q_xy=t(q_xy), q_radius=t(q_radius), q_level=t(q_level), q_angle=t(q_angle), kps2=d_un, desc2=d_desc,
+                  cell_start=d_start, cell_items=d_items, frame_mp=frame_mp)
+    m = ORBMatcher(0.8, True)
+    res_f, res_p = torch.zeros(8, dtype=torch.int32, device=dev), torch.zeros(8, dtype=torch.int32, device=dev)
+    m.SearchByProjectionDevice("frame", dict(common, q_ok=t(ok_frame), result=res_f), nq, capk, post.cols, post.rows, list_cap=64)
+    m.SearchByProjectionDevice("points", dict(common, q_ok=t(ok_points), result=res_p), nq, capk, post.cols, post.rows, list_cap=64)
+    e_off = torch.zeros(2, dtype=torch.int32, device=dev)
+    e_P = torch.zeros((capk, 3), dtype=torch.float64, device=dev)
+    e_z = torch.zeros((capk, 2), dtype=torch.float64, device=dev)
+    e_w = torch.zeros(capk, dtype=torch.float64, device=dev)
+    e_kp = torch.zeros(capk, dtype=torch.int32, device=dev)
+    ba.pose_edges_device(capk, nq, frame_mp, d_un, t(Pw), e_off, e_P, e_z, e_w, e_kp)
+    # ---- the host chain on the records read back
+    n2 = int(d_n[0])
+    k2u = np.frombuffer(d_un[0, :n2].cpu().numpy().tobytes(), KP_DTYPE)
+    d2 = d_desc[0, :n2].cpu().numpy()
+    n_f, mp = m.SearchByProjectionFrame(d1, q_xy, q_radius, q_level, q_angle, ok_frame, k2u, d2, w, h, np.full(n2, -1, np.int32))
+    n_p, mp, _ = m.SearchByProjectionPoints(d1, q_xy, q_radius, q_level, ok_points, k2u, d2, w, h, mp)
+    got = frame_mp.cpu().numpy()
+    print("frame search %d + points search %d matches of %d queries, %d key points" % (n_f, n_p, nq, n2))
+    assert int(res_f[1]) == 0 and int(res_p[1]) == 0 and int(res_f[0]) == n_f and int(res_p[0]) == n_p
+    assert n_f > 100 and n_p > 100
+    assert np.array_equal(got[:n2], mp) and np.all(got[n2:] == -1)
+    idx2 = np.flatnonzero(mp >= 0)
+    q = mp[idx2]
+    assert (q % 2 == 0).any() and (q % 2 == 1).any()       # the edges mix both searches' queries
+    ne = int(e_off[1])
+    assert ne == len(idx2) and np.array_equal(e_kp[:ne].cpu().numpy(), idx2)
+    assert np.array_equal(e_P[:ne].cpu().numpy(), Pw[q].astype(np.float64))
+    zz = np.stack([k2u["x"][idx2], k2u["y"][idx2]], 1).astype(np.float64)
+    ww = (np.float32(1.0) / k2u["size"][idx2] / k2u["size"][idx2]).astype(np.float64)
+    assert np.array_equal(e_z[:ne].cpu().numpy(), zz) and np.array_equal(e_w[:ne].cpu().numpy(), ww)
