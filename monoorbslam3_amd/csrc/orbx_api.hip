@@ -19,6 +19,9 @@
 #include "orb_math.h"
 #include "orbx_internal.h"
 
+#ifndef ORBX_HANDLE_STREAM_FLAGS // (a build with hipStreamNonBlocking measures what the blocking handle stream costs a single-frame call: tools/ab_latency.sh)
+#define ORBX_HANDLE_STREAM_FLAGS hipStreamDefault
+#endif
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // shared with the matcher translation unit (orbm_matcher.hip)
@@ -487,7 +490,7 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
     // The handle's own stream is a BLOCKING stream (hipStreamDefault): it is what a NULL stream argument means, and it must be
     // ordered with the legacy default stream in both directions (include/orbx.h, "Streams").  The internal side / sub-streams
     // below are forked from and joined into the stream of the call with events and stay non-blocking.
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess)
+    if (hipStreamCreateWithFlags(&c->stream, ORBX_HANDLE_STREAM_FLAGS) != hipSuccess)
         return cleanup(fail(ORBX_E_NO_DEVICE, "hipStreamCreate failed"));
     for (int i = 0; i <= ORBX_N_STAGES; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return cleanup(fail(ORBX_E_NO_DEVICE, "hipEventCreate failed"));
