@@ -218,15 +218,56 @@ __global__ __launch_bounds__(64 * RL_WAVES) void k_resize_lds(const uint8_t *__r
     uint32_t sel[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) sel[i] = (uint32_t)(ofs[i] - ofs[0]) * 0x00010001u + 0x0c010c00u; // bytes (o, o+1) -> 16-bit halves
+    // The horizontal step of a SOURCE row is computed once and kept for the output rows that use it: at scale 1.2 an output row's
+    // two source rows are (s, s + 1) and the next one's (s + 1, s + 2) four times out of five, so eight output rows take about
+    // 10.4 horizontal rows instead of 16 (LDS reads, window shifts, byte selects and dot products all go down by a third).  Which
+    // rows are at hand is wave-uniform (the row taps come through the scalar cache): the choice is a scalar branch.  The value
+    // kept is already the ">> 4" of cv::resize's vertical step.  Same integers as resize_quad, pixel for pixel.
+    typedef unsigned short rl_u16x2 __attribute__((ext_vector_type(2)));
+    auto hrow = [&](int rr, uint32_t g[4]) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(tcol + rr * RL_LP);
+        const uint32_t a0 = p[0], a1 = p[1], a2 = p[2];
+        const uint32_t wl = __builtin_amdgcn_alignbit(a1, a0, sh8), wh = __builtin_amdgcn_alignbit(a2, a1, sh8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            g[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(rl_u16x2, __builtin_amdgcn_perm(wh, wl, sel[i])), __builtin_bit_cast(rl_u16x2, cc[i]), 0u, false) >> 4;
+    };
+    int rowA = -1, rowB = -1; // the source rows (tile-relative) whose horizontal results gA / gB hold
+    uint32_t gA[4] = {0, 0, 0, 0}, gB[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < RS_ROWS; ++r) {
         if (dy0 + r >= dh) break;
         const OrbxTap ty = ytap[dy0 + r];
         const int r0 = min(max(ty.ofs, 0), sh - 1) - r_lo, r1 = min(max(ty.ofs + 1, 0), sh - 1) - r_lo;
-        const uint32_t *p0 = reinterpret_cast<const uint32_t *>(tcol + r0 * RL_LP), *p1 = reinterpret_cast<const uint32_t *>(tcol + r1 * RL_LP);
-        const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], c0 = p1[0], c1 = p1[1], c2 = p1[2];
-        const uint32_t q = resize_quad(__builtin_amdgcn_alignbit(a1, a0, sh8), __builtin_amdgcn_alignbit(a2, a1, sh8),
-                                       __builtin_amdgcn_alignbit(c1, c0, sh8), __builtin_amdgcn_alignbit(c2, c1, sh8), sel, cc, ty.c0, ty.c1);
+        if (r0 != rowA) {
+            if (r0 == rowB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gA[i] = gB[i];
+            } else {
+                hrow(r0, gA);
+            }
+            rowA = r0;
+        }
+        if (r1 != rowB) {
+            if (r1 == rowA) { // (the clamped last row: both taps on one source row)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gB[i] = gA[i];
+            } else {
+                hrow(r1, gB);
+            }
+            rowB = r1;
+        }
+        // vertical step: ((b0 * g0 >> 16) + (b1 * g1 >> 16) + 2) >> 2.  The "+ 2" rides on the first product as 2 << 16, the two
+        // ">> 16" are the word selects of one SDWA addition, and the four ">> 2" are two packed 16-bit shifts.
+        uint32_t sm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t p0 = __umul24((uint32_t)ty.c0, gA[i]) + 0x20000u, p1 = __umul24((uint32_t)ty.c1, gB[i]);
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(sm[i]) : "v"(p0), "v"(p1));
+        }
+        const rl_u16x2 lo = __builtin_bit_cast(rl_u16x2, __builtin_amdgcn_perm(sm[1], sm[0], 0x05040100u)) >> (unsigned short)2;
+        const rl_u16x2 hi = __builtin_bit_cast(rl_u16x2, __builtin_amdgcn_perm(sm[3], sm[2], 0x05040100u)) >> (unsigned short)2;
+        const uint32_t q = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
         *reinterpret_cast<uint32_t *>(D + (size_t)(dy0 + r) * dst_pitch + dx0) = q; // rows of the arena are 64-byte aligned and padded
     }
 }
@@ -1864,6 +1905,8 @@ __global__ __launch_bounds__(256) OR_VGPR_ATTR void k_orient(const uint8_t *__re
     __shared__ __align__(16) uint32_t s_mask[64][4];
     int frame, blk;
     if (!xcd_remap(per_frame, n_frames, &frame, &blk)) return;
+    // (s_setprio 3 here and / or in the batch quadtree, so that they issue ahead of the co-resident match: 2.23-2.26 ms per step
+    // against 2.19-2.20; profiles/NEGATIVES.md)
     const int tid = threadIdx.x, sub = tid & (OR_LANES - 1), grp = tid / OR_LANES;
     const int L = levels->n_levels, kc = levels->kcap_total;
     const int *cnts = b.sel_count + frame * ORBX_MAX_LEVELS;
