@@ -2453,7 +2453,11 @@ __global__ __launch_bounds__(BD_T) BD_OCC void k_blur_desc(FastSrc src, BdLevels
     auto describe = [&](const BdItem &it) {
         if (it.out_idx < 0) return;
         const int x = (int)(it.xy & 0xFFFF), y = (int)(it.xy >> 16);
-        const float a = it.cs, bb = it.sn;
+        float a = it.cs, bb = it.sn;
+        // (the record comes through the scalar cache: as scalar operands cos and sin would put the 32 multiplications below into
+        // the slow issue class -- v_and with a scalar operand 4.95 cycles against 3.2 / 2.7, profiles/r03_valu_ops3.txt -- two
+        // moves make them vector operands)
+        asm("" : "+v"(a), "+v"(bb));
         // cvRound through the float adder as in k_orient_desc: bits(v + 1.5 * 2^23) = M + round(v), M's low bits are zero
         const float MAGIC = 12582912.f;
         const uint32_t M = 0x4B400000u;
@@ -2471,6 +2475,8 @@ __global__ __launch_bounds__(BD_T) BD_OCC void k_blur_desc(FastSrc src, BdLevels
                 const uint32_t c0 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px0[j], a), ORB_FMUL(py0[j], bb)), MAGIC));
                 const uint32_t r1 = __float_as_uint(ORB_FADD(ORB_FADD(ORB_FMUL(px1[j], bb), ORB_FMUL(py1[j], a)), MAGIC));
                 const uint32_t c1 = __float_as_uint(ORB_FADD(ORB_FSUB(ORB_FMUL(px1[j], a), ORB_FMUL(py1[j], bb)), MAGIC));
+                // (v_mad_u32_u24 + v_add instead of the v_mul_u32_u24 + v_add3 the compiler picks: 0.492 against 0.489 ms; the next
+                // record requested a key point ahead: no change)
                 const int t0 = s_ring[__umul24(r0, BD_RP) + c0 + K];
                 const int t1 = s_ring[__umul24(r1, BD_RP) + c1 + K];
                 bits[j] = __ballot(t0 < t1);
