@@ -1049,13 +1049,14 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
             const uint32_t *t = reinterpret_cast<const uint32_t *>(&tile[rsub * FS_TP + 4 * g]); // (row r - 3, column tc - 4)
             uint32_t ent = (uint32_t)rsub | ((uint32_t)g << 8);
             const int t_step = R * (FS_TP / 4);
-            // rows this lane still has below it, kept in a vector register and turned into a mask arithmetically
-            // ((left - 1) >> 31 is all ones once left <= 0): subtract, shift and a three-input logic operation are in the cheap
-            // issue class, the add-with-a-scalar, compare and select they replace are not (profiles/r03_valu_ops3.txt)
-            int left = ch - rsub;
-            int vstep = R;
-            asm volatile("" : "+v"(vstep)); // a vector register operand: the same subtraction with a scalar one issues at half the rate
-            for (int r0 = 0; r0 < ch; r0 += R, t += t_step, ent += (uint32_t)R, left -= vstep) {
+            // Only the LAST step of a pass can hold rows below the cell (ch = 30 and R = 2 for a full strip: none at all); every
+            // other step takes the lanes' validity mask as it is.  In the last one the rows a lane still has below it become a mask
+            // arithmetically ((left - 1) >> 31 is all ones once left <= 0: subtract, shift and a three-input logic operation are in
+            // the cheap issue class, the compare and select they replace are not, profiles/r03_valu_ops3.txt).  The choice is a
+            // scalar branch.
+            int rsub_v = rsub;
+            asm volatile("" : "+v"(rsub_v));
+            for (int r0 = 0; r0 < ch; r0 += R, t += t_step, ent += (uint32_t)R) {
                 FS_COUNT(2, 1);
                 FS_MARK("compass_begin");
                 const uint32_t M6 = 0x3F3F3F3Fu;
@@ -1066,9 +1067,14 @@ __global__ __launch_bounds__(64) void k_fast_strip(FastSrc src, const OrbxLevels
                 // a 9-arc holds two adjacent compass points: (S or N) and (E or W), all darker or all brighter
                 uint32_t m = ((Vd - dn) | (Vd - up)) & ((Vd - E) | (Vd - Wv));
                 m |= ((Vb + dn) | (Vb + up)) & ((Vb + E) | (Vb + Wv));
-                uint32_t gone; // all ones once left <= 0 (written as an instruction: the compiler would turn the shift back into compare + select)
-                asm("v_ashrrev_i32 %0, 31, %1" : "=v"(gone) : "v"(left - 1));
-                m &= vm & ~gone;
+                if (r0 + R <= ch) {
+                    m &= vm;
+                } else {
+                    const int left = (ch - r0) - rsub_v;
+                    uint32_t gone; // all ones once left <= 0 (written as an instruction: the compiler would turn the shift back into compare + select)
+                    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(gone) : "v"(left - 1));
+                    m &= vm & ~gone;
+                }
                 const bool surv = m != 0;
                 const u64 mk = __ballot(surv);
                 if (surv) iq[wave_rank_from(mk, iq_tail) & (FS_IQ - 1)] = m | ent;
