@@ -27,7 +27,7 @@ BUDGET = {
 }
 
 
-def _isa():
+def _isa(source="orbx_kernels"):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not found")
@@ -37,11 +37,22 @@ def _isa():
             h.update(open(os.path.join(CSRC, f), "rb").read())
     out_dir = os.path.join(ROOT, "build", "isa")
     os.makedirs(out_dir, exist_ok=True)
-    out = os.path.join(out_dir, "orbx_kernels_%s.s" % h.hexdigest()[:16])
+    out = os.path.join(out_dir, "%s_%s.s" % (source, h.hexdigest()[:16]))
     if not os.path.exists(out):
-        subprocess.run([hipcc] + FLAGS + ["-o", out, os.path.join(CSRC, "orbx_kernels.hip")], check=True, cwd=CSRC,
+        subprocess.run([hipcc] + FLAGS + ["-o", out, os.path.join(CSRC, source + ".hip")], check=True, cwd=CSRC,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return open(out).read()
+
+
+def _kernels(isa):
+    """mangled name -> (VGPRs, scratch bytes, static LDS bytes)"""
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", isa, re.S):
+        body = m.group(2)
+        out[m.group(1)] = (int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)),
+                           int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)),
+                           int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1)))
+    return out
 
 
 def test_occupancy_critical_kernels_stay_within_their_register_budgets():
@@ -57,3 +68,27 @@ def test_occupancy_critical_kernels_stay_within_their_register_budgets():
     assert set(found) == set(BUDGET), "kernels renamed? missing: %s" % sorted(set(BUDGET) - set(found))
     over = {k: (found[k], BUDGET[k]) for k in BUDGET if found[k][0] > BUDGET[k][0] or found[k][1] > BUDGET[k][1]}
     assert not over, "over budget (got (vgpr, scratch), budget (vgpr, scratch, why)): %s" % over
+
+
+def test_the_match_and_its_partners_fit_one_cu_together():
+    """bench.py's default step runs the previous batch's match -- k_best2_fp4 as ONE 8-wave workgroup per CU
+    (ORBM_VAR_BEST2_RESIDENT = 1) -- beside the quadtree, k_desc_bins and k_orient of the next extraction (DESIGN 4f,
+    profiles/r05_overlap.md).  That only works while the shares add up on a CU of 4 SIMDs x 512 VGPRs and 160 KB of LDS: the
+    match's two waves per SIMD, two quadtree workgroups (one wave per SIMD each), four k_orient waves per SIMD."""
+    x, m = _kernels(_isa("orbx_kernels")), _kernels(_isa("orbm_matcher"))
+    pick = lambda d, key: next(v for k, v in d.items() if key in k)  # noqa: E731
+    alloc = lambda vg: (vg + 7) // 8 * 8                            # VGPRs are allocated in blocks of 8 on gfx950  # noqa: E731
+    match_vg, match_scratch, match_lds = pick(m, "k_best2_fp4ILb1E")
+    plain_vg, plain_scratch, _ = pick(m, "k_best2_fp4ILb0E")
+    oct_vg, _, oct_lds = pick(x, "oct_batch12k_octree_lds")
+    ori_vg, _, ori_lds = pick(x, "k_orientILb0E")
+    assert match_vg <= 128 and plain_vg <= 128 and plain_scratch == 0      # two workgroups per CU at full occupancy, no spill in the hot form
+    assert match_scratch <= 64                                             # the walking form keeps a few loop-carried values in scratch BETWEEN blocks
+    assert match_lds <= 40 * 1024
+    oct_dyn = 34 * 1024                                                    # orbx_octree_lds_bytes for 1242x375 / 2000 features (33.3 KB)
+    # the match (8 waves: 2 per SIMD) + two quadtree workgroups (4 waves: 1 per SIMD each)
+    assert 2 * alloc(match_vg) + 2 * alloc(oct_vg) <= 512
+    assert match_lds + 2 * (oct_lds + oct_dyn) <= 160 * 1024
+    # the match + four k_orient waves per SIMD (workgroups of 4 waves, 1 per SIMD: four workgroups)
+    assert 2 * alloc(match_vg) + 4 * alloc(ori_vg) <= 512
+    assert match_lds + 4 * ori_lds <= 160 * 1024
