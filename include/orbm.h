@@ -226,6 +226,32 @@ int orbm_search_by_projection_points_device(orbm_t *h, float nn_ratio, const uin
                                             const int32_t *d_cell_items, int grid_cols, int grid_rows, int n2, int list_cap,
                                             int32_t *d_frame_mp, int32_t *d_result, void *stream);
 
+/* SearchForInitialization (modules/ORB/ORBMatcher.cpp:33-116) on device-resident records: frame 1's key points / descriptors and
+ * frame 2's undistorted record + CSR grid as orbf_frame_post_device leaves it.  d_pre [n1][2] is vecPreMatched, in / out (:112-114);
+ * d_matches12 [n1] receives the matches (-1 = none).  The window lists (getFeaturesInArea(pre, windowSize, level1, level1) of the
+ * level-0 features), the order-dependent matching with its stealing rule (:63, :75-81), the rotation histogram -- robbed queries
+ * stay in it, as in the reference -- and ComputeThreeMaxima all run on the device; the result equals the host entry point's.
+ * Limits: n2 + 5 n1 <= 38400 (the claims live in LDS), list_cap entries per query on average (pool of n1 * list_cap).
+ * d_result (int32 x 8): [0] matches, [1] = 1 when the lists overflowed the pool (d_matches12 all -1, d_pre untouched: repeat with
+ * a larger list_cap or use the host entry point), [2] sweeps of the fixed point, [3] list entries.
+ * Enqueued on `stream` (NULL: orbx.h, "Streams"); one call in flight per handle. */
+int orbm_search_for_initialization_device(orbm_t *h, float nn_ratio, int check_orientation, const void *d_kps1, const uint8_t *d_desc1,
+                                          int n1, const void *d_kps2, const uint8_t *d_desc2, const int32_t *d_cell_start2,
+                                          const int32_t *d_cell_items2, int grid_cols, int grid_rows, int n2, float *d_pre,
+                                          int window_size, int list_cap, int32_t *d_matches12, int32_t *d_result, void *stream);
+
+/* The per-point search of the static fuse SearchByProjection(keyFrame, mapPoints, Map*, th) (ORBMatcher.cpp:556-575) on a
+ * device-resident key-frame record (key points, descriptors, CSR grid): KeyFrame::getFeaturesInArea(p, radius, predictLevel - 1,
+ * predictLevel) with its strict window test, the chi-square gate of :566-567 (d_sigma2 = the level table of square sigmas, indexed
+ * by the key point's octave) and the closest descriptor below TH_LOW + 1.  d_best_idx [nq] (-1 = none) / d_best_dist [nq]; what
+ * the reference does with a hit (:577-589) mutates its objects and stays with the caller (compat/ORBMatcher.h).
+ * d_result (int32 x 8): [0] points with a hit, [1] = 1 if a window held more than list_cap hits (that point's answer is then
+ * taken from the first list_cap: repeat with a larger list_cap).  Enqueued on `stream` (NULL: orbx.h, "Streams"). */
+int orbm_search_fuse_device(orbm_t *h, const uint8_t *d_q_desc, const float *d_q_xy, const float *d_q_radius, const int32_t *d_q_level,
+                            const uint8_t *d_q_ok, int nq, const void *d_kps, const uint8_t *d_desc, const int32_t *d_cell_start,
+                            const int32_t *d_cell_items, int grid_cols, int grid_rows, const float *d_sigma2, int list_cap,
+                            int32_t *d_best_idx, int32_t *d_best_dist, int32_t *d_result, void *stream);
+
 /* MapPoint::computeDescriptor (modules/BasicObject/MapPoint.cpp:103-152) for n_groups map points at once.
  * Group g = the descriptors desc[off[g] .. off[g+1]) of one point's observations (the caller skips bad key frames,
  * :115-120).  best_idx[g] = index inside the group of the descriptor with the least median Hamming distance to the

@@ -986,6 +986,139 @@ __global__ __launch_bounds__(PR_T) void k_projection_resolve(const int32_t *__re
         if (MODE == 1) { result[4] = s_n[1]; result[5] = s_n[2]; result[6] = s_n[3]; }
     }
 }
+// ---------------------------------------------------------------------------------------------
+// SearchForInitialization on the device (ORBMatcher.cpp:33-116).  The reference walks frame 1's level-0 features in order; a
+// feature skips every candidate that a feature BEFORE it matched at a distance <= its own (`matchedDistance[idx2] <= dist`, :63 --
+// for the best AND the second best), takes the closest of the rest if it passes TH_LOW and the ratio test, and STEALS the
+// candidate from whoever held it (:75-78); the loser is not tried again.  The same fixed point as k_projection_resolve: every
+// query holds a tentative (candidate, distance); a sweep recomputes all of them at once, query i seeing for candidate c
+// matchedDistance = the smallest distance among the queries j < i that currently claim c -- found by walking c's claimant
+// chain (head[c] -> next[j] -> ..., rebuilt every sweep with one atomic exchange per claimant; chains are a handful long).
+// Query 0 depends on nothing, query i is final one sweep after everything before it: a sweep that changes nothing is the
+// sequential result.  Then, as the reference: every ACCEPTED query entered the rotation histogram when it was accepted, also
+// the ones robbed later (:84-91: their entries stay and count in ComputeThreeMaxima); a candidate's last claimant holds it;
+// matches outside the three main bins go (:96-109); vecPreMatched takes the matched positions (:112-114).
+// result[0] = matches, [1] = 1 when the packed lists overflowed the pool (nothing written), [2] = sweeps, [3] = list entries.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_init_queries(const orbx_kp *__restrict__ kps1, int n1, float window, uint8_t *__restrict__ q_ok,
+                               float *__restrict__ q_r, int32_t *__restrict__ q_lv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    const int oct = kps1[i].octave;
+    q_ok[i] = oct <= 0;  // :48 `if (level1 > 0) continue`
+    q_r[i] = window;
+    q_lv[i] = oct;       // getFeaturesInArea(..., level1, level1) (:50-52)
+}
+__global__ __launch_bounds__(PR_T) void k_init_resolve(const int32_t *__restrict__ counts, const int32_t *__restrict__ offs,
+                                                       const uint32_t *__restrict__ pool, int pool_cap,
+                                                       const int32_t *__restrict__ total, int n1, int n2,
+                                                       const orbx_kp *__restrict__ kps1, const orbx_kp *__restrict__ kps2,
+                                                       float nn_ratio, int check_orientation, int32_t *__restrict__ matches12,
+                                                       float *__restrict__ pre, int32_t *__restrict__ result)
+{
+    extern __shared__ int32_t ir_lds[];
+    // head[n2]; next, the claims (a_c, a_d) and a sweep's new claims (n_c, n_d) [n1 each]
+    int32_t *head = ir_lds, *next = ir_lds + n2, *a_c = next + n1, *a_d = a_c + n1, *n_c = a_d + n1, *n_d = n_c + n1;
+    __shared__ int s_hist[ORBM_HISTO_LENGTH], s_keep[3], s_n;
+    const int tid = threadIdx.x;
+    const int tot = *total;
+    for (int i = tid; i < n1; i += PR_T) matches12[i] = -1; // :37
+    if (tot > pool_cap) {
+        if (tid == 0) { result[0] = 0; result[1] = 1; result[2] = 0; result[3] = tot; }
+        return;
+    }
+    for (int i = tid; i < n1; i += PR_T) { a_c[i] = -1; a_d[i] = 0; }
+    if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
+    if (tid == 0) s_n = 0;
+    auto choose = [&](int i, int *dist_out) -> int {
+        const int n = counts[i];
+        if (n <= 0) return -1;
+        const uint32_t *e = pool + offs[i];
+        int best = INT_MAX - 1, second = INT_MAX, idx = -1;
+        for (int t = 0; t < n; ++t) {
+            const int c = (int)(e[t] & 0x3FFFFFu), d = (int)(e[t] >> 22);
+            int md = INT_MAX; // matchedDistance[c] as query i finds it: the closest claim of a query before it
+            for (int j = head[c]; j >= 0; j = next[j])
+                if (j < i) md = min(md, a_d[j]);
+            if (md <= d) continue; // :63
+            if (d < best) { second = best; best = d; idx = c; }
+            else if (d < second) second = d;
+        }
+        *dist_out = best;
+        // :74 (second == INT_MAX: the product is 2.1e9 * ratio in float and cvRound saturates the way lrint does on the host)
+        return (best <= ORBM_TH_LOW && best < orb_round_f((float)second * nn_ratio)) ? idx : -1;
+    };
+    int sweeps = 0;
+    for (;;) {
+        __syncthreads();
+        for (int c = tid; c < n2; c += PR_T) head[c] = -1;
+        __syncthreads();
+        for (int i = tid; i < n1; i += PR_T)
+            if (a_c[i] >= 0) next[i] = atomicExch(&head[a_c[i]], i);
+        __syncthreads();
+        int changed = 0;
+        for (int i = tid; i < n1; i += PR_T) { // every query reads the OLD claims: the new ones become visible behind a barrier
+            int d = 0;
+            n_c[i] = choose(i, &d);
+            n_d[i] = d;
+        }
+        __syncthreads();
+        for (int i = tid; i < n1; i += PR_T)
+            if (n_c[i] != a_c[i] || (n_c[i] >= 0 && n_d[i] != a_d[i])) { a_c[i] = n_c[i]; a_d[i] = n_d[i]; changed = 1; }
+        ++sweeps;
+        if (!__syncthreads_or(changed) || sweeps > n1 + 1) break;
+    }
+    // (head / next of the last sweep belong to the stable claims)
+    // ---- rotation histogram of every accepted query (:84-91), then the holders: a candidate's LAST claimant (:75-81)
+    for (int i = tid; i < n1; i += PR_T) {
+        const int c = a_c[i];
+        if (c < 0) continue;
+        if (check_orientation) {
+            const float factor = 1.f / ORBM_HISTO_LENGTH;
+            float rot = ORB_FSUB(kps1[i].angle, kps2[c].angle);
+            if (rot < 0.f) rot = ORB_FADD(rot, 360.f);
+            int bin = orb_round_f(ORB_FMUL(rot, factor));
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            atomicAdd(&s_hist[bin], 1);
+        }
+    }
+    __syncthreads();
+    if (check_orientation && tid == 0) { // ComputeThreeMaxima (:594-622)
+        int max1 = 0, max2 = -1, max3 = -2, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < ORBM_HISTO_LENGTH; ++i) {
+            const int n = s_hist[i];
+            if (n > max1) { max3 = max2; max2 = max1; max1 = n; i3 = i2; i2 = i1; i1 = i; }
+            else if (n > max2) { max3 = max2; max2 = n; i3 = i2; i2 = i; }
+            else if (n > max3) { max3 = n; i3 = i; }
+        }
+        if (max2 < max1 / 10) { i2 = -1; i3 = -1; }
+        else if (max3 < max1 / 10) i3 = -1;
+        s_keep[0] = i1; s_keep[1] = i2; s_keep[2] = i3;
+    }
+    __syncthreads();
+    for (int i = tid; i < n1; i += PR_T) {
+        const int c = a_c[i];
+        if (c < 0) continue;
+        bool holds = true; // no later query claims c
+        for (int j = head[c]; j >= 0; j = next[j]) holds = holds && j <= i;
+        if (!holds) continue;
+        if (check_orientation) {
+            const float factor = 1.f / ORBM_HISTO_LENGTH;
+            float rot = ORB_FSUB(kps1[i].angle, kps2[c].angle);
+            if (rot < 0.f) rot = ORB_FADD(rot, 360.f);
+            int bin = orb_round_f(ORB_FMUL(rot, factor));
+            if (bin == ORBM_HISTO_LENGTH) bin = 0;
+            if (bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) continue; // :100-106
+        }
+        matches12[i] = c;
+        pre[2 * i] = kps2[c].x; pre[2 * i + 1] = kps2[c].y; // :112-114
+        atomicAdd(&s_n, 1);
+    }
+    __syncthreads();
+    if (tid == 0) { result[0] = s_n; result[1] = 0; result[2] = sweeps; result[3] = tot; }
+}
+
 // window levels of the two searches: octave - 1 .. octave + hi (:226-229 hi = 1, :367-369 hi = 0)
 __global__ void k_projection_levels(const int32_t *__restrict__ lv, int n, int hi, int32_t *__restrict__ lo_out, int32_t *__restrict__ hi_out)
 {
@@ -2268,6 +2401,104 @@ extern "C" int orbm_search_by_projection_points_device(orbm_t *c, float nn_ratio
 {
     return projection_device(c, 1, nn_ratio, 0, d_q_desc, d_q_xy, d_q_radius, d_q_level, nullptr, d_q_ok, nq, d_kps2, d_desc2,
                              d_cell_start, d_cell_items, grid_cols, grid_rows, n2, list_cap, d_frame_mp, d_result, stream);
+}
+
+// The static fuse's per-point search (ORBMatcher.cpp:556-575) on a device-resident key-frame record: the window lists with the
+// KeyFrame's strict window test and the chi-square gate (k_window_lists), then the closest hit of every list.  What the
+// reference does with the hit (:577-589: observations added, map points replaced) mutates its objects and stays with the caller.
+__global__ void k_fuse_levels(const int32_t *__restrict__ lv, int n, int32_t *__restrict__ lo) // predictLevel - 1 (:556)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lo[i] = lv[i] - 1;
+}
+__global__ __launch_bounds__(256) void k_fuse_best(const int32_t *__restrict__ counts, const uint32_t *__restrict__ lists, int cap, int nq,
+                                                   int32_t *__restrict__ best_idx, int32_t *__restrict__ best_dist,
+                                                   int32_t *__restrict__ result)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    int found = 0, over = 0;
+    if (q < nq) {
+        const int n = counts[q];
+        int bestDist = ORBM_TH_LOW + 1, bestIdx1 = -1; // :563
+        over = n > cap;
+        const uint32_t *e = lists + (size_t)q * cap;
+        for (int t = 0; t < min(n, cap); ++t) {
+            const int d = (int)(e[t] >> 22);
+            if (d < bestDist) { bestDist = d; bestIdx1 = (int)(e[t] & 0x3FFFFFu); } // :570-573, list order = the reference's
+        }
+        best_idx[q] = bestIdx1; best_dist[q] = bestDist;
+        found = bestIdx1 != -1;
+    }
+    const int f = __syncthreads_count(found), o = __syncthreads_or(over);
+    if (threadIdx.x == 0) {
+        if (f) atomicAdd(&result[0], f);
+        if (o) atomicExch(&result[1], 1);
+    }
+}
+extern "C" int orbm_search_fuse_device(orbm_t *c, const uint8_t *d_q_desc, const float *d_q_xy, const float *d_q_radius,
+                                       const int32_t *d_q_level, const uint8_t *d_q_ok, int nq, const void *d_kps, const uint8_t *d_desc,
+                                       const int32_t *d_cell_start, const int32_t *d_cell_items, int grid_cols, int grid_rows,
+                                       const float *d_sigma2, int list_cap, int32_t *d_best_idx, int32_t *d_best_dist,
+                                       int32_t *d_result, void *stream)
+{
+    if (!c || !d_q_desc || !d_q_xy || !d_q_radius || !d_q_level || !d_q_ok || !d_kps || !d_desc || !d_cell_start || !d_cell_items ||
+        !d_sigma2 || !d_best_idx || !d_best_dist || !d_result || grid_cols < 1 || grid_rows < 1 || nq < 0 || list_cap < 1)
+        return orbx_set_error(ORBX_E_ARG, "bad argument");
+    M_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    if (!stream) c->null_pending = true;
+    M_TRY(hipMemsetAsync(d_result, 0, 32, s));
+    if (nq == 0) return ORBX_OK;
+    // scratch: [counts nq][lo nq][lists nq * list_cap]
+    const size_t N = (size_t)nq;
+    M_TRY(c->w_out.need(N * 8 + N * list_cap * 4 + 16));
+    int32_t *d_counts = (int32_t *)c->w_out.p, *d_lo = d_counts + N;
+    uint32_t *d_lists = (uint32_t *)(d_lo + N);
+    hipLaunchKernelGGL(k_fuse_levels, dim3((nq + 255) / 256), dim3(256), 0, s, d_q_level, nq, d_lo);
+    hipLaunchKernelGGL(k_window_lists, dim3((nq + 3) / 4), dim3(256), 0, s, (const orbx_kp *)d_kps, d_desc, d_cell_start, d_cell_items,
+                       grid_cols, grid_rows, d_q_desc, d_q_xy, d_q_radius, d_lo, d_q_level, d_q_ok, nq, 1, d_sigma2, list_cap, d_counts,
+                       d_lists, nullptr, nullptr);
+    hipLaunchKernelGGL(k_fuse_best, dim3((nq + 255) / 256), dim3(256), 0, s, d_counts, d_lists, list_cap, nq, d_best_idx, d_best_dist, d_result);
+    M_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+
+// SearchForInitialization on device-resident records (include/orbm.h)
+extern "C" int orbm_search_for_initialization_device(orbm_t *c, float nn_ratio, int check_orientation, const void *d_kps1,
+                                                     const uint8_t *d_desc1, int n1, const void *d_kps2, const uint8_t *d_desc2,
+                                                     const int32_t *d_cell_start2, const int32_t *d_cell_items2, int grid_cols,
+                                                     int grid_rows, int n2, float *d_pre, int window_size, int list_cap,
+                                                     int32_t *d_matches12, int32_t *d_result, void *stream)
+{
+    if (!c || !d_kps1 || !d_desc1 || !d_kps2 || !d_desc2 || !d_cell_start2 || !d_cell_items2 || !d_pre || !d_matches12 || !d_result ||
+        grid_cols < 1 || grid_rows < 1 || n1 < 0 || n2 < 0 || list_cap < 1 || window_size < 0)
+        return orbx_set_error(ORBX_E_ARG, "bad argument");
+    if (n2 >= (1 << 22)) return orbx_set_error(ORBX_E_UNSUPPORTED, "more than 2^22 key points");
+    const size_t lds = ((size_t)n2 + 5 * (size_t)n1) * 4;
+    if (lds > 150 * 1024) return orbx_set_error(ORBX_E_UNSUPPORTED, "n2 + 5 n1 above 38400: the resolve keeps the claims in LDS");
+    M_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    if (!stream) c->null_pending = true;
+    M_TRY(hipMemsetAsync(d_result, 0, 32, s));
+    if (n1 == 0) return ORBX_OK;
+    if (n2 == 0) { M_TRY(hipMemsetAsync(d_matches12, 0xFF, sizeof(int32_t) * (size_t)n1, s)); return ORBX_OK; }
+    // scratch: [total, pad x3][counts n1][offs n1][level n1][radius n1][ok n1 bytes, padded][pool n1 * list_cap]
+    const size_t pool_cap = (size_t)n1 * list_cap, N = (size_t)n1, okb = (N + 15) / 16 * 16;
+    M_TRY(c->w_out.need(16 + N * 16 + okb + pool_cap * 4 + 16));
+    int32_t *d_total = (int32_t *)c->w_out.p, *d_counts = d_total + 4, *d_offs = d_counts + N, *d_lv = d_offs + N;
+    float *d_r = (float *)(d_lv + N);
+    uint8_t *d_ok = (uint8_t *)(d_r + N);
+    uint32_t *d_pool = (uint32_t *)(d_ok + okb);
+    M_TRY(hipMemsetAsync(d_total, 0, 16, s));
+    hipLaunchKernelGGL(k_init_queries, dim3((n1 + 255) / 256), dim3(256), 0, s, (const orbx_kp *)d_kps1, n1, (float)window_size, d_ok, d_r, d_lv);
+    hipLaunchKernelGGL(k_window_lists, dim3((n1 + 3) / 4), dim3(256), 0, s, (const orbx_kp *)d_kps2, d_desc2, d_cell_start2, d_cell_items2,
+                       grid_cols, grid_rows, d_desc1, d_pre, d_r, d_lv, d_lv, d_ok, n1, 0, nullptr, (int)std::min(pool_cap, (size_t)INT_MAX),
+                       d_counts, d_pool, d_total, d_offs);
+    M_TRY(orbx_lds_opt_in(reinterpret_cast<const void *>(k_init_resolve), 150 * 1024));
+    hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(PR_T), lds, s, d_counts, d_offs, d_pool, (int)std::min(pool_cap, (size_t)INT_MAX), d_total,
+                       n1, n2, (const orbx_kp *)d_kps1, (const orbx_kp *)d_kps2, nn_ratio, check_orientation, d_matches12, d_pre, d_result);
+    M_TRY(hipGetLastError());
+    return ORBX_OK;
 }
 
 // The window lists of one device-resident frame record (orbx_extract_batch_device -> orbf_frame_post_device): the grid

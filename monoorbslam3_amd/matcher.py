@@ -57,6 +57,9 @@ def _mlib():
             "orbm_search_by_projection_points_device": (i32, [vp, f32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32,
                                                               vp, vp, vp]),
             "orbm_search_by_bow_device": (i32, [vp, f32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+            "orbm_search_for_initialization_device": (i32, [vp, f32, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, i32,
+                                                            vp, vp, vp]),
+            "orbm_search_fuse_device": (i32, [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp]),
             "orbm_search_for_triangulation_device": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp,
                                                            vp, vp]),
             "orbm_window_lists_device": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]),
@@ -292,7 +295,25 @@ class ORBMatcher:
                 self._hd._h, self.nn_ratio, p("q_desc"), p("q_xy"), p("q_radius"), p("q_level"), p("q_ok"), nq, p("kps2"),
                 p("desc2"), p("cell_start"), p("cell_items"), grid_cols, grid_rows, n2, list_cap, p("frame_mp"), p("result"), st))
 
+    def SearchForInitializationDevice(self, d, n1, n2, grid_cols, grid_rows, window=100, list_cap=768, stream=None):
+        """orbm_search_for_initialization_device on torch device tensors: d = dict(kps1, desc1, kps2 (frame 2's record as
+        orbf_frame_post_device leaves it), desc2, cell_start, cell_items, pre (float32 [n1, 2], in / out), matches12 (int32 [n1], out),
+        result (int32 x 8, out))."""
+        p = lambda k: d[k].data_ptr()  # noqa: E731
+        _lib.check(self._L.orbm_search_for_initialization_device(
+            self._hd._h, self.nn_ratio, int(self.be_check_orientation), p("kps1"), p("desc1"), n1, p("kps2"), p("desc2"),
+            p("cell_start"), p("cell_items"), grid_cols, grid_rows, n2, p("pre"), window, list_cap, p("matches12"), p("result"),
+            _lib.stream_arg(stream)))
+
     # -- static SearchByProjection(keyFrame, mapPoints, Map*, th): the fuse (ORBMatcher.cpp:524-592) ------------
+    def SearchFuseDevice(self, d, nq, grid_cols, grid_rows, list_cap=48, stream=None):
+        """orbm_search_fuse_device on torch device tensors: d = dict(q_desc, q_xy, q_radius, q_level, q_ok, kps, desc, cell_start,
+        cell_items, sigma2, best_idx (int32 [nq], out), best_dist (int32 [nq], out), result (int32 x 8, out))."""
+        p = lambda k: d[k].data_ptr()  # noqa: E731
+        _lib.check(self._L.orbm_search_fuse_device(
+            self._hd._h, p("q_desc"), p("q_xy"), p("q_radius"), p("q_level"), p("q_ok"), nq, p("kps"), p("desc"), p("cell_start"),
+            p("cell_items"), grid_cols, grid_rows, p("sigma2"), list_cap, p("best_idx"), p("best_dist"), p("result"), _lib.stream_arg(stream)))
+
     def SearchByBowDevice(self, d, n1, n2, stream=None):
         """orbm_search_by_bow_device on torch device tensors: d = dict(desc1, kps1 (orbx_kp records), kf_mp_ok, fv1=(nodes, off, idx, n), desc2, kps2,
         frame_mp (in / out), fv2=(nodes, off, idx, n), result (int32 x 8))."""

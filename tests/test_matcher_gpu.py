@@ -197,6 +197,70 @@ def test_search_for_initialization_on_extracted_frames(oracle_mod):
         assert n_got > 50
 
 
+@pytest.mark.parametrize("ori", [True, False])
+def test_search_for_initialization_on_the_device(oracle_mod, ori):
+    """orbm_search_for_initialization_device (ORBMatcher.cpp:33-116 with the window lists, the stealing rule of :63 / :75-81, the
+    rotation histogram that keeps robbed queries, ComputeThreeMaxima and the vecPreMatched update on the device): matches12, the
+    count and the updated pre-matches equal the oracle's sequential loop and the host entry point -- on two extracted views, and on a
+    crowded synthetic scene (near-duplicate descriptors in a small area: many features want the same candidate, several are robbed,
+    the fixed point needs more than two sweeps)."""
+    import torch
+    from monoorbslam3_amd.extractor import ORBExtractor, KP_DTYPE
+    from monoorbslam3_amd.frame import FramePost
+    from monoorbslam3_amd.matcher import ORBMatcher
+    dev = torch.device("cuda", 0)
+    w, h = 752, 480
+    canvas = synth.make_canvas(w + 40, h + 20, seed=77)
+    f1 = np.ascontiguousarray(canvas[5:5 + h, 10:10 + w])
+    f2 = np.ascontiguousarray(canvas[9:9 + h, 22:22 + w])
+    ex = ORBExtractor(2000, 1.2, 8, 20, 7)
+    cases = [("views",) + ex(f1) + ex(f2)]
+    # crowded: 900 level-0 features of either frame inside a 260 x 200 px area, descriptors from 40 clusters with a few flipped bits
+    rng = np.random.RandomState(2026)
+    centres = rng.randint(0, 256, (40, 32)).astype(np.uint8)
+    def crowd(n, seed):
+        r = np.random.RandomState(seed)
+        k = np.zeros(n, KP_DTYPE)
+        k["x"] = r.uniform(200, 460, n).astype(np.float32); k["y"] = r.uniform(100, 300, n).astype(np.float32)
+        k["size"] = 1.0; k["angle"] = (r.normal(40, 25, n) % 360).astype(np.float32); k["octave"] = (r.uniform(size=n) > 0.85).astype(np.int32)
+        k["class_id"] = -1
+        d = centres[r.randint(0, 40, n)] ^ np.packbits(r.uniform(size=(n, 256)) < 0.03, axis=1, bitorder="little")
+        return k, d.astype(np.uint8)
+    cases.append(("crowded",) + crowd(900, 1) + crowd(850, 2))
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kp = lambda k: torch.from_numpy(np.frombuffer(np.ascontiguousarray(k).tobytes(), np.uint8).copy()).to(dev)  # noqa: E731
+    post = FramePost(w, h, 460.0, 460.0, w / 2.0, h / 2.0)
+    m = ORBMatcher(0.9, ori)
+    for name, k1, d1, k2, d2 in cases:
+        n1, n2 = len(k1), len(k2)
+        pre = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+        n_ref, m_ref, pre_ref = oracle_mod.search_for_initialization(0.9, ori, k1, d1, k2, d2, w, h, pre, 100)
+        n_host, m_host, pre_host = m.SearchForInitialization(k1, d1, k2, d2, w, h, pre, 100)
+        _, k2u, start, items = post(k2)
+        assert k2u.tobytes() == np.ascontiguousarray(k2).tobytes()   # no distortion: the record IS the key points
+        d = dict(kps1=kp(k1), desc1=up(d1), kps2=kp(k2u), desc2=up(d2), cell_start=up(start.astype(np.int32)),
+                 cell_items=up(np.concatenate([items, np.zeros(1, items.dtype)]).astype(np.int32)), pre=up(pre),
+                 matches12=torch.full((n1,), 7, dtype=torch.int32, device=dev), result=torch.zeros(8, dtype=torch.int32, device=dev))
+        m.SearchForInitializationDevice(d, n1, n2, post.cols, post.rows, window=100, list_cap=1024)
+        res = d["result"].cpu().numpy()
+        print(name, "device result", res.tolist(), "oracle", n_ref, "host", n_host)
+        assert res[1] == 0 and res[0] == n_ref == n_host, (name, res, n_ref, n_host)
+        assert np.array_equal(d["matches12"].cpu().numpy(), m_ref) and np.array_equal(m_host, m_ref), name
+        assert np.array_equal(d["pre"].cpu().numpy(), pre_ref) and np.array_equal(pre_host, pre_ref), name
+        assert n_ref > 50
+        if name == "crowded":
+            assert res[2] > 2   # the fixed point had chains to follow
+        # a pool too small for the lists: reported, matches12 all -1, pre untouched
+        d["pre"].copy_(up(pre)); d["matches12"].fill_(7)
+        m.SearchForInitializationDevice(d, n1, n2, post.cols, post.rows, window=100, list_cap=2)
+        res = d["result"].cpu().numpy()
+        assert res[1] == 1 and res[0] == 0 and (d["matches12"].cpu().numpy() == -1).all() and np.array_equal(d["pre"].cpu().numpy(), pre)
+    # nothing to match against
+    d["matches12"].fill_(7)
+    m.SearchForInitializationDevice(d, n1, 0, post.cols, post.rows)
+    assert (d["matches12"].cpu().numpy() == -1).all() and int(d["result"][0]) == 0
+
+
 def _two_views(w=752, h=480, nf=2000):
     from monoorbslam3_amd.extractor import ORBExtractor
     canvas = synth.make_canvas(w + 40, h + 20, seed=909)
@@ -569,6 +633,26 @@ def test_search_fuse(oracle_mod):
     # without candidates / without key points
     e_bi, e_bd, e_n = m.SearchFuse(q_desc[:3], q_xy[:3], q_radius[:3], q_level[:3], np.zeros(3, np.uint8), k1, d1, w, h, sigma2)
     assert e_n == 0 and (e_bi == -1).all()
+    # ---- the same search on a device-resident key-frame record (orbm_search_fuse_device): the KeyFrame's grid as orbf builds it
+    import torch
+    from monoorbslam3_amd.frame import FramePost
+    dev = torch.device("cuda", 0)
+    post = FramePost(w, h, 460.0, 460.0, w / 2.0, h / 2.0)
+    _, k1u, start, items = post(k1)
+    assert k1u.tobytes() == np.ascontiguousarray(k1).tobytes()
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    nq = len(q_desc)
+    d = dict(q_desc=up(q_desc), q_xy=up(q_xy), q_radius=up(q_radius), q_level=up(q_level), q_ok=up(q_ok),
+             kps=torch.from_numpy(np.frombuffer(np.ascontiguousarray(k1).tobytes(), np.uint8).copy()).to(dev), desc=up(d1),
+             cell_start=up(start.astype(np.int32)), cell_items=up(np.concatenate([items, np.zeros(1, items.dtype)]).astype(np.int32)),
+             sigma2=up(sigma2), best_idx=torch.full((nq,), 9, dtype=torch.int32, device=dev),
+             best_dist=torch.full((nq,), 9, dtype=torch.int32, device=dev), result=torch.zeros(8, dtype=torch.int32, device=dev))
+    m.SearchFuseDevice(d, nq, post.cols, post.rows, list_cap=48)
+    res = d["result"].cpu().numpy()
+    assert res[1] == 0 and res[0] == r_n
+    assert np.array_equal(d["best_idx"].cpu().numpy(), r_bi) and np.array_equal(d["best_dist"].cpu().numpy(), r_bd)
+    m.SearchFuseDevice(d, nq, post.cols, post.rows, list_cap=1)   # windows with more than one hit: reported
+    assert d["result"].cpu().numpy()[1] == 1
 
 
 def test_window_lists_on_a_device_resident_frame_record(oracle_mod):
