@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--match-placement", default=None, choices=["after-fast", "eager"],
                     help="when the match of a batch starts: behind the next batch's FAST stage (orbx_stream_wait_fast), beside its "
                          "latency-bound quadtree / k_desc_bins / orientation (default; with --best2-resident 1: 2.18 ms per step, "
-                         "two kernels in flight 35-38 %% of the step), or as soon as its own batch is extracted, beside the next "
+                         "two kernels in flight 33-38 %% of the step), or as soon as its own batch is extracted, beside the next "
                          "batch's pyramid (eager: 2.33 ms; profiles/r05_overlap.md).  One frame per step (config 4) always takes eager: "
                          "its match reads the previous step's records, which the next extraction overwrites")
     ap.add_argument("--records", action="store_true",
