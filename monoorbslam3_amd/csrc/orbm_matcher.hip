@@ -1207,9 +1207,11 @@ __global__ __launch_bounds__(BQ_T) void k_bow_queries(BowFv f1, BowFv f2, const 
     int too_big = 0;
     for (int p1 = tid; p1 < nn1; p1 += BQ_T) {
         const int p2 = node_p2[p1];
-        if (p2 < 0) continue;
+        if (p2 < 0 || f1.off[p1 + 1] <= f1.off[p1]) continue; // (a node without entries has no query and no first-query index)
         const int qb = node_qbegin[p1];
-        const int qe = min(p1 + 1 < nn1 ? node_qbegin[p1 + 1] : total, total);
+        int nx = p1 + 1; // the next node that has entries: its first query ends this node's
+        while (nx < nn1 && f1.off[nx + 1] <= f1.off[nx]) ++nx;
+        const int qe = min(nx < nn1 ? node_qbegin[nx] : total, total);
         if (qe - qb > BR_MAX_NODE || f2.off[p2 + 1] - f2.off[p2] > BR_MAX_NODE) too_big = 1;
     }
     too_big = __syncthreads_or(too_big);
