@@ -308,8 +308,9 @@ def main():
                    cell_items=z((B, cap), torch.int32), bow_ids=z((B, cap), torch.int32), bow_vals=z((B, cap), torch.float64),
                    n_words=z((B,), torch.int32), fv_nodes=z((B, cap), torch.int32), fv_off=z((B, cap + 1), torch.int32),
                    fv_idx=z((B, cap), torch.int32), n_fv=z((B,), torch.int32))
-    # dedicated non-default streams: the C ABI treats a NULL stream as "the handle's own stream", and the RCCL
-    # gather below must be ordered behind the kernels it depends on
+    # dedicated non-blocking streams: the extraction and the match overlap only on streams of their own (a NULL stream is the
+    # legacy stream 0 itself for every device entry point, include/orbx.h "Streams"), and the RCCL gather below must be
+    # ordered behind the kernels it depends on
     torch.cuda.synchronize()
     side = torch.cuda.Stream(device=dev)
     mstream = torch.cuda.Stream(device=dev)

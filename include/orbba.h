@@ -14,6 +14,10 @@
  * of g2o 20201223's OptimizationAlgorithmLevenberg + BlockSolver_6_3 (not vendored in the reference; restated from
  * its published sources, checked against the numpy restatement in oracle/ba_ref.py to a stated tolerance).
  * Everything is IEEE double.  Host pointers in and out.
+ * Threads (orbx.h, "Streams and threads"): the entry points take no handle and are re-entrant.  The reference runs poseOptimize
+ * on the Tracking thread (Tracking.cpp:273-358) while localBundleAdjustment runs on LocalMapping's (LocalMapping.cpp:45-52): every
+ * host-pointer call leases a non-blocking stream, a device arena and a page-locked staging block from a per-device pool for its
+ * duration -- one copy up, one copy down, one small read-back per LM trial; no stream-0 operation, no allocation in steady state.
  */
 #ifndef ORBBA_H
 #define ORBBA_H

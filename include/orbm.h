@@ -12,10 +12,10 @@
  * reference's Frame/KeyFrame types onto these plain-array entry points.
  *
  * Returns 0 or a negative ORBX_E_* code (orbx.h); text in orbx_last_error().
- * All entry points are re-entrant: a handle owns its stream and scratch, and the
- * reference calls SearchForTriangulation from the LocalMapping thread while
- * Tracking calls SearchByBow (LocalMapping.cpp:168, Tracking.cpp:262) -- use one
- * handle per thread.
+ * All entry points are re-entrant: a handle owns its (non-blocking) stream and scratch, and the
+ * reference calls SearchForTriangulation and the fuse from the LocalMapping thread while
+ * Tracking calls SearchByBow / SearchByProjection (LocalMapping.cpp:168, 282, 301; Tracking.cpp:262, 289) -- use one
+ * handle per thread; handles never wait for each other (orbx.h, "Streams and threads"; tests/cpp/two_threads.cpp).
  */
 #ifndef ORBM_H
 #define ORBM_H

@@ -12,8 +12,11 @@
  * outputs are the two std::maps flattened in key order -- the FeatureVector in exactly the CSR form orbm_fv takes.
  *
  * Returns 0 or a negative ORBX_E_* code (orbx.h); text in orbx_last_error().
- * The tree is read-only and shared, but a handle's per-feature scratch is not: keep the transform calls of one handle on
- * one stream (they are then ordered); orbv_transform_features_device uses no scratch and may run anywhere.
+ * Threads (orbx.h, "Streams and threads"): the reference's vocabulary is ONE object that Tracking (Frame.cpp:168-178) and
+ * LocalMapping (LocalMapping.cpp:90) call at the same time.  The tree is read-only; orbv_transform (host pointers) leases a
+ * stream, scratch and staging of its own per call, so it is RE-ENTRANT on one shared handle (tests/cpp/two_threads.cpp).  The
+ * *_device entry points use the handle's one per-feature scratch: keep the device transform calls of one handle on one stream
+ * (they are then ordered); orbv_transform_features_device uses no scratch and may run anywhere.
  */
 #ifndef ORBV_H
 #define ORBV_H

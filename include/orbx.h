@@ -12,16 +12,26 @@
  * There is no CPU fallback: without a HIP device the calls fail with
  * ORBX_E_NO_DEVICE.
  *
- * Streams -- ONE rule for every `void *stream` argument of orbx.h, orbm.h, orbf.h, orbv.h, orbba.h and orbd.h:
- * it is a hipStream_t, and NULL means "ordered with the legacy default stream", exactly as a NULL stream does in the HIP
- * runtime itself.  An entry point that takes a handle runs a NULL-stream call on the handle's own stream, which is created
- * BLOCKING (hipStreamDefault): it waits for everything enqueued earlier on the null stream (hipMemcpy, kernels launched
- * with stream 0, torch's default stream) and null-stream work enqueued after the call waits for it.  An entry point without
- * a handle (orbba_*_device, orbd_*) runs a NULL-stream call on stream 0 itself.  Either way a caller that fills its device
- * buffers on the null stream, calls with NULL and reads the results on the null stream needs no synchronisation of its own
- * (tests/cpp/null_stream.cpp).  A caller that works on a NON-BLOCKING stream of its own (hipStreamNonBlocking, any
- * torch.cuda.Stream) passes that stream: nothing orders a non-blocking stream with NULL.  The library's internal side
- * streams are forked from and joined into the stream of the call with events; the caller sees one in-order stream.
+ * Streams and threads -- ONE rule for every entry point of orbx.h, orbm.h, orbf.h, orbv.h, orbba.h and orbd.h:
+ *  (1) A `*_device` entry point (device pointers, a `void *stream` argument) enqueues on exactly the stream it is given.  The
+ *      argument is a hipStream_t, and NULL is the legacy default stream (stream 0) ITSELF, as in the HIP runtime, with or without
+ *      a handle.  A caller that fills its device buffers on the null stream (hipMemcpy, kernels on stream 0, torch's default
+ *      stream), calls with NULL and reads the results on the null stream needs no synchronisation of its own
+ *      (tests/cpp/null_stream.cpp); a caller that works on a NON-BLOCKING stream (hipStreamNonBlocking, any torch.cuda.Stream)
+ *      passes that stream.  No device entry point waits on the host (first use and growth of a handle's scratch excepted).  The
+ *      call uses the handle's scratch: one device call in flight per handle.
+ *  (2) A host-pointer entry point (host arrays in and out, no stream argument) is synchronous: it uploads, computes, downloads
+ *      and waits on a stream the library owns -- the handle's own, or one leased for the call by the handle-less orbba_* entry
+ *      points and by orbv_transform -- and that stream is NON-BLOCKING: it is ordered neither with stream 0 nor with any other
+ *      handle, and steady-state calls neither allocate nor touch the legacy stream.  So two host threads that work through
+ *      handles of their own never wait for each other on the device -- the reference's Tracking and LocalMapping threads
+ *      (System.cpp:55; LocalMapping.cpp:45-52, 168, 282, 301), tests/cpp/two_threads.cpp.  The one coupling the library adds
+ *      itself: a host-pointer call on a handle whose NULL-stream device call may still be in flight first waits for stream 0.
+ *  A handle is single-threaded (one call at a time); handles are independent of each other; orbv_transform on ONE shared
+ *  vocabulary handle is re-entrant (the reference's vocabulary is a singleton both threads use).  Stream 0 is a process-wide
+ *  resource: NULL-stream device calls of two threads are serialised by the runtime as any legacy-stream work is, so a second
+ *  thread that wants device entry points passes a stream of its own.  The library's internal side streams are forked from and
+ *  joined into the stream of the call with events; the caller sees one in-order stream.
  */
 #ifndef ORBX_H
 #define ORBX_H

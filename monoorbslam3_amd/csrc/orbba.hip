@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -225,12 +226,84 @@ __global__ __launch_bounds__(256) void k_ba_reduce_point(int n_points, const int
 }
 
 namespace {
-struct Dev {
-    void *p = nullptr;
-    ~Dev() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max(bytes, (size_t)8)); }
-    template <typename T> T *as() { return reinterpret_cast<T *>(p); }
+// The device side of one host-pointer call.  The BA entry points take no handle and run on two of the reference's threads
+// (poseOptimize on Tracking, Tracking.cpp:273-358; localBundleAdjustment on LocalMapping, LocalMapping.cpp:45-52), so a call
+// leases a workspace for its duration: a NON-BLOCKING stream, one device arena, one page-locked staging block and two events,
+// pooled per device.  Concurrent calls never share a stream or scratch, none of them touches stream 0 (include/orbx.h,
+// "Streams": a legacy-stream operation is a barrier against every blocking stream of every thread), and a steady-state call
+// allocates nothing (hipMalloc / hipFree wait for the whole device).  Inputs go up in ONE copy from the staging block, results
+// come back in one, and the LM loop reads one small block per trial.
+struct BaWork {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    uint8_t *d = nullptr, *h = nullptr;
+    size_t d_bytes = 0, h_bytes = 0;
+    hipError_t need(size_t dev_bytes, size_t host_bytes)
+    {
+        hipError_t e = hipSuccess;
+        if (dev_bytes > d_bytes) {
+            if (d) (void)hipFree(d);
+            d = nullptr; d_bytes = 0;
+            const size_t want = dev_bytes + dev_bytes / 4;
+            if ((e = hipMalloc((void **)&d, want)) != hipSuccess) return e;
+            d_bytes = want;
+        }
+        if (host_bytes > h_bytes) {
+            if (h) (void)hipHostFree(h);
+            h = nullptr; h_bytes = 0;
+            const size_t want = host_bytes + host_bytes / 4;
+            if ((e = hipHostMalloc((void **)&h, want, hipHostMallocDefault)) != hipSuccess) return e;
+            h_bytes = want;
+        }
+        return e;
+    }
 };
+std::mutex g_work_mu;
+std::vector<BaWork *> g_work_idle; // never destroyed: the HIP runtime may be gone when static destructors run
+
+struct BaLease {
+    BaWork *w = nullptr;
+    ~BaLease()
+    {
+        if (!w) return;
+        (void)hipStreamSynchronize(w->stream); // an error return may leave work in flight: the next lessee must not meet it
+        std::lock_guard<std::mutex> lock(g_work_mu);
+        g_work_idle.push_back(w);
+    }
+    hipError_t acquire()
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        {
+            std::lock_guard<std::mutex> lock(g_work_mu);
+            for (size_t i = 0; i < g_work_idle.size(); ++i)
+                if (g_work_idle[i]->device == dev) {
+                    w = g_work_idle[i];
+                    g_work_idle.erase(g_work_idle.begin() + (long)i);
+                    return hipSuccess;
+                }
+        }
+        BaWork *n = new BaWork();
+        n->device = dev;
+        if ((e = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreate(&n->e0)) != hipSuccess ||
+            (e = hipEventCreate(&n->e1)) != hipSuccess) {
+            if (n->e0) (void)hipEventDestroy(n->e0);
+            if (n->stream) (void)hipStreamDestroy(n->stream);
+            delete n;
+            return e;
+        }
+        w = n;
+        return hipSuccess;
+    }
+};
+// offsets of a call's arrays in the arena (and, for the staged ones, in the page-locked block), 256-byte aligned
+struct Layout {
+    size_t n = 0;
+    size_t add(size_t bytes) { const size_t o = n; n += (bytes + 255) & ~(size_t)255; return o; }
+};
+inline void put(uint8_t *base, size_t off, const void *src, size_t bytes) { if (bytes) memcpy(base + off, src, bytes); }
 } // namespace
 
 extern "C" int orbba_linearize(const orbba_problem *p, orbba_result *r, int device)
@@ -259,54 +332,57 @@ extern "C" int orbba_linearize(const orbba_problem *p, orbba_result *r, int devi
         std::vector<int> fill(pose_off.begin(), pose_off.end() - 1);
         for (int e = 0; e < NE; ++e) pose_edges[fill[p->edge_pose[e]]++] = e;
     }
-    Dev dR, dt, dfix, dP, dep, del, dz, dw, dchi, derr, dHlp, dCpp, dCll, dpo, dpe, dlo, dHpp, dbp, dHll, dbl;
-    B_TRY(dR.alloc(sizeof(double) * 9 * NP)); B_TRY(dt.alloc(sizeof(double) * 3 * NP)); B_TRY(dfix.alloc(NP));
-    B_TRY(dP.alloc(sizeof(double) * 3 * NL)); B_TRY(dep.alloc(sizeof(int) * NE)); B_TRY(del.alloc(sizeof(int) * NE));
-    B_TRY(dz.alloc(sizeof(double) * 2 * NE)); B_TRY(dw.alloc(sizeof(double) * NE)); B_TRY(dchi.alloc(sizeof(double) * NE));
-    B_TRY(derr.alloc(sizeof(double) * 2 * NE)); B_TRY(dHlp.alloc(sizeof(double) * 18 * NE));
-    B_TRY(dCpp.alloc(sizeof(double) * 27 * NE)); B_TRY(dCll.alloc(sizeof(double) * 9 * NE));
-    B_TRY(dpo.alloc(sizeof(int) * (NP + 1))); B_TRY(dpe.alloc(sizeof(int) * std::max(NE, 1))); B_TRY(dlo.alloc(sizeof(int) * (NL + 1)));
-    B_TRY(dHpp.alloc(sizeof(double) * 36 * NP)); B_TRY(dbp.alloc(sizeof(double) * 6 * NP));
-    B_TRY(dHll.alloc(sizeof(double) * 9 * NL)); B_TRY(dbl.alloc(sizeof(double) * 3 * NL));
-    B_TRY(hipMemcpy(dR.p, p->pose_R, sizeof(double) * 9 * NP, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dt.p, p->pose_t, sizeof(double) * 3 * NP, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dfix.p, p->pose_fixed, NP, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dP.p, p->points, sizeof(double) * 3 * NL, hipMemcpyHostToDevice));
+    // arena: [inputs, one copy up][edge-major scratch][outputs, one copy down: the small blocks first, H_lp last]
+    Layout L;
+    const size_t oR = L.add(72 * (size_t)NP), ot = L.add(24 * (size_t)NP), ofix = L.add(NP), oP = L.add(24 * (size_t)NL),
+                 oep = L.add(4 * (size_t)NE), oel = L.add(4 * (size_t)NE), oz = L.add(16 * (size_t)NE), ow = L.add(8 * (size_t)NE),
+                 ope = L.add(4 * (size_t)NE), opo = L.add(4 * (size_t)(NP + 1)), olo = L.add(4 * (size_t)(NL + 1));
+    const size_t in_bytes = L.n;
+    const size_t oCpp = L.add(216 * (size_t)NE), oCll = L.add(72 * (size_t)NE);
+    const size_t out_begin = L.n;
+    const size_t oHpp = L.add(288 * (size_t)NP), obp = L.add(48 * (size_t)NP), oHll = L.add(72 * (size_t)NL), obl = L.add(24 * (size_t)NL),
+                 ochi = L.add(8 * (size_t)NE), oerr = L.add(16 * (size_t)NE);
+    const size_t out_small_end = L.n;
+    const size_t oHlp = L.add(144 * (size_t)NE);
+    const size_t out_end = (r->H_lp && NE) ? L.n : out_small_end;
+    BaLease lease;
+    B_TRY(lease.acquire());
+    BaWork *w = lease.w;
+    B_TRY(w->need(L.n, std::max(in_bytes, out_end - out_begin)));
+    hipStream_t s = w->stream;
+    uint8_t *d = w->d, *h = w->h;
+    put(h, oR, p->pose_R, 72 * (size_t)NP); put(h, ot, p->pose_t, 24 * (size_t)NP); put(h, ofix, p->pose_fixed, NP);
+    put(h, oP, p->points, 24 * (size_t)NL);
     if (NE) {
-        B_TRY(hipMemcpy(dep.p, p->edge_pose, sizeof(int) * NE, hipMemcpyHostToDevice));
-        B_TRY(hipMemcpy(del.p, p->edge_point, sizeof(int) * NE, hipMemcpyHostToDevice));
-        B_TRY(hipMemcpy(dz.p, p->edge_z, sizeof(double) * 2 * NE, hipMemcpyHostToDevice));
-        B_TRY(hipMemcpy(dw.p, p->edge_inv_sigma2, sizeof(double) * NE, hipMemcpyHostToDevice));
-        B_TRY(hipMemcpy(dpe.p, pose_edges.data(), sizeof(int) * NE, hipMemcpyHostToDevice));
+        put(h, oep, p->edge_pose, 4 * (size_t)NE); put(h, oel, p->edge_point, 4 * (size_t)NE); put(h, oz, p->edge_z, 16 * (size_t)NE);
+        put(h, ow, p->edge_inv_sigma2, 8 * (size_t)NE); put(h, ope, pose_edges.data(), 4 * (size_t)NE);
     }
-    B_TRY(hipMemcpy(dpo.p, pose_off.data(), sizeof(int) * (NP + 1), hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dlo.p, point_off.data(), sizeof(int) * (NL + 1), hipMemcpyHostToDevice));
-    hipEvent_t e0, e1;
-    B_TRY(hipEventCreate(&e0)); B_TRY(hipEventCreate(&e1));
+    put(h, opo, pose_off.data(), 4 * (size_t)(NP + 1)); put(h, olo, point_off.data(), 4 * (size_t)(NL + 1));
+    B_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
     const BaCam cam = make_cam(p->fx, p->fy, p->cx, p->cy, p->huber_delta, p->camera_model, p->fisheye_k);
-    B_TRY(hipEventRecord(e0, 0));
+    auto D = [&](size_t off) { return reinterpret_cast<double *>(d + off); };
+    auto I = [&](size_t off) { return reinterpret_cast<int *>(d + off); };
+    B_TRY(hipEventRecord(w->e0, s));
     if (NE)
-        hipLaunchKernelGGL(k_ba_edges, dim3((NE + 255) / 256), dim3(256), 0, 0, cam, NE, dR.as<double>(), dt.as<double>(),
-                           dfix.as<uint8_t>(), dP.as<double>(), dep.as<int>(), del.as<int>(), dz.as<double>(), dw.as<double>(),
-                           (const uint8_t *)nullptr, dchi.as<double>(), derr.as<double>(), dHlp.as<double>(), dCpp.as<double>(), dCll.as<double>());
-    hipLaunchKernelGGL(k_ba_reduce_pose, dim3(NP), dim3(256), 0, 0, dpo.as<int>(), dpe.as<int>(), dCpp.as<double>(),
-                       dHpp.as<double>(), dbp.as<double>());
-    hipLaunchKernelGGL(k_ba_reduce_point, dim3((NL + 255) / 256), dim3(256), 0, 0, NL, dlo.as<int>(), dCll.as<double>(),
-                       dHll.as<double>(), dbl.as<double>());
-    B_TRY(hipEventRecord(e1, 0));
-    B_TRY(hipEventSynchronize(e1));
+        hipLaunchKernelGGL(k_ba_edges, dim3((NE + 255) / 256), dim3(256), 0, s, cam, NE, D(oR), D(ot), d + ofix, D(oP), I(oep), I(oel), D(oz),
+                           D(ow), (const uint8_t *)nullptr, D(ochi), D(oerr), D(oHlp), D(oCpp), D(oCll));
+    hipLaunchKernelGGL(k_ba_reduce_pose, dim3(NP), dim3(256), 0, s, I(opo), I(ope), D(oCpp), D(oHpp), D(obp));
+    hipLaunchKernelGGL(k_ba_reduce_point, dim3((NL + 255) / 256), dim3(256), 0, s, NL, I(olo), D(oCll), D(oHll), D(obl));
+    B_TRY(hipEventRecord(w->e1, s));
     B_TRY(hipGetLastError());
+    B_TRY(hipMemcpyAsync(h, d + out_begin, out_end - out_begin, hipMemcpyDeviceToHost, s));
+    B_TRY(hipStreamSynchronize(s));
     float ms = 0;
-    B_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    B_TRY(hipEventElapsedTime(&ms, w->e0, w->e1));
     r->kernel_ms = ms;
-    if (r->chi2 && NE) B_TRY(hipMemcpy(r->chi2, dchi.p, sizeof(double) * NE, hipMemcpyDeviceToHost));
-    if (r->error && NE) B_TRY(hipMemcpy(r->error, derr.p, sizeof(double) * 2 * NE, hipMemcpyDeviceToHost));
-    if (r->H_lp && NE) B_TRY(hipMemcpy(r->H_lp, dHlp.p, sizeof(double) * 18 * NE, hipMemcpyDeviceToHost));
-    if (r->H_pp) B_TRY(hipMemcpy(r->H_pp, dHpp.p, sizeof(double) * 36 * NP, hipMemcpyDeviceToHost));
-    if (r->b_p) B_TRY(hipMemcpy(r->b_p, dbp.p, sizeof(double) * 6 * NP, hipMemcpyDeviceToHost));
-    if (r->H_ll) B_TRY(hipMemcpy(r->H_ll, dHll.p, sizeof(double) * 9 * NL, hipMemcpyDeviceToHost));
-    if (r->b_l) B_TRY(hipMemcpy(r->b_l, dbl.p, sizeof(double) * 3 * NL, hipMemcpyDeviceToHost));
+    auto O = [&](size_t off) { return h + (off - out_begin); }; // an output's place in the staging block
+    if (r->chi2 && NE) memcpy(r->chi2, O(ochi), 8 * (size_t)NE);
+    if (r->error && NE) memcpy(r->error, O(oerr), 16 * (size_t)NE);
+    if (r->H_lp && NE) memcpy(r->H_lp, O(oHlp), 144 * (size_t)NE);
+    if (r->H_pp) memcpy(r->H_pp, O(oHpp), 288 * (size_t)NP);
+    if (r->b_p) memcpy(r->b_p, O(obp), 48 * (size_t)NP);
+    if (r->H_ll) memcpy(r->H_ll, O(oHll), 72 * (size_t)NL);
+    if (r->b_l) memcpy(r->b_l, O(obl), 24 * (size_t)NL);
     return ORBX_OK;
 }
 
@@ -659,6 +735,22 @@ __global__ __launch_bounds__(256) void k_lm_chi2(int n_edges, double delta, cons
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// computeLambdaInit (g2o OptimizationAlgorithmLevenberg): max |H_jj| over the free poses' and the points' diagonal entries.
+// One workgroup; a maximum does not depend on the order it is taken in.
+__global__ __launch_bounds__(256) void k_lm_diag_max(int n_free, const int *__restrict__ free_pose, const double *__restrict__ Hpp,
+                                                     int n_points, const double *__restrict__ Hll, double *__restrict__ out)
+{
+    __shared__ double red4[4];
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < 6 * n_free; i += 256) mx = fmax(mx, fabs(Hpp[(size_t)36 * free_pose[i / 6] + 7 * (i % 6)]));
+    for (int i = threadIdx.x; i < 3 * n_points; i += 256) mx = fmax(mx, fabs(Hll[(size_t)9 * (i / 3) + 4 * (i % 3)]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = fmax(fmax(red4[0], red4[1]), fmax(red4[2], red4[3]));
+}
+
 extern "C" int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o, orbba_lm_result *r, int device)
 {
     if (!p || !o || !r) return orbx_set_error(ORBX_E_ARG, "null argument");
@@ -702,77 +794,83 @@ extern "C" int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o,
         for (int e = 0; e < NE; ++e) pose_edges[fill[p->edge_pose[e]]++] = e;
     }
     const int EB = (NE + 255) / 256, LB = (NL + 255) / 256;
-    Dev dR, dt, dRb, dtb, dfix, dP, dPb, dep, del, dz, dw, dact, dchi, dHlp, dCpp, dCll, dpo, dpe, dlo, dHpp, dbp, dHll, dbl, dinv,
-        dtl, dfree, dslot, deo, dS, drhs, dxp, dxl, dpart, dflag;
-    B_TRY(dR.alloc(8 * 9 * NP)); B_TRY(dt.alloc(8 * 3 * NP)); B_TRY(dRb.alloc(8 * 9 * NP)); B_TRY(dtb.alloc(8 * 3 * NP));
-    B_TRY(dfix.alloc(NP)); B_TRY(dP.alloc(8 * 3 * NL)); B_TRY(dPb.alloc(8 * 3 * NL));
-    B_TRY(dep.alloc(4 * NE)); B_TRY(del.alloc(4 * NE)); B_TRY(dz.alloc(16 * NE)); B_TRY(dw.alloc(8 * NE)); B_TRY(dact.alloc(NE));
-    B_TRY(dchi.alloc(8 * NE)); B_TRY(dHlp.alloc((size_t)8 * 18 * NE)); B_TRY(dCpp.alloc((size_t)8 * 27 * NE));
-    B_TRY(dCll.alloc((size_t)8 * 9 * NE));
-    B_TRY(dpo.alloc(4 * (NP + 1))); B_TRY(dpe.alloc(4 * NE)); B_TRY(dlo.alloc(4 * (NL + 1)));
-    B_TRY(dHpp.alloc(8 * 36 * NP)); B_TRY(dbp.alloc(8 * 6 * NP)); B_TRY(dHll.alloc(8 * 9 * NL)); B_TRY(dbl.alloc(8 * 3 * NL));
-    B_TRY(dinv.alloc(8 * 9 * NL)); B_TRY(dtl.alloc(8 * 3 * NL)); B_TRY(dfree.alloc(4 * NF)); B_TRY(dslot.alloc(4 * NP));
-    B_TRY(deo.alloc((size_t)4 * NF * NL)); B_TRY(dS.alloc((size_t)8 * N * N)); B_TRY(drhs.alloc(8 * N)); B_TRY(dxp.alloc(8 * N));
-    B_TRY(dxl.alloc(8 * 3 * NL)); B_TRY(dpart.alloc(8 * (EB + LB + 1))); B_TRY(dflag.alloc(4));
-    B_TRY(hipMemcpy(dR.p, p->pose_R, 8 * 9 * NP, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dt.p, p->pose_t, 8 * 3 * NP, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dfix.p, p->pose_fixed, NP, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dP.p, p->points, 8 * 3 * NL, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dep.p, p->edge_pose, 4 * NE, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(del.p, p->edge_point, 4 * NE, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dz.p, p->edge_z, 16 * NE, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dw.p, p->edge_inv_sigma2, 8 * NE, hipMemcpyHostToDevice));
-    if (o->edge_active) B_TRY(hipMemcpy(dact.p, o->edge_active, NE, hipMemcpyHostToDevice));
-    const uint8_t *d_active = o->edge_active ? dact.as<uint8_t>() : nullptr;
-    B_TRY(hipMemcpy(dpo.p, pose_off.data(), 4 * (NP + 1), hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dpe.p, pose_edges.data(), 4 * NE, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dlo.p, point_off.data(), 4 * (NL + 1), hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dfree.p, free_pose.data(), 4 * NF, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dslot.p, pose_slot.data(), 4 * NP, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(deo.p, edge_of.data(), (size_t)4 * NF * NL, hipMemcpyHostToDevice));
+    // arena: [estimates R t P -- in and out][other inputs][scratch][chi2 out][read-back block]
+    Layout L;
+    const size_t oR = L.add(72 * (size_t)NP), ot = L.add(24 * (size_t)NP), oP = L.add(24 * (size_t)NL);
+    const size_t est_bytes = L.n;
+    const size_t ofix = L.add(NP), oep = L.add(4 * (size_t)NE), oel = L.add(4 * (size_t)NE), oz = L.add(16 * (size_t)NE),
+                 ow = L.add(8 * (size_t)NE), oact = L.add(NE), opo = L.add(4 * (size_t)(NP + 1)), ope = L.add(4 * (size_t)NE),
+                 olo = L.add(4 * (size_t)(NL + 1)), ofree = L.add(4 * (size_t)NF), oslot = L.add(4 * (size_t)NP),
+                 oeo = L.add((size_t)4 * NF * NL);
+    const size_t in_bytes = L.n;
+    const size_t oRb = L.add(est_bytes), // push() / pop(): R, t, P kept in the same relative layout
+                 oHlp = L.add(144 * (size_t)NE), oCpp = L.add(216 * (size_t)NE), oCll = L.add(72 * (size_t)NE),
+                 oHpp = L.add(288 * (size_t)NP), obp = L.add(48 * (size_t)NP), oHll = L.add(72 * (size_t)NL), obl = L.add(24 * (size_t)NL),
+                 oinv = L.add(72 * (size_t)NL), otl = L.add(24 * (size_t)NL), oS = L.add((size_t)8 * N * N), orhs = L.add(8 * (size_t)N),
+                 oxp = L.add(8 * (size_t)N), oxl = L.add(24 * (size_t)NL);
+    const size_t ochi = L.add(8 * (size_t)NE);
+    // what the host reads per trial, ONE copy: [chi2 partials at the iteration's estimate: EB][at the trial's: EB]
+    // [computeScale partials of the points: LB][of the poses: 1][max |H_jj|: 1][Cholesky flag: int in 8 bytes]
+    const int RB_CUR = 0, RB_TRY = EB, RB_SCL = 2 * EB, RB_POSE = 2 * EB + LB, RB_MAX = RB_POSE + 1, RB_FLAG = RB_POSE + 2, RB_N = RB_POSE + 3;
+    const size_t orb = L.add(8 * (size_t)RB_N);
+    // page-locked block: [read-back][inputs up / results down]
+    Layout HL;
+    const size_t hrb = HL.add(8 * (size_t)RB_N), hio = HL.add(std::max(in_bytes, est_bytes + 8 * (size_t)NE + 256));
+    BaLease lease;
+    B_TRY(lease.acquire());
+    BaWork *w = lease.w;
+    B_TRY(w->need(L.n, HL.n));
+    hipStream_t s = w->stream;
+    uint8_t *d = w->d, *h = w->h + hio;
+    double *const rb = reinterpret_cast<double *>(w->h + hrb);
+    put(h, oR, p->pose_R, 72 * (size_t)NP); put(h, ot, p->pose_t, 24 * (size_t)NP); put(h, oP, p->points, 24 * (size_t)NL);
+    put(h, ofix, p->pose_fixed, NP); put(h, oep, p->edge_pose, 4 * (size_t)NE); put(h, oel, p->edge_point, 4 * (size_t)NE);
+    put(h, oz, p->edge_z, 16 * (size_t)NE); put(h, ow, p->edge_inv_sigma2, 8 * (size_t)NE);
+    if (o->edge_active) put(h, oact, o->edge_active, NE);
+    put(h, opo, pose_off.data(), 4 * (size_t)(NP + 1)); put(h, ope, pose_edges.data(), 4 * (size_t)NE);
+    put(h, olo, point_off.data(), 4 * (size_t)(NL + 1)); put(h, ofree, free_pose.data(), 4 * (size_t)NF);
+    put(h, oslot, pose_slot.data(), 4 * (size_t)NP); put(h, oeo, edge_of.data(), (size_t)4 * NF * NL);
+    B_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+    auto D = [&](size_t off) { return reinterpret_cast<double *>(d + off); };
+    auto I = [&](size_t off) { return reinterpret_cast<int *>(d + off); };
+    const uint8_t *d_active = o->edge_active ? d + oact : nullptr;
     const BaCam cam = make_cam(p->fx, p->fy, p->cx, p->cy, p->huber_delta, p->camera_model, p->fisheye_k);
-    hipEvent_t e0, e1;
-    B_TRY(hipEventCreate(&e0)); B_TRY(hipEventCreate(&e1));
-    B_TRY(hipEventRecord(e0, 0));
+    B_TRY(hipEventRecord(w->e0, s));
 
-    std::vector<double> part((size_t)EB + LB + 1);
-    // errors at the current estimate (+ the whole linearisation when `full`), returns activeRobustChi2
-    auto evaluate = [&](bool full, double *chi_out) -> int {
-        hipLaunchKernelGGL(k_ba_edges, dim3(EB), dim3(256), 0, 0, cam, NE, dR.as<double>(), dt.as<double>(), dfix.as<uint8_t>(),
-                           dP.as<double>(), dep.as<int>(), del.as<int>(), dz.as<double>(), dw.as<double>(), d_active,
-                           dchi.as<double>(), (double *)nullptr, full ? dHlp.as<double>() : nullptr,
-                           full ? dCpp.as<double>() : nullptr, full ? dCll.as<double>() : nullptr);
+    // errors at the current estimate (+ the whole linearisation when `full`); activeRobustChi2 as partial sums into the
+    // read-back block's slot `slot`
+    auto evaluate = [&](bool full, int slot) {
+        hipLaunchKernelGGL(k_ba_edges, dim3(EB), dim3(256), 0, s, cam, NE, D(oR), D(ot), d + ofix, D(oP), I(oep), I(oel), D(oz), D(ow),
+                           d_active, D(ochi), (double *)nullptr, full ? D(oHlp) : nullptr, full ? D(oCpp) : nullptr,
+                           full ? D(oCll) : nullptr);
         if (full) {
-            hipLaunchKernelGGL(k_ba_reduce_pose, dim3(NP), dim3(256), 0, 0, dpo.as<int>(), dpe.as<int>(), dCpp.as<double>(),
-                               dHpp.as<double>(), dbp.as<double>());
-            hipLaunchKernelGGL(k_ba_reduce_point, dim3(LB), dim3(256), 0, 0, NL, dlo.as<int>(), dCll.as<double>(),
-                               dHll.as<double>(), dbl.as<double>());
+            hipLaunchKernelGGL(k_ba_reduce_pose, dim3(NP), dim3(256), 0, s, I(opo), I(ope), D(oCpp), D(oHpp), D(obp));
+            hipLaunchKernelGGL(k_ba_reduce_point, dim3(LB), dim3(256), 0, s, NL, I(olo), D(oCll), D(oHll), D(obl));
         }
-        hipLaunchKernelGGL(k_lm_chi2, dim3(EB), dim3(256), 0, 0, NE, cam.delta, dchi.as<double>(), d_active, dpart.as<double>());
-        B_TRY(hipMemcpy(part.data(), dpart.p, 8 * EB, hipMemcpyDeviceToHost));
-        double sum = 0.0;
-        for (int b = 0; b < EB; ++b) sum += part[b];
-        *chi_out = sum;
+        hipLaunchKernelGGL(k_lm_chi2, dim3(EB), dim3(256), 0, s, NE, cam.delta, D(ochi), d_active, D(orb) + slot);
+    };
+    // the read-back block in host memory: the call's only waits besides the final one
+    auto read_back = [&]() -> int {
+        B_TRY(hipGetLastError());
+        B_TRY(hipMemcpyAsync(rb, d + orb, 8 * (size_t)RB_N, hipMemcpyDeviceToHost, s));
+        B_TRY(hipStreamSynchronize(s));
         return ORBX_OK;
     };
+    auto sum = [&](int from, int n) { double v = 0.0; for (int b = 0; b < n; ++b) v += rb[from + b]; return v; };
 
     double lam = 0.0, ni = 2.0, chi_initial = 0.0, current = 0.0;
     int its = 0, trials_total = 0, rc = ORBX_OK;
     for (int it = 0; it < o->max_iterations; ++it) {
-        if ((rc = evaluate(true, &current))) return rc;
+        evaluate(true, RB_CUR);
+        bool have_current = false;
         if (it == 0) {
-            chi_initial = current;
             if (o->user_lambda_init > 0) lam = o->user_lambda_init;
             else { // computeLambdaInit: tau * max |H_jj| over the free vertices
-                std::vector<double> hpp((size_t)36 * NP), hll((size_t)9 * NL);
-                B_TRY(hipMemcpy(hpp.data(), dHpp.p, 8 * 36 * NP, hipMemcpyDeviceToHost));
-                B_TRY(hipMemcpy(hll.data(), dHll.p, 8 * 9 * NL, hipMemcpyDeviceToHost));
-                double mx = 0.0;
-                for (int ip : free_pose)
-                    for (int k = 0; k < 6; ++k) mx = std::max(mx, std::fabs(hpp[(size_t)36 * ip + 7 * k]));
-                for (int l = 0; l < NL; ++l)
-                    for (int k = 0; k < 3; ++k) mx = std::max(mx, std::fabs(hll[(size_t)9 * l + 4 * k]));
-                lam = tau * mx;
+                hipLaunchKernelGGL(k_lm_diag_max, dim3(1), dim3(256), 0, s, NF, I(ofree), D(oHpp), NL, D(oHll), D(orb) + RB_MAX);
+                if ((rc = read_back())) return rc;
+                lam = tau * rb[RB_MAX];
+                current = sum(RB_CUR, EB);
+                have_current = true;
             }
             ni = 2.0;
         }
@@ -780,47 +878,41 @@ extern "C" int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o,
         int qmax = 0;
         do {
             // push(): keep the estimates
-            B_TRY(hipMemcpyAsync(dRb.p, dR.p, 8 * 9 * NP, hipMemcpyDeviceToDevice, 0));
-            B_TRY(hipMemcpyAsync(dtb.p, dt.p, 8 * 3 * NP, hipMemcpyDeviceToDevice, 0));
-            B_TRY(hipMemcpyAsync(dPb.p, dP.p, 8 * 3 * NL, hipMemcpyDeviceToDevice, 0));
-            hipLaunchKernelGGL(k_lm_points, dim3(LB), dim3(256), 0, 0, NL, lam, dHll.as<double>(), dbl.as<double>(),
-                               dinv.as<double>(), dtl.as<double>());
-            hipLaunchKernelGGL(k_lm_schur, dim3(NF * (NF + 1) / 2), dim3(256), 0, 0, NF, NL, lam, dfree.as<int>(), deo.as<int>(),
-                               dHpp.as<double>(), dbp.as<double>(), dHlp.as<double>(), dinv.as<double>(), dtl.as<double>(),
-                               dS.as<double>(), drhs.as<double>());
+            B_TRY(hipMemcpyAsync(d + oRb, d + oR, est_bytes, hipMemcpyDeviceToDevice, s)); // R, t, P and their copies are laid out alike
+            hipLaunchKernelGGL(k_lm_points, dim3(LB), dim3(256), 0, s, NL, lam, D(oHll), D(obl), D(oinv), D(otl));
+            hipLaunchKernelGGL(k_lm_schur, dim3(NF * (NF + 1) / 2), dim3(256), 0, s, NF, NL, lam, I(ofree), I(oeo), D(oHpp), D(obp), D(oHlp),
+                               D(oinv), D(otl), D(oS), D(orhs));
+            int *const d_flag = reinterpret_cast<int *>(D(orb) + RB_FLAG);
             // ORBBA_VAR_CHOL = 1: the global-memory kernel, the parity twin (read per call)
             bool in_lds = N <= CH_MAX_N && g_ba_chol.load() == 0;
             if (in_lds) {
                 const size_t lds = sizeof(double) * ((size_t)(N + 1) * (N + 1) + N);
                 // per device; when the opt-in or the launch is refused the global-memory kernel solves the system instead --
-                // a launch that did not happen would leave the previous iteration's step in dxp / dflag
+                // a launch that did not happen would leave the previous iteration's step in xp / the flag
                 in_lds = orbx_lds_opt_in(reinterpret_cast<const void *>(k_lm_chol_solve_lds), lds) == hipSuccess;
                 if (in_lds) {
-                    hipLaunchKernelGGL(k_lm_chol_solve_lds, dim3(1), dim3(CH_T), lds, 0, N, dS.as<double>(), drhs.as<double>(), dxp.as<double>(),
-                                       dflag.as<int>());
+                    hipLaunchKernelGGL(k_lm_chol_solve_lds, dim3(1), dim3(CH_T), lds, s, N, D(oS), D(orhs), D(oxp), d_flag);
                     in_lds = hipGetLastError() == hipSuccess;
                 }
             }
             if (!in_lds) {
-                hipLaunchKernelGGL(k_lm_chol_solve, dim3(1), dim3(256), 0, 0, N, dS.as<double>(), drhs.as<double>(), dxp.as<double>(),
-                                   dflag.as<int>());
+                hipLaunchKernelGGL(k_lm_chol_solve, dim3(1), dim3(256), 0, s, N, D(oS), D(orhs), D(oxp), d_flag);
                 B_TRY(hipGetLastError());
             }
-            hipLaunchKernelGGL(k_lm_backsub, dim3(LB), dim3(256), 0, 0, NL, lam, dlo.as<int>(), dep.as<int>(), dslot.as<int>(),
-                               dHlp.as<double>(), dxp.as<double>(), dbl.as<double>(), dinv.as<double>(), dxl.as<double>(),
-                               dpart.as<double>() + EB);
-            hipLaunchKernelGGL(k_lm_update_poses, dim3(1), dim3(256), 0, 0, NF, lam, dfree.as<int>(), dxp.as<double>(),
-                               dbp.as<double>(), dR.as<double>(), dt.as<double>(), dpart.as<double>() + EB + LB);
-            hipLaunchKernelGGL(k_lm_update_points, dim3((3 * NL + 255) / 256), dim3(256), 0, 0, 3 * NL, dxl.as<double>(),
-                               dP.as<double>());
-            double temp = 0.0;
-            if ((rc = evaluate(false, &temp))) return rc;
+            hipLaunchKernelGGL(k_lm_backsub, dim3(LB), dim3(256), 0, s, NL, lam, I(olo), I(oep), I(oslot), D(oHlp), D(oxp), D(obl), D(oinv),
+                               D(oxl), D(orb) + RB_SCL);
+            hipLaunchKernelGGL(k_lm_update_poses, dim3(1), dim3(256), 0, s, NF, lam, I(ofree), D(oxp), D(obp), D(oR), D(ot), D(orb) + RB_POSE);
+            hipLaunchKernelGGL(k_lm_update_points, dim3((3 * NL + 255) / 256), dim3(256), 0, s, 3 * NL, D(oxl), D(oP));
+            evaluate(false, RB_TRY);
+            if ((rc = read_back())) return rc;
+            if (!have_current) { current = sum(RB_CUR, EB); have_current = true; }
+            if (it == 0 && qmax == 0) chi_initial = current;
+            double temp = sum(RB_TRY, EB);
             int ok2 = 0;
-            B_TRY(hipMemcpy(&ok2, dflag.p, 4, hipMemcpyDeviceToHost));
-            B_TRY(hipMemcpy(part.data() + EB, dpart.as<double>() + EB, 8 * (LB + 1), hipMemcpyDeviceToHost));
+            memcpy(&ok2, rb + RB_FLAG, sizeof(int));
             if (!ok2) temp = std::numeric_limits<double>::max();
-            double scale = part[(size_t)EB + LB]; // poses first, then the points block by block
-            for (int b = 0; b < LB; ++b) scale += part[(size_t)EB + b];
+            double scale = rb[RB_POSE]; // poses first, then the points block by block
+            for (int b = 0; b < LB; ++b) scale += rb[RB_SCL + b];
             scale += 1e-3;
             rho = (current - temp) / scale;
             ++trials_total;
@@ -834,9 +926,7 @@ extern "C" int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o,
                 lam *= ni;
                 ni *= 2;
                 // pop(): restore
-                B_TRY(hipMemcpyAsync(dR.p, dRb.p, 8 * 9 * NP, hipMemcpyDeviceToDevice, 0));
-                B_TRY(hipMemcpyAsync(dt.p, dtb.p, 8 * 3 * NP, hipMemcpyDeviceToDevice, 0));
-                B_TRY(hipMemcpyAsync(dP.p, dPb.p, 8 * 3 * NL, hipMemcpyDeviceToDevice, 0));
+                B_TRY(hipMemcpyAsync(d + oR, d + oRb, est_bytes, hipMemcpyDeviceToDevice, s));
                 if (!std::isfinite(lam)) break;
             }
             ++qmax;
@@ -844,24 +934,26 @@ extern "C" int orbba_optimize(const orbba_problem *p, const orbba_lm_options *o,
         ++its;
         if (qmax == max_trials || rho == 0 || !std::isfinite(lam)) break; // Terminate
     }
-    double final_chi = 0.0;
-    if ((rc = evaluate(false, &final_chi))) return rc;
-    B_TRY(hipEventRecord(e1, 0));
-    B_TRY(hipEventSynchronize(e1));
+    evaluate(false, RB_TRY);
+    B_TRY(hipEventRecord(w->e1, s));
     B_TRY(hipGetLastError());
+    B_TRY(hipMemcpyAsync(rb, d + orb, 8 * (size_t)RB_N, hipMemcpyDeviceToHost, s));
+    B_TRY(hipMemcpyAsync(h, d, est_bytes, hipMemcpyDeviceToHost, s));
+    if (r->chi2) B_TRY(hipMemcpyAsync(h + est_bytes, d + ochi, 8 * (size_t)NE, hipMemcpyDeviceToHost, s));
+    B_TRY(hipStreamSynchronize(s));
+    const double final_chi = sum(RB_TRY, EB);
     float ms = 0;
-    B_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    B_TRY(hipEventElapsedTime(&ms, w->e0, w->e1));
     r->iterations = its;
     r->trials = trials_total;
     r->lambda = lam;
     r->chi2_initial = o->max_iterations > 0 ? chi_initial : final_chi;
     r->chi2_final = final_chi;
     r->device_ms = ms;
-    if (r->pose_R) B_TRY(hipMemcpy(r->pose_R, dR.p, 8 * 9 * NP, hipMemcpyDeviceToHost));
-    if (r->pose_t) B_TRY(hipMemcpy(r->pose_t, dt.p, 8 * 3 * NP, hipMemcpyDeviceToHost));
-    if (r->points) B_TRY(hipMemcpy(r->points, dP.p, 8 * 3 * NL, hipMemcpyDeviceToHost));
-    if (r->chi2) B_TRY(hipMemcpy(r->chi2, dchi.p, 8 * NE, hipMemcpyDeviceToHost));
+    if (r->pose_R) memcpy(r->pose_R, h + oR, 72 * (size_t)NP);
+    if (r->pose_t) memcpy(r->pose_t, h + ot, 24 * (size_t)NP);
+    if (r->points) memcpy(r->points, h + oP, 24 * (size_t)NL);
+    if (r->chi2) memcpy(r->chi2, h + est_bytes, 8 * (size_t)NE);
     return ORBX_OK;
 }
 
@@ -1212,42 +1304,47 @@ extern "C" int orbba_pose_optimize_batch(const orbba_pose_problem *p, orbba_pose
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return orbx_set_error(ORBX_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     if (device >= 0) B_TRY(hipSetDevice(device));
-    Dev doff, dR0, dt0, dP, dz, dw, dR, dt, din, dni, dchi;
-    B_TRY(doff.alloc(4 * (B + 1))); B_TRY(dR0.alloc(8 * 9 * B)); B_TRY(dt0.alloc(8 * 3 * B)); B_TRY(dP.alloc((size_t)24 * NE));
-    B_TRY(dz.alloc((size_t)16 * NE)); B_TRY(dw.alloc((size_t)8 * NE)); B_TRY(dR.alloc(8 * 9 * B)); B_TRY(dt.alloc(8 * 3 * B));
-    B_TRY(din.alloc(NE)); B_TRY(dni.alloc(4 * B)); B_TRY(dchi.alloc((size_t)8 * NE));
-    B_TRY(hipMemcpy(doff.p, p->edge_off, 4 * (B + 1), hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dR0.p, p->pose_R, 8 * 9 * B, hipMemcpyHostToDevice));
-    B_TRY(hipMemcpy(dt0.p, p->pose_t, 8 * 3 * B, hipMemcpyHostToDevice));
-    if (NE) {
-        B_TRY(hipMemcpy(dP.p, p->points, (size_t)24 * NE, hipMemcpyHostToDevice));
-        B_TRY(hipMemcpy(dz.p, p->edge_z, (size_t)16 * NE, hipMemcpyHostToDevice));
-        B_TRY(hipMemcpy(dw.p, p->edge_inv_sigma2, (size_t)8 * NE, hipMemcpyHostToDevice));
-    }
+    // arena: [inputs, one copy up][results, one copy down]
+    Layout L;
+    const size_t ooff = L.add(4 * (size_t)(B + 1)), oR0 = L.add(72 * (size_t)B), ot0 = L.add(24 * (size_t)B), oP = L.add(24 * (size_t)NE),
+                 oz = L.add(16 * (size_t)NE), ow = L.add(8 * (size_t)NE);
+    const size_t in_bytes = L.n;
+    const size_t oR = L.add(72 * (size_t)B), ot = L.add(24 * (size_t)B), oni = L.add(4 * (size_t)B), oin = L.add(NE);
+    const size_t out_small_end = L.n;
+    const size_t ochi = L.add(8 * (size_t)NE);
+    const size_t out_end = (NE && r->chi2) ? L.n : out_small_end;
+    BaLease lease;
+    B_TRY(lease.acquire());
+    BaWork *w = lease.w;
+    B_TRY(w->need(L.n, std::max(in_bytes, out_end - in_bytes)));
+    hipStream_t s = w->stream;
+    uint8_t *d = w->d, *h = w->h;
+    put(h, ooff, p->edge_off, 4 * (size_t)(B + 1)); put(h, oR0, p->pose_R, 72 * (size_t)B); put(h, ot0, p->pose_t, 24 * (size_t)B);
+    if (NE) { put(h, oP, p->points, 24 * (size_t)NE); put(h, oz, p->edge_z, 16 * (size_t)NE); put(h, ow, p->edge_inv_sigma2, 8 * (size_t)NE); }
+    B_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
     const BaCam cam = make_cam(p->fx, p->fy, p->cx, p->cy, p->huber_delta, p->camera_model, p->fisheye_k);
-    hipEvent_t e0, e1;
-    B_TRY(hipEventCreate(&e0)); B_TRY(hipEventCreate(&e1));
-    B_TRY(hipEventRecord(e0, 0));
+    auto D = [&](size_t off) { return reinterpret_cast<double *>(d + off); };
+    B_TRY(hipEventRecord(w->e0, s));
     int max_n = 0;
     for (int f = 0; f < B; ++f) max_n = std::max(max_n, p->edge_off[f + 1] - p->edge_off[f]);
     const int cap = std::min(pose_lds_cap(), max_n); // (no more LDS than the largest frame needs: more workgroups per CU for a big batch)
     B_TRY(pose_lds_configure(cap));
-    hipLaunchKernelGGL(k_pose_optimize, dim3(B), dim3(256), pose_lds_bytes(cap), 0, cam, p->rounds > 0 ? p->rounds : 4,
-                       p->iterations > 0 ? p->iterations : 10, cap, doff.as<int>(), dR0.as<double>(), dt0.as<double>(), dP.as<double>(),
-                       dz.as<double>(), dw.as<double>(), dR.as<double>(), dt.as<double>(), din.as<uint8_t>(), dni.as<int>(),
-                       dchi.as<double>());
-    B_TRY(hipEventRecord(e1, 0));
-    B_TRY(hipEventSynchronize(e1));
+    hipLaunchKernelGGL(k_pose_optimize, dim3(B), dim3(256), pose_lds_bytes(cap), s, cam, p->rounds > 0 ? p->rounds : 4,
+                       p->iterations > 0 ? p->iterations : 10, cap, reinterpret_cast<int *>(d + ooff), D(oR0), D(ot0), D(oP), D(oz), D(ow),
+                       D(oR), D(ot), d + oin, reinterpret_cast<int *>(d + oni), D(ochi));
+    B_TRY(hipEventRecord(w->e1, s));
     B_TRY(hipGetLastError());
+    B_TRY(hipMemcpyAsync(h, d + in_bytes, out_end - in_bytes, hipMemcpyDeviceToHost, s));
+    B_TRY(hipStreamSynchronize(s));
     float ms = 0;
-    B_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    B_TRY(hipEventElapsedTime(&ms, w->e0, w->e1));
     r->kernel_ms = ms;
-    B_TRY(hipMemcpy(r->pose_R, dR.p, 8 * 9 * B, hipMemcpyDeviceToHost));
-    B_TRY(hipMemcpy(r->pose_t, dt.p, 8 * 3 * B, hipMemcpyDeviceToHost));
-    B_TRY(hipMemcpy(r->n_inliers, dni.p, 4 * B, hipMemcpyDeviceToHost));
-    if (NE) B_TRY(hipMemcpy(r->inlier, din.p, NE, hipMemcpyDeviceToHost));
-    if (NE && r->chi2) B_TRY(hipMemcpy(r->chi2, dchi.p, (size_t)8 * NE, hipMemcpyDeviceToHost));
+    auto O = [&](size_t off) { return h + (off - in_bytes); }; // a result's place in the staging block
+    memcpy(r->pose_R, O(oR), 72 * (size_t)B);
+    memcpy(r->pose_t, O(ot), 24 * (size_t)B);
+    memcpy(r->n_inliers, O(oni), 4 * (size_t)B);
+    if (NE) memcpy(r->inlier, O(oin), NE);
+    if (NE && r->chi2) memcpy(r->chi2, O(ochi), 8 * (size_t)NE);
     return ORBX_OK;
 }
 

@@ -33,7 +33,7 @@ struct orbf_ctx {
     OrbfCam cam{};
     float *d_scale = nullptr;
     hipStream_t stream = nullptr;
-    bool null_pending = false; // a device call was enqueued on stream 0 (NULL): destroy waits for it too
+    bool null_pending = false; // a device call was enqueued on stream 0 (NULL): the next host-pointer call and destroy wait for it
     int32_t *d_cell_of = nullptr, *d_tmp = nullptr;
     size_t scratch_items = 0;
     // host-convenience staging
@@ -191,7 +191,7 @@ extern "C" int orbf_create(const orbf_camera *cam, int device, orbf_t **out)
         delete c;
         return orbx_set_error(ORBX_E_ARG, "image too large for the grid kernel (more than 7679 cells)");
     }
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault); // blocking: ordered with the null stream (include/orbx.h, "Streams")
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); // host-pointer calls only (include/orbx.h, "Streams")
     if (e == hipSuccess && cam->size_scale) {
         const size_t bytes = (size_t)cam->width * cam->height * 4;
         e = hipMalloc(&c->d_scale, bytes);
@@ -262,6 +262,8 @@ extern "C" int orbf_frame_post(orbf_t *c, orbx_kp *kp_raw, int n, orbx_kp *kp_un
     if (!c || !kp_raw || !kp_un || !cell_start || !cell_items) return orbx_set_error(ORBX_E_ARG, "null argument");
     if (n < 0) return orbx_set_error(ORBX_E_ARG, "negative key-point count");
     F_TRY(hipSetDevice(c->device));
+    // the handle's stream is non-blocking: NULL-stream device calls of this handle still in flight use the same scratch
+    if (c->null_pending) { F_TRY(hipStreamSynchronize((hipStream_t)0)); c->null_pending = false; }
     const int nc = c->cam.cols * c->cam.rows, cap = n > 0 ? n : 1;
     if ((size_t)cap > c->stage_cap) {
         F_TRY(hipStreamSynchronize(c->stream));

@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(256) void k_bow_finish(int check_orientation, const
 struct orbm_ctx {
     int device;
     hipStream_t stream;
-    bool null_pending = false; // a device call was enqueued on stream 0 (NULL): destroy waits for it too
+    bool null_pending = false; // a device call was enqueued on stream 0 (NULL): the next host-pointer call and destroy wait for it
     DevBuf a, b, out, q_idx, c_begin, c_len, out_begin, c_idx, row_ok, col_ok, bidx, bbest, bsecond;
     DevBuf w_in, w_out, w_grid; // window searches: staged inputs, lists, CSR grid + scratch
     PinBuf h_in, h_out;
@@ -1414,6 +1414,16 @@ struct orbm_ctx {
     int n_cus = 256;            // the device's CU count (set at create)
     size_t window_last_total = 0; // candidates the previous window search returned (sizes the first copy-out)
 };
+
+// A host-pointer entry point starts here: the handle's device and -- the handle's stream being NON-BLOCKING, so that a second
+// thread's handle or a legacy-stream operation anywhere in the process never orders against it (include/orbx.h, "Streams") -- a
+// wait for NULL-stream device calls of THIS handle that may still be using its scratch.
+static hipError_t host_call_begin(orbm_ctx *c)
+{
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess && c->null_pending) { e = hipStreamSynchronize((hipStream_t)0); c->null_pending = false; }
+    return e;
+}
 
 extern "C" int orbm_create(int device, orbm_t **out)
 {
@@ -1426,7 +1436,7 @@ extern "C" int orbm_create(int device, orbm_t **out)
     if (device >= ndev) return orbx_set_error(ORBX_E_ARG, "device ordinal out of range");
     orbm_ctx *c = new orbm_ctx();
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess) { // blocking: ordered with the null stream (include/orbx.h, "Streams")
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { // host-pointer calls only (include/orbx.h, "Streams")
         delete c;
         return orbx_set_error(ORBX_E_NO_DEVICE, "stream creation failed");
     }
@@ -1475,7 +1485,7 @@ extern "C" int orbm_hamming_matrix(orbm_t *c, const uint8_t *a, int na, const ui
 {
     if (!c || !a || !b || !out || na < 0 || nb < 0) return orbx_set_error(ORBX_E_ARG, "bad argument");
     if (na == 0 || nb == 0) return ORBX_OK;
-    M_TRY(hipSetDevice(c->device));
+    M_TRY(host_call_begin(c));
     M_TRY(c->a.need((size_t)na * 32));
     M_TRY(c->b.need((size_t)nb * 32));
     M_TRY(c->out.need((size_t)na * nb * 2));
@@ -1540,7 +1550,7 @@ extern "C" int orbm_best2(orbm_t *c, const uint8_t *a, int na, const uint8_t *b,
     if (!c || !a || !best_idx || !best || !second || na < 0 || nb < 0 || (nb > 0 && !b))
         return orbx_set_error(ORBX_E_ARG, "bad argument");
     if (na == 0) return ORBX_OK;
-    M_TRY(hipSetDevice(c->device));
+    M_TRY(host_call_begin(c));
     hipStream_t s = c->stream;
     M_TRY(c->a.need((size_t)na * 32));
     M_TRY(c->b.need((size_t)std::max(nb, 1) * 32));
@@ -1584,7 +1594,7 @@ static int hamming_lists(orbm_ctx *c, const uint8_t *a, int na, const uint8_t *b
     out.resize(n_out);
     const int nq = (int)q_idx.size();
     if (nq == 0 || n_out == 0) return ORBX_OK;
-    M_TRY(hipSetDevice(c->device));
+    M_TRY(host_call_begin(c));
     hipStream_t s = c->stream;
     M_TRY(c->a.need((size_t)na * 32));
     M_TRY(c->b.need((size_t)nb * 32));
@@ -1623,7 +1633,7 @@ static int topk_lists(orbm_ctx *c, const uint8_t *a, int na, const uint8_t *b, i
     *k_out = TOPK;
     out.assign((size_t)nq * TOPK, 0xFFFFFFFFu);
     if (nq == 0 || n_cidx == 0) return ORBX_OK;
-    M_TRY(hipSetDevice(c->device));
+    M_TRY(host_call_begin(c));
     hipStream_t s = c->stream;
     M_TRY(c->a.need((size_t)na * 32));
     M_TRY(c->b.need((size_t)nb * 32));
@@ -1717,7 +1727,7 @@ extern "C" int orbm_distinctive_descriptors(orbm_t *c, const uint8_t *desc, cons
             return orbx_set_error(ORBX_E_UNSUPPORTED, "more than 1024 observations of one map point");
     }
     if (total > 0 && !desc) return orbx_set_error(ORBX_E_ARG, "null descriptors");
-    M_TRY(hipSetDevice(c->device));
+    M_TRY(host_call_begin(c));
     hipStream_t s = c->stream;
     M_TRY(c->a.need((size_t)std::max(total, 1) * 32));
     M_TRY(c->c_begin.need((size_t)(n_groups + 1) * 4));
@@ -2051,7 +2061,7 @@ static int window_candidates(orbm_ctx *c, bool strict, const float *sigma2, int 
     const int nc = cols * rows;
     bool on_device = c->window_on_device && nc > 0 && (size_t)(2 * nc + 1) * 4 <= 60000 && n2 < (1 << 22);
     if (on_device) {
-        M_TRY(hipSetDevice(c->device));
+        M_TRY(host_call_begin(c));
         hipStream_t s = c->stream;
         auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
         size_t o = 0;

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -40,15 +41,8 @@ struct VocDev {
     int L, n_words, scoring, weighting;
 };
 
-struct orbv_ctx {
-    int device = 0, k = 0, L = 0, scoring = 0, weighting = 0, n_nodes = 0, n_words = 0;
-    std::vector<int32_t> parent;
-    std::vector<uint8_t> is_leaf, desc;
-    std::vector<double> weight;
-    VocDev dev{};
-    void *d_first = nullptr, *d_pk_id = nullptr, *d_pk_desc = nullptr, *d_word_id = nullptr, *d_weight = nullptr;
+struct VocLane {
     hipStream_t stream = nullptr;
-    bool null_pending = false; // a device call was enqueued on stream 0 (NULL): destroy waits for it too
     // per-feature scratch of the batch transform
     uint32_t *s_word = nullptr, *s_node = nullptr;
     double *s_w = nullptr;
@@ -57,6 +51,31 @@ struct orbv_ctx {
     void *h_desc = nullptr, *h_bow_ids = nullptr, *h_bow_vals = nullptr, *h_fv_nodes = nullptr, *h_fv_off = nullptr,
          *h_fv_idx = nullptr, *h_counts = nullptr;
     size_t h_cap = 0;
+    void release()
+    {
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); stream = nullptr; }
+        for (void *p : {(void *)s_word, (void *)s_node, (void *)s_w, h_desc, h_bow_ids, h_bow_vals, h_fv_nodes, h_fv_off, h_fv_idx, h_counts})
+            if (p) (void)hipFree(p);
+        s_word = s_node = nullptr; s_w = nullptr; s_items = 0;
+        h_desc = h_bow_ids = h_bow_vals = h_fv_nodes = h_fv_off = h_fv_idx = h_counts = nullptr; h_cap = 0;
+    }
+};
+
+struct orbv_ctx {
+    int device = 0, k = 0, L = 0, scoring = 0, weighting = 0, n_nodes = 0, n_words = 0;
+    std::vector<int32_t> parent;
+    std::vector<uint8_t> is_leaf, desc;
+    std::vector<double> weight;
+    VocDev dev{};
+    void *d_first = nullptr, *d_pk_id = nullptr, *d_pk_desc = nullptr, *d_word_id = nullptr, *d_weight = nullptr;
+    bool null_pending = false; // a device call was enqueued on stream 0 (NULL): destroy waits for it too
+    // The reference's vocabulary is ONE object that Tracking (Frame::computeBow, Frame.cpp:168-178) and LocalMapping
+    // (KeyFrame::computeBow, LocalMapping.cpp:90) call at the same time: the tree above is read-only, everything a call writes
+    // lives in a lane.  The device entry points use `dev_lane` (scratch only; one call in flight per handle, as orbv.h says);
+    // every host-pointer call leases a lane of its own -- non-blocking stream, scratch, staging -- so orbv_transform is re-entrant.
+    VocLane dev_lane;
+    std::mutex mu;
+    std::vector<VocLane *> idle;
 };
 
 __device__ __forceinline__ int ham256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1)
@@ -283,7 +302,6 @@ static int upload(orbv_ctx *c)
     V_TRY(hipMemcpy(c->d_weight, c->weight.data(), (size_t)n * 8, hipMemcpyHostToDevice));
     c->dev = VocDev{(const int32_t *)c->d_first, (const uint32_t *)c->d_pk_id, (const uint4 *)c->d_pk_desc,
                     (const uint32_t *)c->d_word_id, (const double *)c->d_weight, c->L, c->n_words, c->scoring, c->weighting};
-    V_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamDefault)); // blocking: ordered with the null stream (include/orbx.h, "Streams")
     return ORBX_OK;
 }
 
@@ -399,12 +417,11 @@ extern "C" void orbv_destroy(orbv_t *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->null_pending) (void)hipStreamSynchronize((hipStream_t)0);
-    for (void *p : {c->d_first, c->d_pk_id, c->d_pk_desc, c->d_word_id, c->d_weight, (void *)c->s_word, (void *)c->s_node,
-                    (void *)c->s_w, c->h_desc, c->h_bow_ids, c->h_bow_vals, c->h_fv_nodes, c->h_fv_off, c->h_fv_idx, c->h_counts})
+    for (VocLane *ln : c->idle) { ln->release(); delete ln; }
+    c->dev_lane.release();
+    for (void *p : {c->d_first, c->d_pk_id, c->d_pk_desc, c->d_word_id, c->d_weight})
         if (p) (void)hipFree(p);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -453,6 +470,39 @@ extern "C" int orbv_transform_features_device(orbv_t *c, const uint8_t *d_desc, 
     return ORBX_OK;
 }
 
+// k_voc_descend + k_voc_group of a batch on stream `s`, with lane `ln`'s per-feature scratch
+static int transform_enqueue(orbv_ctx *c, VocLane &ln, int n_frames, const uint8_t *d_desc, const int32_t *d_n, int cap, int levelsup,
+                             uint32_t *d_bow_ids, double *d_bow_vals, int32_t *d_n_words, uint32_t *d_fv_nodes, int32_t *d_fv_off,
+                             uint32_t *d_fv_idx, int32_t *d_n_fv, hipStream_t s)
+{
+    const size_t need = (size_t)n_frames * cap;
+    if (need > ln.s_items) {
+        V_TRY(hipDeviceSynchronize());
+        for (void **p : {(void **)&ln.s_word, (void **)&ln.s_node, (void **)&ln.s_w})
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        ln.s_items = 0;
+        const size_t grow = need + need / 2;
+        V_TRY(hipMalloc(&ln.s_word, grow * 4));
+        V_TRY(hipMalloc(&ln.s_node, grow * 4));
+        V_TRY(hipMalloc(&ln.s_w, grow * 8));
+        ln.s_items = grow;
+    }
+    if (c->n_words > 0) { // empty vocabulary: transform() returns empty maps (:1133), k_voc_group handles it
+        hipLaunchKernelGGL(k_voc_descend, dim3((std::min(cap, ORBV_MAX_FEATURES) + 255) / 256, n_frames), dim3(256), 0, s,
+                           c->dev, d_desc, d_n, 0, cap, levelsup, ln.s_word, ln.s_node, ln.s_w);
+        V_TRY(hipGetLastError());
+    }
+    int p_max = 256;
+    while (p_max < std::min(cap, ORBV_MAX_FEATURES)) p_max <<= 1;
+    const size_t lds = (size_t)p_max * 16;
+    // more than 64 KB of dynamic LDS has to be requested once per device
+    V_TRY(orbx_lds_opt_in(reinterpret_cast<const void *>(k_voc_group), (size_t)ORBV_MAX_FEATURES * 16));
+    hipLaunchKernelGGL(k_voc_group, dim3(n_frames), dim3(256), lds, s, c->dev, d_n, cap, p_max, ln.s_word, ln.s_node, ln.s_w,
+                       d_bow_ids, d_bow_vals, d_n_words, d_fv_nodes, d_fv_off, d_fv_idx, d_n_fv);
+    V_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+
 extern "C" int orbv_transform_device(orbv_t *c, int n_frames, const uint8_t *d_desc, const int32_t *d_n, int cap,
                                      int levelsup, uint32_t *d_bow_ids, double *d_bow_vals, int32_t *d_n_words,
                                      uint32_t *d_fv_nodes, int32_t *d_fv_off, uint32_t *d_fv_idx, int32_t *d_n_fv,
@@ -468,35 +518,38 @@ extern "C" int orbv_transform_device(orbv_t *c, int n_frames, const uint8_t *d_d
     if (check_levelsup(levelsup)) return ORBX_E_ARG;
     if (n_frames == 0) return ORBX_OK;
     V_TRY(hipSetDevice(c->device));
-    hipStream_t s = (hipStream_t)stream; // NULL is stream 0 itself (include/orbx.h, "Streams")
-    if (!stream) c->null_pending = true;
-    const size_t need = (size_t)n_frames * cap;
-    if (need > c->s_items) {
-        V_TRY(hipDeviceSynchronize());
-        for (void **p : {(void **)&c->s_word, (void **)&c->s_node, (void **)&c->s_w})
-            if (*p) { (void)hipFree(*p); *p = nullptr; }
-        c->s_items = 0;
-        const size_t grow = need + need / 2;
-        V_TRY(hipMalloc(&c->s_word, grow * 4));
-        V_TRY(hipMalloc(&c->s_node, grow * 4));
-        V_TRY(hipMalloc(&c->s_w, grow * 8));
-        c->s_items = grow;
-    }
-    if (c->n_words > 0) { // empty vocabulary: transform() returns empty maps (:1133), k_voc_group handles it
-        hipLaunchKernelGGL(k_voc_descend, dim3((std::min(cap, ORBV_MAX_FEATURES) + 255) / 256, n_frames), dim3(256), 0, s,
-                           c->dev, d_desc, d_n, 0, cap, levelsup, c->s_word, c->s_node, c->s_w);
-        V_TRY(hipGetLastError());
-    }
-    int p_max = 256;
-    while (p_max < std::min(cap, ORBV_MAX_FEATURES)) p_max <<= 1;
-    const size_t lds = (size_t)p_max * 16;
-    // more than 64 KB of dynamic LDS has to be requested once per device
-    V_TRY(orbx_lds_opt_in(reinterpret_cast<const void *>(k_voc_group), (size_t)ORBV_MAX_FEATURES * 16));
-    hipLaunchKernelGGL(k_voc_group, dim3(n_frames), dim3(256), lds, s, c->dev, d_n, cap, p_max, c->s_word, c->s_node, c->s_w,
-                       d_bow_ids, d_bow_vals, d_n_words, d_fv_nodes, d_fv_off, d_fv_idx, d_n_fv);
-    V_TRY(hipGetLastError());
-    return ORBX_OK;
+    if (!stream) c->null_pending = true; // NULL is stream 0 itself (include/orbx.h, "Streams")
+    return transform_enqueue(c, c->dev_lane, n_frames, d_desc, d_n, cap, levelsup, d_bow_ids, d_bow_vals, d_n_words, d_fv_nodes, d_fv_off,
+                             d_fv_idx, d_n_fv, (hipStream_t)stream);
 }
+
+namespace {
+// a host-pointer call's lane: taken from the handle's idle list (or made), given back when the call returns
+struct LaneLease {
+    orbv_ctx *c;
+    VocLane *ln = nullptr;
+    explicit LaneLease(orbv_ctx *ctx) : c(ctx) {}
+    ~LaneLease()
+    {
+        if (!ln) return;
+        (void)hipStreamSynchronize(ln->stream); // an error return may leave work in flight
+        std::lock_guard<std::mutex> lock(c->mu);
+        c->idle.push_back(ln);
+    }
+    hipError_t acquire()
+    {
+        {
+            std::lock_guard<std::mutex> lock(c->mu);
+            if (!c->idle.empty()) { ln = c->idle.back(); c->idle.pop_back(); return hipSuccess; }
+        }
+        VocLane *n = new VocLane();
+        hipError_t e = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete n; return e; }
+        ln = n;
+        return hipSuccess;
+    }
+};
+} // namespace
 
 extern "C" int orbv_transform(orbv_t *c, const uint8_t *desc, int n, int levelsup, uint32_t *bow_ids, double *bow_vals,
                               int32_t *n_words, uint32_t *fv_nodes, int32_t *fv_off, uint32_t *fv_idx, int32_t *n_fv)
@@ -509,41 +562,45 @@ extern "C" int orbv_transform(orbv_t *c, const uint8_t *desc, int n, int levelsu
     *n_fv = 0;
     fv_off[0] = 0;
     if (n == 0) return ORBX_OK;
+    if (check_levelsup(levelsup)) return ORBX_E_ARG;
     V_TRY(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    if ((size_t)n > c->h_cap) {
+    LaneLease lease(c);
+    V_TRY(lease.acquire());
+    VocLane &ln = *lease.ln;
+    hipStream_t s = ln.stream;
+    if ((size_t)n > ln.h_cap) {
         V_TRY(hipStreamSynchronize(s));
-        for (void **p : {&c->h_desc, &c->h_bow_ids, &c->h_bow_vals, &c->h_fv_nodes, &c->h_fv_off, &c->h_fv_idx, &c->h_counts})
+        for (void **p : {&ln.h_desc, &ln.h_bow_ids, &ln.h_bow_vals, &ln.h_fv_nodes, &ln.h_fv_off, &ln.h_fv_idx, &ln.h_counts})
             if (*p) { (void)hipFree(*p); *p = nullptr; }
-        c->h_cap = 0;
+        ln.h_cap = 0;
         const size_t g = (size_t)n + n / 2 + 64;
-        V_TRY(hipMalloc(&c->h_desc, g * 32));
-        V_TRY(hipMalloc(&c->h_bow_ids, g * 4));
-        V_TRY(hipMalloc(&c->h_bow_vals, g * 8));
-        V_TRY(hipMalloc(&c->h_fv_nodes, g * 4));
-        V_TRY(hipMalloc(&c->h_fv_off, (g + 1) * 4));
-        V_TRY(hipMalloc(&c->h_fv_idx, g * 4));
-        V_TRY(hipMalloc(&c->h_counts, 12));
-        c->h_cap = g;
+        V_TRY(hipMalloc(&ln.h_desc, g * 32));
+        V_TRY(hipMalloc(&ln.h_bow_ids, g * 4));
+        V_TRY(hipMalloc(&ln.h_bow_vals, g * 8));
+        V_TRY(hipMalloc(&ln.h_fv_nodes, g * 4));
+        V_TRY(hipMalloc(&ln.h_fv_off, (g + 1) * 4));
+        V_TRY(hipMalloc(&ln.h_fv_idx, g * 4));
+        V_TRY(hipMalloc(&ln.h_counts, 12));
+        ln.h_cap = g;
     }
-    int32_t *cnt = (int32_t *)c->h_counts; // [0] n, [1] n_words, [2] n_fv
+    int32_t *cnt = (int32_t *)ln.h_counts; // [0] n, [1] n_words, [2] n_fv
     const int32_t n32 = n;
-    V_TRY(hipMemcpyAsync(c->h_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    V_TRY(hipMemcpyAsync(ln.h_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
     V_TRY(hipMemcpyAsync(cnt, &n32, 4, hipMemcpyHostToDevice, s));
-    int rc = orbv_transform_device(c, 1, (const uint8_t *)c->h_desc, cnt, n, levelsup, (uint32_t *)c->h_bow_ids,
-                                   (double *)c->h_bow_vals, cnt + 1, (uint32_t *)c->h_fv_nodes, (int32_t *)c->h_fv_off,
-                                   (uint32_t *)c->h_fv_idx, cnt + 2, s);
+    int rc = transform_enqueue(c, ln, 1, (const uint8_t *)ln.h_desc, cnt, n, levelsup, (uint32_t *)ln.h_bow_ids,
+                               (double *)ln.h_bow_vals, cnt + 1, (uint32_t *)ln.h_fv_nodes, (int32_t *)ln.h_fv_off,
+                               (uint32_t *)ln.h_fv_idx, cnt + 2, s);
     if (rc) return rc;
     int32_t back[3];
     V_TRY(hipMemcpyAsync(back, cnt, 12, hipMemcpyDeviceToHost, s));
     V_TRY(hipStreamSynchronize(s));
     *n_words = back[1];
     *n_fv = back[2];
-    V_TRY(hipMemcpyAsync(bow_ids, c->h_bow_ids, (size_t)back[1] * 4, hipMemcpyDeviceToHost, s));
-    V_TRY(hipMemcpyAsync(bow_vals, c->h_bow_vals, (size_t)back[1] * 8, hipMemcpyDeviceToHost, s));
-    V_TRY(hipMemcpyAsync(fv_nodes, c->h_fv_nodes, (size_t)back[2] * 4, hipMemcpyDeviceToHost, s));
-    V_TRY(hipMemcpyAsync(fv_off, c->h_fv_off, (size_t)(back[2] + 1) * 4, hipMemcpyDeviceToHost, s));
-    V_TRY(hipMemcpyAsync(fv_idx, c->h_fv_idx, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    V_TRY(hipMemcpyAsync(bow_ids, ln.h_bow_ids, (size_t)back[1] * 4, hipMemcpyDeviceToHost, s));
+    V_TRY(hipMemcpyAsync(bow_vals, ln.h_bow_vals, (size_t)back[1] * 8, hipMemcpyDeviceToHost, s));
+    V_TRY(hipMemcpyAsync(fv_nodes, ln.h_fv_nodes, (size_t)back[2] * 4, hipMemcpyDeviceToHost, s));
+    V_TRY(hipMemcpyAsync(fv_off, ln.h_fv_off, (size_t)(back[2] + 1) * 4, hipMemcpyDeviceToHost, s));
+    V_TRY(hipMemcpyAsync(fv_idx, ln.h_fv_idx, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     V_TRY(hipStreamSynchronize(s));
     return ORBX_OK;
 }

@@ -19,8 +19,8 @@
 #include "orb_math.h"
 #include "orbx_internal.h"
 
-#ifndef ORBX_HANDLE_STREAM_FLAGS // (a build with hipStreamNonBlocking measures what the blocking handle stream costs a single-frame call: tools/ab_latency.sh)
-#define ORBX_HANDLE_STREAM_FLAGS hipStreamDefault
+#ifndef ORBX_HANDLE_STREAM_FLAGS // (a build with hipStreamDefault is round 5's blocking handle stream: tools/ab_latency.sh, tools/two_thread_latency.sh)
+#define ORBX_HANDLE_STREAM_FLAGS hipStreamNonBlocking
 #endif
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -487,9 +487,12 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
     c->cur_w = c->cur_h = -1;
     auto cleanup = [&](int code) { orbx_destroy(c); return code; };
     if (hipSetDevice(dev) != hipSuccess) return cleanup(fail(ORBX_E_NO_DEVICE, "hipSetDevice failed"));
-    // The handle's own stream is a BLOCKING stream (hipStreamDefault): it is what a NULL stream argument means, and it must be
-    // ordered with the legacy default stream in both directions (include/orbx.h, "Streams").  The internal side / sub-streams
-    // below are forked from and joined into the stream of the call with events and stay non-blocking.
+    // The handle's own stream serves the HOST-POINTER entry points only (a NULL stream argument of a device entry point is
+    // stream 0 itself) and is NON-BLOCKING: such a call uploads, computes, downloads and waits on it, so nothing of it has to be
+    // ordered with the legacy stream -- and a blocking stream would make every legacy-stream operation of any thread of the
+    // process (another thread's hipMemcpy, its NULL-stream device calls) a barrier against this handle's work: the reference runs
+    // Tracking and LocalMapping side by side (include/orbx.h, "Streams").  The internal side / sub-streams below are forked
+    // from and joined into the stream of the call with events.
     if (hipStreamCreateWithFlags(&c->stream, ORBX_HANDLE_STREAM_FLAGS) != hipSuccess)
         return cleanup(fail(ORBX_E_NO_DEVICE, "hipStreamCreate failed"));
     for (int i = 0; i <= ORBX_N_STAGES; ++i)
@@ -939,6 +942,8 @@ extern "C" int orbx_extract_batch(orbx_t *c, const uint8_t *imgs, int n_frames, 
     }
     rc = ensure_geometry(c, width, height, n_frames, dcap);
     if (rc) return rc;
+    // a NULL-stream device call of this handle may still be in flight on the pyramid and scratch this call is about to use
+    if (c->null_pending) { HIP_TRY(hipStreamSynchronize((hipStream_t)0)); c->null_pending = false; }
     const int scap = c->alloc_out_cap;
     hipStream_t s = c->stream;
     PhaseTrace tr;

@@ -221,3 +221,20 @@ def test_cpp_caller_on_the_null_stream(tmp_path):
     out = subprocess.run([exe], text=True, capture_output=True, timeout=300)
     print(out.stdout, out.stderr)
     assert out.returncode == 0 and "null stream ok" in out.stdout
+
+
+def test_two_host_threads_through_the_c_abi(tmp_path):
+    """include/orbx.h "Streams and threads" / SURVEY 8b "Threading": the reference runs Tracking and LocalMapping on two threads
+    (System.cpp:55; LocalMapping.cpp:45-52, 168, 282, 301) that share one vocabulary.  tests/cpp/two_threads.cpp: thread T loops
+    orbx_extract + orbv_transform + orbm_search_by_projection_frame + orbba_pose_optimize_batch, thread M loops orbv_transform +
+    orbm_search_for_triangulation + orbm_search_fuse + orbba_local_bundle_adjustment, each on its own handles; every output of
+    every iteration equals the single-thread answer byte for byte."""
+    exe = str(tmp_path / "two_threads")
+    lib = os.path.join(ROOT, "monoorbslam3_amd", "lib")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "two_threads.cpp"), "-o", exe,
+                           "-L", lib, "-lorbx", "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-pthread", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe, "--iters", "12"], text=True, capture_output=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "two threads ok" in out.stdout

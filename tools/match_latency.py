@@ -59,8 +59,8 @@ for bits, label in ((0, "dense: one node, 2000x2000 pairs"), (4, "16 nodes (~125
     d = dict(desc1=up(a), kps1=kp(k1r), kf_mp_ok=up(ok), fv1=dev_fv(fv1), desc2=up(b), kps2=kp(k2r), frame_mp=up(mp0), fv2=dev_fv(fv2),
              result=torch.zeros(8, dtype=torch.int32, device=dev), has_mp1=up(1 - ok), has_mp2=up(np.zeros(n, np.uint8)),
              matches12=torch.zeros(n, dtype=torch.int32, device=dev))
-    # a stream of its own: torch's default stream has handle 0, which the C ABI reads as "the handle's own stream" -- events
-    # recorded on the default stream would then bracket nothing
+    # a stream of its own (a NULL stream is stream 0 itself for every device entry point, include/orbx.h "Streams"): the events
+    # below are recorded on the stream the chain is enqueued on
     ts = torch.cuda.Stream()
     st = ts.cuda_stream
     assert st != 0
