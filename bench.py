@@ -174,6 +174,141 @@ def stub_run(args, rank, world):
         dist.destroy_process_group()
 
 
+# VALU popcount peak for the 256-bit Hamming distance ("fraction of VALU popcount peak"): a pair costs 8 v_xor_b32 +
+# 8 v_bcnt_u32_b32 (the count accumulates in the instruction's second operand, so there is no add tree), 64 pairs per
+# wave-instruction; v_xor issues in the cheap class (850 G wave-instr/s), v_bcnt_u32_b32 at 568.4 G wave-instr/s
+# (tools/microbench/valu_ops2.hip -> profiles/r02_valu_ops2.txt).  The key update (shift-or, med3, min) is not in the peak.
+VALU_BCNT_GWINST = 568.4
+VALU_POPCOUNT_PEAK_GPAIRS = 64.0 / (8.0 / VALU_RATE_CHEAP_GWINST + 8.0 / VALU_BCNT_GWINST)
+
+
+def bench_config3(dev, device_index):
+    """BASELINE config 3 (ORBmatcher::SearchByBoW Hamming BF, 2000 x 2000 256-bit descriptors): the dense best / second-best
+    search on the FP4 matrix path and on its VALU twin -- one problem (latency) and 256 problems in one launch (rate) --, and
+    the whole SearchByBow on device-resident records with every feature in one vocabulary node.  Device time by HIP events on the
+    stream the calls are enqueued on, median of 15."""
+    from monoorbslam3_amd import synth, _lib
+    from monoorbslam3_amd.extractor import KP_DTYPE
+    from monoorbslam3_amd.matcher import MatcherHandle, ORBMatcher, _mlib
+    n, P = 2000, 256
+    a, b, _ = synth.make_descriptor_pair(n, seed=1)
+    ML = _mlib()
+    st = torch.cuda.Stream(device=dev)
+    d_a = torch.from_numpy(a).to(dev).unsqueeze(0).repeat(P, 1, 1).contiguous()
+    d_b = torch.from_numpy(b).to(dev).unsqueeze(0).repeat(P, 1, 1).contiguous()
+    d_na = torch.full((P,), n, dtype=torch.int32, device=dev)
+    d_bi = torch.zeros((P, n), dtype=torch.int32, device=dev)
+    d_bd = torch.zeros((P, n), dtype=torch.int16, device=dev)
+    d_sd = torch.zeros((P, n), dtype=torch.int16, device=dev)
+
+    def timed(fn, reps=15):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for r in range(reps + 2):
+            torch.cuda.synchronize()
+            with torch.cuda.stream(st):
+                e0.record(st)
+                fn()
+                e1.record(st)
+            torch.cuda.synchronize()
+            if r >= 2:
+                ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    out = {"descriptors": "%d x %d, 256 bit" % (n, n), "timed_by": "HIP events on the calls' stream, median of 15"}
+    ref = None
+    for variant in ("fp4", "valu"):
+        mh = MatcherHandle(device=device_index)
+        mh.set_variant("best2", variant)
+        call = lambda np_: _lib.check(ML.orbm_best2_device(mh._h, np_, d_a.data_ptr(), n, d_na.data_ptr(), n, d_b.data_ptr(), n,  # noqa: E731
+                                                           d_na.data_ptr(), n, None, None, d_bi.data_ptr(), d_bd.data_ptr(),
+                                                           d_sd.data_ptr(), st.cuda_stream))
+        ms1 = timed(lambda: call(1))
+        msP = timed(lambda: call(P))
+        got = (d_bi[0].cpu().numpy().copy(), d_bd[0].cpu().numpy().copy(), d_sd[0].cpu().numpy().copy())
+        if ref is None:
+            ref = got
+        same = all(np.array_equal(x, y) for x, y in zip(ref, got))
+        assert same, "the VALU and the FP4 best-2 kernels disagree"
+        pairs = float(n) * n
+        r = {"one_problem_ms": round(ms1, 4), "one_problem_gpairs_per_s": round(pairs / (ms1 * 1e-3) / 1e9, 1),
+             "problems_per_launch": P, "launch_ms": round(msP, 4), "gpairs_per_s": round(P * pairs / (msP * 1e-3) / 1e9, 1)}
+        if variant == "fp4":
+            tops = P * pairs * 512 / (msP * 1e-3) / 1e12
+            r.update({"kernel": "k_best2_fp4 (v_mfma_f32_32x32x64_f8f6f4)", "achieved_TOPS": round(tops, 1), "peak_TOPS": MFMA_FP4_PEAK_TOPS,
+                      "frac_of_dense_fp4_peak": round(tops / MFMA_FP4_PEAK_TOPS, 3)})
+        else:
+            r.update({"kernel": "k_best2 (v_xor_b32 + v_bcnt_u32_b32, the parity twin)", "peak_gpairs_per_s": round(VALU_POPCOUNT_PEAK_GPAIRS, 1),
+                      "frac_of_valu_popcount_peak": round(P * pairs / (msP * 1e-3) / 1e9 / VALU_POPCOUNT_PEAK_GPAIRS, 3),
+                      "peak_note": "64 pairs per (8 v_xor at 850 + 8 v_bcnt at 568.4 G wave-instr/s), profiles/r02_valu_ops2.txt; "
+                                   "the kernel also issues a shift-or, a med3 and a min per pair for the two running keys",
+                      "equal_to_fp4_outputs": same})
+        out["best2_" + variant] = r
+    # the whole SearchByBow (node join, top-8 lists, greedy resolve, rotation histogram) with all features in ONE node
+    rng = np.random.RandomState(0)
+    k1, k2 = np.zeros(n, KP_DTYPE), np.zeros(n, KP_DTYPE)
+    k1["angle"], k2["angle"] = rng.uniform(0, 360, n).astype(np.float32), rng.uniform(0, 360, n).astype(np.float32)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    kp = lambda k: torch.from_numpy(np.frombuffer(k.tobytes(), np.uint8).copy()).to(dev)  # noqa: E731
+
+    def dev_fv(fv):
+        nodes, off, idx = fv
+        pad = lambda x, dt, m: torch.from_numpy(np.concatenate([np.asarray(x, dt), np.zeros(max(m - len(x), 0), dt)])).to(dev)  # noqa: E731
+        return (pad(nodes, np.uint32, n).view(torch.int32), pad(off, np.int32, n + 1), pad(idx, np.uint32, n).view(torch.int32),
+                torch.tensor([len(nodes)], dtype=torch.int32, device=dev))
+    d = dict(desc1=up(a), kps1=kp(k1), kf_mp_ok=up(np.ones(n, np.uint8)), fv1=dev_fv(synth.feature_vector_by_prefix(a, 0)), desc2=up(b),
+             kps2=kp(k2), frame_mp=torch.full((n,), -1, dtype=torch.int32, device=dev), fv2=dev_fv(synth.feature_vector_by_prefix(b, 0)),
+             result=torch.zeros(8, dtype=torch.int32, device=dev))
+    m = ORBMatcher(0.7, True, handle=MatcherHandle(device=device_index))
+
+    def bow():
+        d["frame_mp"].fill_(-1)
+        m.SearchByBowDevice(d, n, n, stream=st.cuda_stream)
+    ms = timed(bow)
+    res = d["result"].cpu().numpy()
+    out["search_by_bow_device"] = {"ms": round(ms, 4), "matches": int(res[0]), "sweeps": int(res[2]),
+                                   "gpairs_per_s": round(float(n) * n / (ms * 1e-3) / 1e9, 1),
+                                   "note": "orbm_search_by_bow_device, one vocabulary node holding all 2000 x 2000 pairs "
+                                           "(the clearing of frame_mp included); ORBMatcher.cpp:118-201"}
+    return out
+
+
+def bench_config5(device_index):
+    """BASELINE config 5 (local BA, 20 key frames x 3000 map points): one linearisation -- per-edge reprojection residual and
+    Jacobians (k_ba_edges) + the block J^T W J reductions (k_ba_reduce_pose / k_ba_reduce_point) -- by the HIP events of
+    orbba_linearize, against SURVEY 8(d)'s byte count; and the whole Optimize::localBundleAdjustment loop."""
+    from monoorbslam3_amd import ba, synth
+    pr = synth.make_ba_problem(20, 3000)
+    args5 = (pr["cam"], pr["pose_R"], pr["pose_t"], pr["pose_fixed"], pr["points"], pr["edge_pose"], pr["edge_point"], pr["edge_z"],
+             pr["edge_inv_sigma2"])
+    ne, n_p, n_l = len(pr["edge_pose"]), 20, 3000
+    ks, ws = [], []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        g = ba.linearize(*args5)
+        ws.append((time.perf_counter() - t0) * 1e3)
+        ks.append(g["kernel_ms"])
+    k_ms = sorted(ks[2:])[len(ks[2:]) // 2]
+    # SURVEY 8(d): per edge read 8 (indices) + 16 (z) + 8 (inv sigma^2) + gathers 96 (pose) + 24 (point), write H_pl 144;
+    # reductions 20 x (36 + 6) x 8 + 3000 x (9 + 3) x 8
+    alg = ne * (8 + 16 + 8 + 96 + 24 + 144) + n_p * 42 * 8 + n_l * 12 * 8
+    gbs = alg / (k_ms * 1e-3) / 1e9
+    lb = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        got = ba.local_bundle_adjustment(*args5)
+        lb.append(((time.perf_counter() - t0) * 1e3, got["device_ms"]))
+    lb = sorted(lb[1:])[1]
+    return {"poses": n_p, "points": n_l, "edges": int(ne),
+            "linearize_kernels_ms": round(k_ms, 4), "linearize_call_ms": round(sorted(ws[2:])[len(ws[2:]) // 2], 3),
+            "algorithmic_bytes_per_launch": int(alg), "achieved_GBps": round(gbs, 1), "peak_GBps": HBM_PEAK_GBS,
+            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "dtype": "f64",
+            "bound_note": "three dependent launches of %d / %d / %d workgroups of 256 threads on 256 CUs: launch- and latency-bound, the "
+                          "machine is never full" % ((ne + 255) // 256, n_p, (n_l + 255) // 256),
+            "local_bundle_adjustment_call_ms": round(lb[0], 3), "local_bundle_adjustment_device_ms": round(lb[1], 3),
+            "timed_by": "kernels: HIP events inside orbba_linearize on the call's stream (median of 5); calls: host clock, host arrays in and out"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +326,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-match", action="store_true", help="time extraction only")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the extra (untimed) keys config3 (2000 x 2000 Hamming best-2 / SearchByBow) and config5 (local BA 20 x 3000)")
     ap.add_argument("--no-density-sweep", action="store_true",
                     help="skip the extra (untimed) extraction runs on frames with about a tenth and a third of the headline workload's corner density")
     ap.add_argument("--match-placement", default=None, choices=["after-fast", "eager"],
@@ -504,9 +641,39 @@ def main():
         torch.cuda.synchronize()
         dte = time.perf_counter() - t0
         h2d, d2h = B * W * H, B * (4 + cap * 60)
-        e2e = {"value": round(B * args.steps / dte, 2), "unit": "frames/s", "ms_per_step": round(dte / args.steps * 1e3, 4),
+        # each direction alone and both at once with no kernel running: says whether the step is bound by max(H2D, D2H) -- the
+        # copies overlap -- or by their sum -- one engine or one link direction at a time
+        def copies_ms(do_in, do_out, n=4):
+            torch.cuda.synchronize()
+            t0c = time.perf_counter()
+            for k in range(n):
+                i = k % NBUF
+                if do_in:
+                    with torch.cuda.stream(cp_in):
+                        d_in[i].copy_(h_in, non_blocking=True)
+                if do_out:
+                    with torch.cuda.stream(cp_out):
+                        h_out[i][0].copy_(d_n[i], non_blocking=True)
+                        h_out[i][1].copy_(d_kp[i], non_blocking=True)
+                        h_out[i][2].copy_(d_desc[i], non_blocking=True)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0c) / n * 1e3
+        copies_ms(True, True, 1)
+        h2d_ms, d2h_ms, both_ms = copies_ms(True, False), copies_ms(False, True), copies_ms(True, True)
+        e2e_ms = dte / args.steps * 1e3
+        overlap = both_ms < 0.5 * (max(h2d_ms, d2h_ms) + h2d_ms + d2h_ms)   # nearer to the maximum than to the sum
+        e2e = {"value": round(B * args.steps / dte, 2), "unit": "frames/s", "ms_per_step": round(e2e_ms, 4),
                "h2d_bytes_per_step": int(h2d), "d2h_bytes_per_step": int(d2h),
                "pcie_GBps": round((h2d + d2h) * args.steps / dte / 1e9, 2),
+               "h2d_alone": {"ms_per_step": round(h2d_ms, 4), "GBps": round(h2d / (h2d_ms * 1e-3) / 1e9, 2)},
+               "d2h_alone": {"ms_per_step": round(d2h_ms, 4), "GBps": round(d2h / (d2h_ms * 1e-3) / 1e9, 2)},
+               "both_directions_no_kernels": {"ms_per_step": round(both_ms, 4), "GBps": round((h2d + d2h) / (both_ms * 1e-3) / 1e9, 2),
+                                              "copies_overlap": bool(overlap)},
+               "explained": ("ms_per_step %.2f against max(H2D, D2H) = %.2f, H2D + D2H = %.2f, both directions at once %.2f and the "
+                             "HBM-resident step %.2f ms: %s" % (
+                                 e2e_ms, max(h2d_ms, d2h_ms), h2d_ms + d2h_ms, both_ms, dt / args.steps * 1e3,
+                                 "the two directions overlap; the step is bound by the longer copy" if overlap else
+                                 "the two directions do NOT overlap (one copy at a time on this box: the step is their sum)")),
                "note": "inputs from pinned host memory, records (fixed capacity) back to pinned host memory, double-buffered "
                        "on copy streams; PCIe-bound -- `value` is the HBM-resident rate"}
         assert int(h_out[(args.steps - 1) % NBUF][0][0]) > 0
@@ -765,6 +932,9 @@ def main():
         "stages_ms_in_step": {k: round(v, 4) for k, v in in_step.items()},
         "dominant_rule": "the extraction stage with the largest time inside an overlapped step (stages_ms_in_step); the match runs "
                          "beside the extraction on its own stream and counts only if it outlasts the whole extraction",
+        "dominant_rule_history": "round 5 changed the rule (rounds 1-4: the stage with the largest in-step time, the match counted like "
+                                 "any other stage); roofline_longest_in_step_stage keeps that older rule's answer beside `roofline`",
+        "roofline_longest_in_step_stage": roof(max(in_step, key=lambda k: in_step[k])),
         "density_sweep": density,
         "roofline": roof(dominant),
         "roofline_fast": roof("fast"),
@@ -777,6 +947,12 @@ def main():
     }
     if e2e is not None:
         out["value_end_to_end"] = e2e
+    if world == 1 and not args.no_extra_configs:
+        # BASELINE configs 3 and 5 beside the headline: extra keys, outside the timed region
+        del frames
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        out["config3"] = bench_config3(dev, local_rank)
+        out["config5"] = bench_config5(local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(base, NF, min(16, os.cpu_count() or 1), not args.no_match)
     if rank == 0:

@@ -34,9 +34,13 @@ typedef struct orbd_comm orbd_t;
  * a torch.distributed store, a socket) before orbd_create. */
 int orbd_unique_id(uint8_t id[ORBD_ID_BYTES]);
 
-/* ncclCommInitRank on `device` (a HIP ordinal; -1 = the current one).  Collective: every rank calls it. */
+/* ncclCommInitRank on `device` (a HIP ordinal; -1 = the current one).  Collective: every rank calls it.  Fails
+ * (ORBX_E_NO_DEVICE, the text names both pairs) when the communicator RCCL built reports another rank or size than the
+ * arguments (ncclCommUserRank / ncclCommCount). */
 int orbd_create(int rank, int world, const uint8_t id[ORBD_ID_BYTES], int device, orbd_t **out);
 void orbd_destroy(orbd_t *c);
+/* What the communicator itself reports -- ncclCommUserRank / ncclCommCount asked on every call, not the arguments of
+ * orbd_create: a short world on a real node shows here.  -1 / 0 for a NULL handle or when RCCL refuses. */
 int orbd_rank(const orbd_t *c);
 int orbd_world(const orbd_t *c);
 

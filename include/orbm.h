@@ -233,8 +233,14 @@ int orbm_search_by_projection_points_device(orbm_t *h, float nn_ratio, const uin
  * stay in it, as in the reference -- and ComputeThreeMaxima all run on the device; the result equals the host entry point's.
  * Limits: n2 + 5 n1 <= 38400 (the claims live in LDS), list_cap entries per query on average (pool of n1 * list_cap).
  * d_result (int32 x 8): [0] matches, [1] = 1 when the lists overflowed the pool (d_matches12 all -1, d_pre untouched: repeat with
- * a larger list_cap or use the host entry point), [2] sweeps of the fixed point, [3] list entries.
+ * a larger list_cap or use the host entry point), [1] = 2 when the fixed point had not settled after ORBM_INIT_MAX_SWEEPS sweeps
+ * (same guarantee: nothing written; use the host entry point), [2] sweeps of the fixed point, [3] list entries.
+ * Cost: ONE workgroup resolves the search; a sweep walks every level-0 feature's window list (a 100-px window over 2000 features
+ * holds tens of candidates) times the claimant chains.  Measured (profiles/r06_match_latency.txt): 3 sweeps on two extracted
+ * views, 5 on a crowded scene of near-duplicates; the proof's bound is n1 + 1 sweeps, the cap keeps a pathological scene from
+ * holding a CU for milliseconds.
  * Enqueued on `stream` (NULL: orbx.h, "Streams"); one call in flight per handle. */
+#define ORBM_INIT_MAX_SWEEPS 64
 int orbm_search_for_initialization_device(orbm_t *h, float nn_ratio, int check_orientation, const void *d_kps1, const uint8_t *d_desc1,
                                           int n1, const void *d_kps2, const uint8_t *d_desc2, const int32_t *d_cell_start2,
                                           const int32_t *d_cell_items2, int grid_cols, int grid_rows, int n2, float *d_pre,

@@ -21,6 +21,8 @@ struct Rccl {
     int (*GetUniqueId)(nccl_id *) = nullptr;
     int (*CommInitRank)(nccl_comm *, int, nccl_id, int) = nullptr;
     int (*CommDestroy)(nccl_comm) = nullptr;
+    int (*CommCount)(const nccl_comm, int *) = nullptr;
+    int (*CommUserRank)(const nccl_comm, int *) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
@@ -40,7 +42,8 @@ struct Rccl {
     *(void **)(&field) = dlsym(so, name);                                            \
     if (!field) { err = std::string("librccl lacks ") + name; so = nullptr; return false; }
         ORBD_SYM(GetUniqueId, "ncclGetUniqueId") ORBD_SYM(CommInitRank, "ncclCommInitRank")
-        ORBD_SYM(CommDestroy, "ncclCommDestroy") ORBD_SYM(GroupStart, "ncclGroupStart") ORBD_SYM(GroupEnd, "ncclGroupEnd")
+        ORBD_SYM(CommDestroy, "ncclCommDestroy") ORBD_SYM(CommCount, "ncclCommCount") ORBD_SYM(CommUserRank, "ncclCommUserRank")
+        ORBD_SYM(GroupStart, "ncclGroupStart") ORBD_SYM(GroupEnd, "ncclGroupEnd")
         ORBD_SYM(Send, "ncclSend") ORBD_SYM(Recv, "ncclRecv") ORBD_SYM(AllGather, "ncclAllGather")
         ORBD_SYM(GetErrorString, "ncclGetErrorString")
 #undef ORBD_SYM
@@ -93,7 +96,18 @@ extern "C" int orbd_create(int rank, int world, const uint8_t id[ORBD_ID_BYTES],
     memcpy(u.internal, id, ORBD_ID_BYTES);
     nccl_comm comm = nullptr;
     D_NCCL(g_rccl.CommInitRank(&comm, world, u, rank), "ncclCommInitRank");
-    orbd_comm *c = new orbd_comm{rank, world, device, comm};
+    // rank and world are what the COMMUNICATOR reports (ncclCommUserRank / ncclCommCount), not what the caller passed: a short
+    // world shows in orbd_world(), and a communicator that disagrees with the arguments is refused here
+    int c_world = -1, c_rank = -1;
+    int rc = g_rccl.CommCount(comm, &c_world);
+    if (rc == 0) rc = g_rccl.CommUserRank(comm, &c_rank);
+    if (rc != 0 || c_world != world || c_rank != rank) {
+        (void)g_rccl.CommDestroy(comm);
+        if (rc != 0) return rccl_fail("ncclCommCount / ncclCommUserRank", rc);
+        return orbx_set_error(ORBX_E_NO_DEVICE, "RCCL reports rank " + std::to_string(c_rank) + " of " + std::to_string(c_world) +
+                                                    ", orbd_create was given rank " + std::to_string(rank) + " of " + std::to_string(world));
+    }
+    orbd_comm *c = new orbd_comm{c_rank, c_world, device, comm};
     *out = c;
     return ORBX_OK;
 }
@@ -105,8 +119,17 @@ extern "C" void orbd_destroy(orbd_t *c)
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     delete c;
 }
-extern "C" int orbd_rank(const orbd_t *c) { return c ? c->rank : -1; }
-extern "C" int orbd_world(const orbd_t *c) { return c ? c->world : 0; }
+// asked of RCCL on every call (ncclCommUserRank / ncclCommCount); -1 / 0 without a handle or when RCCL refuses
+extern "C" int orbd_rank(const orbd_t *c)
+{
+    int r = -1;
+    return (c && c->comm && g_rccl.CommUserRank && g_rccl.CommUserRank(c->comm, &r) == 0) ? r : -1;
+}
+extern "C" int orbd_world(const orbd_t *c)
+{
+    int n = 0;
+    return (c && c->comm && g_rccl.CommCount && g_rccl.CommCount(c->comm, &n) == 0) ? n : 0;
+}
 
 extern "C" int orbd_shard_count(int n_frames, int rank, int world)
 {

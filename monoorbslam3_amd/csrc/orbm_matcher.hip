@@ -1014,8 +1014,8 @@ __global__ __launch_bounds__(PR_T) void k_init_resolve(const int32_t *__restrict
                                                        const uint32_t *__restrict__ pool, int pool_cap,
                                                        const int32_t *__restrict__ total, int n1, int n2,
                                                        const orbx_kp *__restrict__ kps1, const orbx_kp *__restrict__ kps2,
-                                                       float nn_ratio, int check_orientation, int32_t *__restrict__ matches12,
-                                                       float *__restrict__ pre, int32_t *__restrict__ result)
+                                                       float nn_ratio, int check_orientation, int max_sweeps,
+                                                       int32_t *__restrict__ matches12, float *__restrict__ pre, int32_t *__restrict__ result)
 {
     extern __shared__ int32_t ir_lds[];
     // head[n2]; next, the claims (a_c, a_d) and a sweep's new claims (n_c, n_d) [n1 each]
@@ -1067,7 +1067,15 @@ __global__ __launch_bounds__(PR_T) void k_init_resolve(const int32_t *__restrict
         for (int i = tid; i < n1; i += PR_T)
             if (n_c[i] != a_c[i] || (n_c[i] >= 0 && n_d[i] != a_d[i])) { a_c[i] = n_c[i]; a_d[i] = n_d[i]; changed = 1; }
         ++sweeps;
-        if (!__syncthreads_or(changed) || sweeps > n1 + 1) break;
+        if (!__syncthreads_or(changed)) break;
+        // One workgroup runs the whole search, and a sweep walks every query's window list times the claimant chains.  The fixed
+        // point is reached after 3 sweeps on two extracted views and 5 on a crowded scene of near-duplicates (the proof bounds it
+        // by n1 + 1); a scene that needs more than ORBM_INIT_MAX_SWEEPS hands the search back instead of holding a CU for
+        // milliseconds: result[1] = 2, nothing written (matches12 all -1, pre untouched) -- the host entry point takes it.
+        if (sweeps >= max_sweeps) {
+            if (tid == 0) { result[0] = 0; result[1] = 2; result[2] = sweeps; result[3] = tot; }
+            return;
+        }
     }
     // (head / next of the last sweep belong to the stable claims)
     // ---- rotation histogram of every accepted query (:84-91), then the holders: a candidate's LAST claimant (:75-81)
@@ -1198,27 +1206,34 @@ __global__ __launch_bounds__(BQ_T) void k_bow_queries(BowFv f1, BowFv f2, const 
         if (tid == BQ_T - 1) s_base += s_part[tid];
         __syncthreads();
     }
+    // A node of side 1 WITHOUT entries (a caller-built CSR may hold one; orbv_transform_device never writes one) got no first-query
+    // index above: it takes the next node's, so that every node's extent is [node_qbegin[p], node_qbegin[p + 1]) -- empty for such
+    // a node -- here and in k_bow_resolve alike, and no stale scratch of an earlier call is ever read as a begin.
+    const int total = min(s_base, n1);
+    for (int p1 = tid; p1 < nn1; p1 += BQ_T) {
+        if (f1.off[p1 + 1] > f1.off[p1]) continue;
+        int nx = p1 + 1; // the next node that has entries (its begin was written by the entry loop, and is not written here)
+        while (nx < nn1 && f1.off[nx + 1] <= f1.off[nx]) ++nx;
+        node_qbegin[p1] = nx < nn1 ? node_qbegin[nx] : total;
+    }
+    if (tid == 0) node_qbegin[nn1] = total;
+    __syncthreads();
     // A shared node with more features on either side than k_bow_resolve keeps state for (BR_MAX_NODE) cannot be resolved on the
     // device.  It is found HERE, before anything is written: the call then reports result[1] = 1 with no query at all, so that
     // k_topk_lists_n, k_bow_resolve and k_bow_finish have nothing to do and frame_mp / matches12 stay exactly as the caller
     // passed them -- the host entry point can still reproduce the reference's loop on them (the guarantee the projection
-    // searches give on overflow).  Same node extents as k_bow_resolve computes.
-    const int total = min(s_base, n1);
+    // searches give on overflow).  The node extents are the ones k_bow_resolve computes.
     int too_big = 0;
     for (int p1 = tid; p1 < nn1; p1 += BQ_T) {
         const int p2 = node_p2[p1];
-        if (p2 < 0 || f1.off[p1 + 1] <= f1.off[p1]) continue; // (a node without entries has no query and no first-query index)
-        const int qb = node_qbegin[p1];
-        int nx = p1 + 1; // the next node that has entries: its first query ends this node's
-        while (nx < nn1 && f1.off[nx + 1] <= f1.off[nx]) ++nx;
-        const int qe = min(nx < nn1 ? node_qbegin[nx] : total, total);
+        if (p2 < 0) continue;
+        const int qb = node_qbegin[p1], qe = min(node_qbegin[p1 + 1], total);
         if (qe - qb > BR_MAX_NODE || f2.off[p2 + 1] - f2.off[p2] > BR_MAX_NODE) too_big = 1;
     }
     too_big = __syncthreads_or(too_big);
     if (tid == 0) {
         *n_queries = too_big ? 0 : total;
         if (too_big) result[1] = 1;
-        node_qbegin[nn1] = 0x7fffffff; // (never read as a begin: the resolve kernel ends a node at the next begin or n_queries)
     }
 }
 
@@ -1280,13 +1295,14 @@ __global__ __launch_bounds__(BR_T) void k_bow_resolve(BowFv f1, BowFv f2, int ma
     for (int p1 = blockIdx.x; p1 < nn1; p1 += gridDim.x) {
         const int p2 = node_p2[p1];
         if (p2 < 0) continue;
-        const int qb = node_qbegin[p1];
-        int qe = p1 + 1 < nn1 ? node_qbegin[p1 + 1] : nq_all;
-        qe = min(qe, nq_all);
+        const int qb = node_qbegin[p1], qe = min(node_qbegin[p1 + 1], nq_all); // (k_bow_queries wrote a begin for EVERY node and for nn1)
         const int nq = qe - qb;
         if (nq <= 0) continue;
         const int cb = f2.off[p2], nc = f2.off[p2 + 1] - cb;
-        if (nq > BR_MAX_NODE || nc > BR_MAX_NODE) continue; // (never taken: k_bow_queries leaves no query at all when a node is this large)
+        if (nq > BR_MAX_NODE || nc > BR_MAX_NODE) { // never taken (k_bow_queries leaves no query at all when a node is this large); reported if it ever is
+            if (tid == 0) result[1] = 1;
+            continue;
+        }
         __syncthreads(); // (the previous node's state is no longer read)
         // initially free candidates: SearchByBow -- no map point yet (:150); triangulation -- no map point on side 2 (:466)
         for (int t = tid; t < nc; t += BR_T) {
@@ -2508,7 +2524,8 @@ extern "C" int orbm_search_for_initialization_device(orbm_t *c, float nn_ratio, 
                        d_counts, d_pool, d_total, d_offs);
     M_TRY(orbx_lds_opt_in(reinterpret_cast<const void *>(k_init_resolve), 150 * 1024));
     hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(PR_T), lds, s, d_counts, d_offs, d_pool, (int)std::min(pool_cap, (size_t)INT_MAX), d_total,
-                       n1, n2, (const orbx_kp *)d_kps1, (const orbx_kp *)d_kps2, nn_ratio, check_orientation, d_matches12, d_pre, d_result);
+                       n1, n2, (const orbx_kp *)d_kps1, (const orbx_kp *)d_kps2, nn_ratio, check_orientation, ORBM_INIT_MAX_SWEEPS, d_matches12, d_pre,
+                       d_result);
     M_TRY(hipGetLastError());
     return ORBX_OK;
 }

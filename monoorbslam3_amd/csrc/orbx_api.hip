@@ -51,6 +51,8 @@ hipError_t orbx_lds_opt_in(const void *kernel, size_t bytes)
 struct orbx_ctx {
     orbx_cfg cfg;
     int device;
+    int n_cus = ORBX_N_CUS; // the device's CU count (hipDeviceAttributeMultiprocessorCount at create): decides whether a few-frames
+                            // quadtree launch gives every workgroup a CU of its own (orbx_octree_plan)
     // reference tables (ORBExtractor.h:109-121)
     float scale_factors[ORBX_MAX_LEVELS], inv_scale_factors[ORBX_MAX_LEVELS];
     float square_sigmas[ORBX_MAX_LEVELS], inv_square_sigmas[ORBX_MAX_LEVELS];
@@ -487,6 +489,7 @@ static int create_common(const orbx_cfg *cfg, const int *quotas_override, orbx_t
     c->cur_w = c->cur_h = -1;
     auto cleanup = [&](int code) { orbx_destroy(c); return code; };
     if (hipSetDevice(dev) != hipSuccess) return cleanup(fail(ORBX_E_NO_DEVICE, "hipSetDevice failed"));
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) c->n_cus = cus; }
     // The handle's own stream serves the HOST-POINTER entry points only (a NULL stream argument of a device entry point is
     // stream 0 itself) and is NON-BLOCKING: such a call uploads, computes, downloads and waits on it, so nothing of it has to be
     // ordered with the legacy stream -- and a blocking stream would make every legacy-stream operation of any thread of the
@@ -795,7 +798,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         auto launch_side = [&]() -> int {
             HIP_TRY(hipStreamWaitEvent(c->side[slot], c->ev_start[slot], 0));
             launch_fast(c->side[slot], d_units, cells_before[G]);
-            orbx_launch_octree(c->side[slot], c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, G);
+            orbx_launch_octree(c->side[slot], c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, G, c->n_cus);
             HIP_TRY(hipEventRecord(c->ev_fast0[slot], c->side[slot]));
             return ORBX_OK;
         };
@@ -812,7 +815,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
         }
         HIP_TRY(hipEventRecord(c->ev_pyr[bslot], s));
         if (cells_before[L] > cells_before[G]) launch_fast(s, d_units + 4 * cells_before[G], cells_before[L] - cells_before[G]);
-        orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, G, L);
+        orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, G, L, c->n_cus);
         if (!side_first) { int rc = launch_side(); if (rc) return rc; }
         HIP_TRY(hipStreamWaitEvent(c->side[bslot], c->ev_pyr[bslot], 0));
         launch_blur(c->side[bslot], 0, L);
@@ -866,7 +869,7 @@ static int enqueue(orbx_ctx *c, hipStream_t s, const uint8_t *d_l0, size_t l0_fs
     if (t) HIP_TRY(hipEventRecord(c->ev[3], s));
     {
         InStep ot(c, ORBX_STAGE_OCTREE, s);
-        orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, L);
+        orbx_launch_octree(s, c->d_levels, LV, b, n_frames, c->sort_lds_bytes, 0, L, c->n_cus);
     }
     if (t) HIP_TRY(hipEventRecord(c->ev[4], s));
     if (side && c->side_blur >= 3) { int rc = fork_blur(); if (rc) return rc; } // next to the orientation only

@@ -135,11 +135,11 @@ void orbx_launch_desc_fused(hipStream_t s, const uint8_t *l0, size_t l0_fs, int 
                             orbx_kp *out_kp, uint8_t *out_desc, int cap, int n_frames);
 #define ORBX_OCT_LDS_LIMIT (160 * 1024 - 256)  // the LDS-resident node list of a level must fit this (else the global-scratch build)
 #define ORBX_OCT_HUGE_LDS (160 * 1024 - 1024)  // what the 1024-thread build is launched with: list arrays + count pyramid
-#define ORBX_N_CUS 256                         // MI355X
+#define ORBX_N_CUS 256                         // MI355X: the default of the device-less planning query; a handle asks its device (orbx_create)
 struct OrbxOctPlan { int kind; size_t lds_bytes, huge_bytes; int huge_end; };
-OrbxOctPlan orbx_octree_plan(const OrbxLevels &levels, int n_frames, int level_begin, int level_end);
+OrbxOctPlan orbx_octree_plan(const OrbxLevels &levels, int n_frames, int level_begin, int level_end, int n_cus = ORBX_N_CUS);
 void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLevels &levels, const OrbxBuffers &b,
-                        int n_frames, size_t sort_lds_bytes, int level_begin, int level_end);
+                        int n_frames, size_t sort_lds_bytes, int level_begin, int level_end, int n_cus = ORBX_N_CUS);
 void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int l0_pitch, const OrbxLevels *d_levels,
                              const OrbxLevels &levels, const OrbxBuffers &b, const int *u_max, orbx_kp *out_kp,
                              uint8_t *out_desc, int cap, int32_t *out_n, int n_frames, hipEvent_t blur_done, int desc_level_min = 0,

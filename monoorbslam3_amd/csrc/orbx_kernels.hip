@@ -518,7 +518,6 @@ __global__ __launch_bounds__(64 * CPW) void k_fast_cells_wave(FastSrc src, const
                                                               size_t cand_fs, int *__restrict__ cand_count, int n_cells,
                                                               int n_frames)
 {
-    constexpr int T = 64 * CPW;
     static_assert(CPW >= 1 && CPW <= 16, "at most 16 waves per workgroup");
     __shared__ __align__(16) uint8_t s_tile[CPW][36 * FC_TP];
     __shared__ __align__(16) uint8_t s_score[CPW][32 * FC_SP];
@@ -1822,7 +1821,7 @@ size_t orbx_octree_lds_bytes(const OrbxLevels &levels)
 //   kind 0: oct_batch::k_octree_lds (256 threads; resident batches)      kind 1: oct_wide::k_octree_lds (512 threads)
 //   kind 2: oct_huge::k_octree_lds (1024 threads, count pyramid) for levels [level_begin, huge_end), kind 1 for the rest
 //   kind 3: oct_wide::k_octree (node list in global scratch: quotas too large for the LDS-resident list)
-OrbxOctPlan orbx_octree_plan(const OrbxLevels &levels, int n_frames, int level_begin, int level_end)
+OrbxOctPlan orbx_octree_plan(const OrbxLevels &levels, int n_frames, int level_begin, int level_end, int n_cus)
 {
     OrbxOctPlan p;
     p.lds_bytes = orbx_octree_lds_bytes(levels); // the largest level's, whatever the range: one configuration
@@ -1846,16 +1845,16 @@ OrbxOctPlan orbx_octree_plan(const OrbxLevels &levels, int n_frames, int level_b
         // large ones: a single frame waits for the longest level, not for the sum).  With more workgroups than CUs a
         // 1024-thread, whole-LDS workgroup per small level would queue behind the others: those levels go to the 512-thread
         // build in a second launch.
-        p.huge_end = (size_t)(level_end - level_begin) * (size_t)n_frames > (size_t)ORBX_N_CUS ? lh : level_end;
+        p.huge_end = (size_t)(level_end - level_begin) * (size_t)n_frames > (size_t)(n_cus > 0 ? n_cus : ORBX_N_CUS) ? lh : level_end;
     }
     return p;
 }
 
 void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLevels &levels, const OrbxBuffers &b,
-                        int n_frames, size_t sort_lds_bytes, int level_begin, int level_end)
+                        int n_frames, size_t sort_lds_bytes, int level_begin, int level_end, int n_cus)
 {
     if (level_end <= level_begin) return;
-    const OrbxOctPlan p = orbx_octree_plan(levels, n_frames, level_begin, level_end);
+    const OrbxOctPlan p = orbx_octree_plan(levels, n_frames, level_begin, level_end, n_cus);
     const int lds = (int)p.lds_bytes;
     dim3 grid(level_end - level_begin, n_frames);
     switch (p.kind) {

@@ -70,7 +70,10 @@ def test_c_abi_record_exchange_world1():
     ex.extract_batch_device(frames.data_ptr(), B, w, h, w, w * h, d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(),
                             side.cuda_stream)
     xc = D.RecordExchange(0, 1, D.RecordExchange.unique_id(), device=0)
+    # both are asked of RCCL (ncclCommUserRank / ncclCommCount), and orbd_create refused a communicator that disagreed
     assert (xc._L.orbd_rank(xc._h), xc._L.orbd_world(xc._h)) == (0, 1)
+    assert xc.world_reported() == 1
+    assert (xc._L.orbd_rank(None), xc._L.orbd_world(None)) == (-1, 0)
     got = xc.gather(d_n, d_kp, d_desc, root=0, stream=side.cuda_stream)
     allg = xc.allgather(d_n, d_kp, d_desc, stream=side.cuda_stream)
     side.synchronize()

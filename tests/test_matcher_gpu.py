@@ -605,6 +605,57 @@ def test_search_by_bow_and_triangulation_on_the_device(oracle_mod, check_ori):
     assert d["result"].cpu().numpy()[0] == 0
 
 
+def test_bow_searches_on_the_device_with_entry_less_nodes(oracle_mod):
+    """A caller-built FeatureVector may hold a node without entries (orbv_transform_device never writes one).  k_bow_queries gives
+    EVERY node a first-query index, so k_bow_resolve's extents [begin[p], begin[p + 1]) never read the scratch an earlier call left
+    behind: empty nodes at the front, in the middle (two in a row) and at the end of side 1, after a call of another shape has
+    filled the handle's scratch; results equal the oracle's loops (ORBMatcher.cpp:136-185, :448-506 skip such a node)."""
+    import torch
+    from monoorbslam3_amd.extractor import KP_DTYPE
+    from monoorbslam3_amd.matcher import MatcherHandle, ORBMatcher
+    dev = torch.device("cuda", 0)
+    mh = MatcherHandle(device=0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kp = lambda k: torch.from_numpy(np.frombuffer(k.tobytes(), np.uint8).copy()).to(dev)  # noqa: E731
+    m = ORBMatcher(0.8, False, handle=mh)
+
+    def run(a, b, fv1, fv2):
+        n1, n2 = len(a), len(b)
+        k1, k2 = np.zeros(n1, KP_DTYPE), np.zeros(n2, KP_DTYPE)
+        ok, mp0 = np.ones(n1, np.uint8), np.full(n2, -1, np.int32)
+        h1, h2 = np.zeros(n1, np.uint8), np.zeros(n2, np.uint8)
+        d = dict(desc1=up(a), kps1=kp(k1), kf_mp_ok=up(ok), fv1=_dev_fv(fv1, torch, dev, n1 + 8), desc2=up(b), kps2=kp(k2), frame_mp=up(mp0),
+                 fv2=_dev_fv(fv2, torch, dev, n2 + 8), result=torch.zeros(8, dtype=torch.int32, device=dev), has_mp1=up(h1), has_mp2=up(h2),
+                 matches12=torch.full((n1,), -5, dtype=torch.int32, device=dev))
+        z1, z2 = np.zeros(n1, np.float32), np.zeros(n2, np.float32)
+        n_ref, mp_ref = oracle_mod.search_by_bow(0.8, False, a, z1, ok, fv1, b, z2, mp0, fv2)
+        m.SearchByBowDevice(d, n1, n2)
+        res = d["result"].cpu().numpy()
+        assert res[1] == 0 and res[0] == n_ref and np.array_equal(d["frame_mp"].cpu().numpy(), mp_ref)
+        t_ref, m_ref = oracle_mod.search_for_triangulation(False, a, z1, h1, fv1, b, z2, h2, fv2)
+        m.SearchForTriangulationDevice(d, n1, n2)
+        res = d["result"].cpu().numpy()
+        assert res[1] == 0 and res[0] == t_ref and np.array_equal(d["matches12"].cpu().numpy(), m_ref)
+        return n_ref, t_ref
+
+    # a first call of another shape leaves its begins in the scratch
+    a0, b0, _ = synth.make_descriptor_pair(1500, seed=3)
+    run(a0, b0, synth.feature_vector_by_prefix(a0, 6), synth.feature_vector_by_prefix(b0, 6))
+    a, b, _ = synth.make_descriptor_pair(900, seed=8)
+    pa, pb = a[:, 0] & 15, b[:, 0] & 15                      # feature_vector_by_prefix(., 4) buckets by these bits
+    nodes1, off1, idx1 = synth.feature_vector_by_prefix(a, 4)
+    nodes2, off2, idx2 = synth.feature_vector_by_prefix(b, 4)
+    assert len(nodes1) == 16 and len(nodes2) == 16 and sorted(set(pa)) == list(range(16)) and sorted(set(pb)) == list(range(16))
+    # side 1 loses the entries of nodes 0, 7, 8 and 15 but keeps the nodes
+    lists = [list(idx1[off1[i]:off1[i + 1]]) for i in range(16)]
+    for i in (0, 7, 8, 15):
+        lists[i] = []
+    off_e = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int32)
+    idx_e = np.array([j for x in lists for j in x], np.uint32)
+    n_ref, t_ref = run(a, b, (np.asarray(nodes1, np.uint32), off_e, idx_e), (nodes2, off2, idx2))
+    assert n_ref > 100 and t_ref > 100
+
+
 def test_search_fuse(oracle_mod):
     """Per-point core of the static fuse SearchByProjection(keyFrame, mapPoints, Map*, th) (ORBMatcher.cpp:524-592):
     KeyFrame window with the strict test, chi-square gate, closest descriptor at distance <= TH_LOW."""

@@ -110,6 +110,50 @@ print("SearchByProjection(map points -> frame), %d queries: %.3f ms" % (n1, ms))
 pre = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
 ms = timeit(lambda: m9.SearchForInitialization(k1, d1, k2, d2, w, h, pre.copy(), 100))
 print("SearchForInitialization (window 100): %.3f ms" % ms)
+# ---- SearchForInitialization resolved on the device (one workgroup, k_init_resolve): device time by HIP events on the call's
+# stream for two extracted views, a crowded scene of near-duplicates and the worst case the limits allow -- every level-0 feature of
+# both frames inside ONE 100-px window, descriptors from 8 clusters (each list holds every candidate, long claimant chains)
+from monoorbslam3_amd.frame import FramePost  # noqa: E402
+post = FramePost(w, h, 460.0, 460.0, w / 2.0, h / 2.0)
+
+
+def crowd(nn, seed, x0, x1, y0, y1, n_clusters, p_flip, centres):
+    r = np.random.RandomState(seed)
+    k = np.zeros(nn, KP_DTYPE)
+    k["x"] = r.uniform(x0, x1, nn).astype(np.float32); k["y"] = r.uniform(y0, y1, nn).astype(np.float32)
+    k["size"] = 1.0; k["angle"] = (r.normal(40, 25, nn) % 360).astype(np.float32); k["class_id"] = -1
+    dd = centres[r.randint(0, n_clusters, nn)] ^ np.packbits(r.uniform(size=(nn, 256)) < p_flip, axis=1, bitorder="little")
+    return k, dd.astype(np.uint8)
+
+
+c40 = np.random.RandomState(2026).randint(0, 256, (40, 32)).astype(np.uint8)
+init_cases = [("two extracted views", k1, d1, k2, d2, 1024),
+              ("crowded: 900 x 850 in 260 x 200 px", *crowd(900, 1, 200, 460, 100, 300, 40, 0.03, c40), *crowd(850, 2, 200, 460, 100, 300, 40, 0.03, c40), 1024),
+              ("worst case: 2000 x 2000 in 90 x 90 px", *crowd(2000, 3, 300, 390, 200, 290, 8, 0.02, c40), *crowd(2000, 4, 300, 390, 200, 290, 8, 0.02, c40), 2048)]
+ts_i = torch.cuda.Stream()
+for label, ka, da, kb, db_, lcap in init_cases:
+    na, nb = len(ka), len(kb)
+    pre0 = np.stack([ka["x"], ka["y"]], axis=1).astype(np.float32)
+    _, kbu, start, items = post(kb)
+    kpb = lambda k: torch.from_numpy(np.frombuffer(np.ascontiguousarray(k).tobytes(), np.uint8).copy()).to(dev)  # noqa: E731
+    di = dict(kps1=kpb(ka), desc1=up(da), kps2=kpb(kbu), desc2=up(db_), cell_start=up(start.astype(np.int32)),
+              cell_items=up(np.concatenate([items, np.zeros(1, items.dtype)]).astype(np.int32)), pre=up(pre0),
+              matches12=torch.zeros(na, dtype=torch.int32, device=dev), result=torch.zeros(8, dtype=torch.int32, device=dev))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tms = []
+    for _ in range(9):
+        di["pre"].copy_(up(pre0))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(ts_i):
+            ev0.record()
+            m9.SearchForInitializationDevice(di, na, nb, post.cols, post.rows, window=100, list_cap=lcap, stream=ts_i.cuda_stream)
+            ev1.record()
+        torch.cuda.synchronize()
+        tms.append(ev0.elapsed_time(ev1))
+    r = di["result"].cpu().numpy()
+    host_ms = timeit(lambda: m9.SearchForInitialization(ka, da, kb, db_, w, h, pre0.copy(), 100), reps=5)
+    print("SearchForInitialization on the device, %-38s %.3f ms device time (median of 9; %d matches, overflow flag %d, %d sweeps, %d list entries); host entry point %.3f ms"
+          % (label + ":", sorted(tms)[4], r[0], r[1], r[2], r[3], host_ms))
 # map-point descriptors: 3000 points x 2..12 observations
 sizes = rng.randint(2, 13, 3000)
 off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
