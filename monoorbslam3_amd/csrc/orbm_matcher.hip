@@ -432,8 +432,9 @@ __global__ __launch_bounds__(BF_WAVES * 64, 4) void k_best2_fp4(const uint8_t *_
     const uint8_t *B = b + (size_t)p * b_stride * 32;
 
     // ---- this lane's two queries (rows row0 + n and row0 + 32 + n) as the B operands of the 4 steps
+    // (popcount(query), needed only by the decode after the last tile, is taken there from a second read of the row: carried
+    // across the tile loop it cost the walking form two of its spills)
     bm_v4i bq[2][4];
-    int pcq[2] = {0, 0};
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int row = min(row0 + 32 * g + n, max(na_max - 1, 0)); // clamped rows are computed but never stored
@@ -441,7 +442,6 @@ __global__ __launch_bounds__(BF_WAVES * 64, 4) void k_best2_fp4(const uint8_t *_
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const uint32_t w0 = na_max > 0 ? pq[2 * t] : 0u, w1 = na_max > 0 ? pq[2 * t + 1] : 0u;
-            pcq[g] += __popc(w0) + __popc(w1);
             const uint32_t w = h ? w1 : w0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) bq[g][t][j] = (int)(0x22222222u | (((~w >> j) & 0x11111111u) << 3)); // set: +1.0, clear: -1.0
@@ -547,9 +547,12 @@ __global__ __launch_bounds__(BF_WAVES * 64, 4) void k_best2_fp4(const uint8_t *_
         if (h == 0 && row < na_max) {
             const size_t orow = (size_t)p * a_stride + row;
             const bool live = row < na && (!row_ok || row_ok[orow]);
+            const uint4 *pq = reinterpret_cast<const uint4 *>(A + (size_t)row * 32);
+            const uint4 q0 = pq[0], q1 = pq[1];
+            const int pcq = __popc(q0.x) + __popc(q0.y) + __popc(q0.z) + __popc(q0.w) + __popc(q1.x) + __popc(q1.y) + __popc(q1.z) + __popc(q1.w);
             // hamming = popcount(query) - acc
-            const uint32_t d1 = f1 == 0 ? 256u : (uint32_t)(pcq[g] - ((int)(f1 >> 13) - 256));
-            const uint32_t ss = f2 == 0 ? 256u : (uint32_t)(pcq[g] - ((int)(f2 >> 13) - 256));
+            const uint32_t d1 = f1 == 0 ? 256u : (uint32_t)(pcq - ((int)(f1 >> 13) - 256));
+            const uint32_t ss = f2 == 0 ? 256u : (uint32_t)(pcq - ((int)(f2 >> 13) - 256));
             // a 256-distance candidate never beats the initial 256 of the reference loop
             best_idx[orow] = (live && d1 < 256) ? (int32_t)(8191u - (f1 & 8191u)) : -1;
             best[orow] = live ? (uint16_t)min(d1, 256u) : (uint16_t)256;
