@@ -44,6 +44,23 @@ static inline unsigned orbx_xcd_grid(int per_frame, int n_frames)
     return 8u * (unsigned)((n_frames + 7) / 8) * (unsigned)per_frame;
 }
 
+// Development hook (orbx_dev_set_lds_pad, not declared in include/): extra dynamic LDS per workgroup of a batch kernel, so that a
+// tool can cap the kernel's occupancy and measure what a co-resident partner would leave it (profiles/r06_pipeline_budget.md).
+// Stage ids: 0 k_resize_lds, 1 k_fast_strip, 2 oct_batch::k_octree_lds, 3 k_orient<false>, 4 k_blur_desc.  0 bytes = as shipped.
+static int g_dev_lds_pad[5] = {0, 0, 0, 0, 0};
+extern "C" int orbx_dev_set_lds_pad(int stage, int bytes)
+{
+    if (stage < 0 || stage >= 5 || bytes < 0 || bytes > 159 * 1024) return ORBX_E_ARG;
+    g_dev_lds_pad[stage] = bytes;
+    return ORBX_OK;
+}
+template <typename K> static size_t dev_pad(K kernel, int stage, size_t static_and_dynamic)
+{
+    const size_t pad = (size_t)g_dev_lds_pad[stage];
+    if (pad) (void)orbx_lds_opt_in(reinterpret_cast<const void *>(kernel), static_and_dynamic + pad);
+    return pad;
+}
+
 __constant__ __attribute__((aligned(16))) int8_t c_pattern[ORB_PATTERN_POINTS * 2] = {ORB_PATTERN_INT8_LIST};
 
 // ---------------------------------------------------------------------------------------------
@@ -290,7 +307,7 @@ void orbx_launch_resize_lds(hipStream_t s, const uint8_t *src, size_t src_fs, in
                             int n_frames, int *zero_counts)
 {
     const int gx = (dw + 255) / 256, gy = (dh + RL_WAVES * RS_ROWS - 1) / (RL_WAVES * RS_ROWS);
-    hipLaunchKernelGGL(k_resize_lds, dim3(orbx_xcd_grid(gx * gy, n_frames)), dim3(64, RL_WAVES), 0, s, src, src_fs, src_pitch, sw, sh,
+    hipLaunchKernelGGL(k_resize_lds, dim3(orbx_xcd_grid(gx * gy, n_frames)), dim3(64, RL_WAVES), dev_pad(k_resize_lds, 0, 0), s, src, src_fs, src_pitch, sw, sh,
                        last_row_bytes, dst, dst_fs, dst_pitch, dw, dh, xtap, ytap, gx, gy, n_frames, zero_counts);
 }
 
@@ -1212,7 +1229,7 @@ void orbx_launch_fast_strips(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
         src.frame_stride[l] = l == 0 ? l0_fs : b.img_frame_stride;
         src.pitch[l] = l == 0 ? l0_pitch : levels.lv[l].pitch;
     }
-    hipLaunchKernelGGL(k_fast_strip, dim3(orbx_xcd_grid(n_strips, n_frames)), dim3(64), 0, s, src, d_levels,
+    hipLaunchKernelGGL(k_fast_strip, dim3(orbx_xcd_grid(n_strips, n_frames)), dim3(64), dev_pad(k_fast_strip, 1, 0), s, src, d_levels,
                        reinterpret_cast<const FastStrip *>(d_strips), b.cand, b.cand_frame_stride, b.cand_count, n_strips,
                        n_frames);
 }
@@ -1860,7 +1877,8 @@ void orbx_launch_octree(hipStream_t s, const OrbxLevels *d_levels, const OrbxLev
     switch (p.kind) {
     case 0:
         (void)orbx_lds_opt_in(reinterpret_cast<const void *>(oct_batch::k_octree_lds), p.lds_bytes); // per device; a refusal shows as the launch error the caller checks
-        hipLaunchKernelGGL(oct_batch::k_octree_lds, grid, dim3(ORBX_OCT_THREADS_BATCH), p.lds_bytes, s, d_levels, b, level_begin, lds);
+        hipLaunchKernelGGL(oct_batch::k_octree_lds, grid, dim3(ORBX_OCT_THREADS_BATCH), p.lds_bytes + dev_pad(oct_batch::k_octree_lds, 2, p.lds_bytes), s,
+                           d_levels, b, level_begin, lds);
         break;
     case 2:
         (void)orbx_lds_opt_in(reinterpret_cast<const void *>(oct_huge::k_octree_lds), p.huge_bytes);
@@ -2227,7 +2245,7 @@ void orbx_launch_orient_desc(hipStream_t s, const uint8_t *l0, size_t l0_fs, int
         hipLaunchKernelGGL(k_orient<true>, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, tab,
                            b, u_max, pf_o, n_frames, nullptr, 0);
     } else {
-        hipLaunchKernelGGL(k_orient<false>, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), 0, s, l0, l0_fs, l0_pitch, d_levels, tab,
+        hipLaunchKernelGGL(k_orient<false>, dim3(orbx_xcd_grid(pf_o, n_frames)), dim3(256), dev_pad(k_orient<false>, 3, 0), s, l0, l0_fs, l0_pitch, d_levels, tab,
                            b, u_max, pf_o, n_frames, reinterpret_cast<const uint4 *>(item_levels ? d_items : nullptr), item_levels);
         hipLaunchKernelGGL(k_angle, dim3((unsigned)(((size_t)levels.kcap_total * n_frames + 255) / 256)), dim3(256), 0, s, d_levels,
                            b, n_frames, reinterpret_cast<float4 *>(item_levels ? d_items : nullptr), item_levels);
@@ -2647,7 +2665,7 @@ void orbx_launch_desc_fused(hipStream_t s, const uint8_t *l0, size_t l0_fs, int 
     int K = 0;
     for (int i = 0; i < 7; ++i) K += taps[i];
     if (K == 256)
-        hipLaunchKernelGGL(k_blur_desc<256>, dim3(orbx_xcd_grid(n_blocks, n_frames)), dim3(BD_T), 0, s, src, tab,
+        hipLaunchKernelGGL(k_blur_desc<256>, dim3(orbx_xcd_grid(n_blocks, n_frames)), dim3(BD_T), dev_pad(k_blur_desc<256>, 4, 0), s, src, tab,
                            reinterpret_cast<const BdBlock *>(d_blocks), reinterpret_cast<const uint4 *>(d_band_h),
                            reinterpret_cast<const uint4 *>(d_band_v), d_bk_start, bk_stride, reinterpret_cast<const BdItem *>(d_items),
                            levels.kcap_total, out_kp, out_desc, cap, n_blocks, n_frames);
