@@ -42,6 +42,8 @@ void orbm_destroy(orbm_t *h);
 #define ORBM_VAR_BEST2_RESIDENT 2 /* k_best2_fp4's grid: 0 one workgroup per (problem, 512 queries) (default); 1 or 2: that many
                                    * workgroups per CU walk the blocks, so the kernel holds a fixed share of every CU (half of the
                                    * registers and 37 KB of LDS per workgroup) -- for a caller that runs it beside other kernels */
+#define ORBM_VAR_INIT_LANES 3 /* orbm_search_for_initialization_device: lanes that share one query's window list in the resolve kernel:
+                              * 0 chosen from the mean list length (default), or 1, 4, 16, 64 (the parity twins) */
 int orbm_set_variant(orbm_t *h, int which, int value);
 
 /* DBoW2::FeatureVector (thirdParty/DBoW2/DBoW2/FeatureVector.h) flattened to CSR:
@@ -235,10 +237,13 @@ int orbm_search_by_projection_points_device(orbm_t *h, float nn_ratio, const uin
  * d_result (int32 x 8): [0] matches, [1] = 1 when the lists overflowed the pool (d_matches12 all -1, d_pre untouched: repeat with
  * a larger list_cap or use the host entry point), [1] = 2 when the fixed point had not settled after ORBM_INIT_MAX_SWEEPS sweeps
  * (same guarantee: nothing written; use the host entry point), [2] sweeps of the fixed point, [3] list entries.
- * Cost: ONE workgroup resolves the search; a sweep walks every level-0 feature's window list (a 100-px window over 2000 features
- * holds tens of candidates) times the claimant chains.  Measured (profiles/r06_match_latency.txt): 3 sweeps on two extracted
- * views, 5 on a crowded scene of near-duplicates; the proof's bound is n1 + 1 sweeps, the cap keeps a pathological scene from
- * holding a CU for milliseconds.
+ * Cost: ONE workgroup resolves the search; a sweep walks every level-0 feature's window list (1, 4 or 16 lanes share a list,
+ * chosen from the mean list length: ORBM_VAR_INIT_LANES) and, per entry, the chain of queries that claim that candidate.  Measured
+ * device time of the whole call (profiles/r06_match_latency.txt): 0.11 ms on two extracted views (22 entries per list, 3 sweeps; the
+ * host entry point 0.17 ms), 1.2 ms on a crowded scene of near-duplicates (900 x 850 features in 260 x 200 px: 390 entries per
+ * list, 5 sweeps; host 0.5 ms -- there the host entry point is the faster one), 5 ms with every feature of both frames in ONE window
+ * (2000-entry lists; host 10 ms).  The proof bounds the sweeps by n1 + 1; ORBM_INIT_MAX_SWEEPS keeps a pathological scene from
+ * holding a CU for longer than that.
  * Enqueued on `stream` (NULL: orbx.h, "Streams"); one call in flight per handle. */
 #define ORBM_INIT_MAX_SWEEPS 64
 int orbm_search_for_initialization_device(orbm_t *h, float nn_ratio, int check_orientation, const void *d_kps1, const uint8_t *d_desc1,

@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(PR_T) void k_init_resolve(const int32_t *__restrict
                                                        const uint32_t *__restrict__ pool, int pool_cap,
                                                        const int32_t *__restrict__ total, int n1, int n2,
                                                        const orbx_kp *__restrict__ kps1, const orbx_kp *__restrict__ kps2,
-                                                       float nn_ratio, int check_orientation, int max_sweeps,
+                                                       float nn_ratio, int check_orientation, int max_sweeps, int group_lanes,
                                                        int32_t *__restrict__ matches12, float *__restrict__ pre, int32_t *__restrict__ result)
 {
     extern __shared__ int32_t ir_lds[];
@@ -1034,20 +1034,43 @@ __global__ __launch_bounds__(PR_T) void k_init_resolve(const int32_t *__restrict
     for (int i = tid; i < n1; i += PR_T) { a_c[i] = -1; a_d[i] = 0; }
     if (tid < ORBM_HISTO_LENGTH) s_hist[tid] = 0;
     if (tid == 0) s_n = 0;
-    auto choose = [&](int i, int *dist_out) -> int {
+    // G lanes per query share the query's window list (1, 4, 16 or 64: a 100-px window over 2000 level-0 features can hold
+    // hundreds of candidates, and with one thread per query the longest list sets the sweep's time; with a whole wave per query
+    // short lists leave most lanes idle and a lane's claimant chains set the wave's time).  The reference's strict first-wins
+    // updates (:64-71) are the two smallest keys (distance << 22 | list position) of the candidates that pass :63.
+    const int G = group_lanes > 0 ? group_lanes : (tot >= 1024 * n1 ? 4 : tot >= 48 * n1 ? 16 : tot >= 12 * n1 ? 4 : 1); // (profiles/r06_match_latency.txt)
+    const int lane = tid & (G - 1), wv = tid / G;
+    auto choose = [&](int i, int *dist_out) -> int { // every lane of the group returns the same answer
         const int n = counts[i];
-        if (n <= 0) return -1;
-        const uint32_t *e = pool + offs[i];
-        int best = INT_MAX - 1, second = INT_MAX, idx = -1;
-        for (int t = 0; t < n; ++t) {
-            const int c = (int)(e[t] & 0x3FFFFFu), d = (int)(e[t] >> 22);
-            int md = INT_MAX; // matchedDistance[c] as query i finds it: the closest claim of a query before it
-            for (int j = head[c]; j >= 0; j = next[j])
-                if (j < i) md = min(md, a_d[j]);
-            if (md <= d) continue; // :63
-            if (d < best) { second = best; best = d; idx = c; }
-            else if (d < second) second = d;
+        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+        const uint32_t *e = pool + (n > 0 ? offs[i] : 0);
+        for (int t0 = lane; t0 < n; t0 += 4 * G) {
+            // four list entries requested before the first is used: the lists are re-read from memory in every sweep, and one
+            // workgroup has few loads in flight (a dependent load per entry: 0.7 us per entry and lane)
+            uint32_t ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ev[u] = t0 + u * G < n ? e[t0 + u * G] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u * G;
+                if (t >= n) break;
+                const int c = (int)(ev[u] & 0x3FFFFFu), d = (int)(ev[u] >> 22);
+                int md = INT_MAX; // matchedDistance[c] as query i finds it: the closest claim of a query before it
+                for (int j = head[c]; j >= 0; j = next[j])
+                    if (j < i) md = min(md, a_d[j]);
+                if (md <= d) continue; // :63
+                const uint32_t k = ((uint32_t)d << 22) | (uint32_t)t;
+                k2 = min(k2, max(k1, k));
+                k1 = min(k1, k);
+            }
         }
+        for (int o = G >> 1; o > 0; o >>= 1) {
+            const uint32_t o1 = (uint32_t)__shfl_xor((int)k1, o), o2 = (uint32_t)__shfl_xor((int)k2, o);
+            k2 = min(max(k1, o1), min(k2, o2));
+            k1 = min(k1, o1);
+        }
+        const int best = k1 == 0xFFFFFFFFu ? INT_MAX - 1 : (int)(k1 >> 22), second = k2 == 0xFFFFFFFFu ? INT_MAX : (int)(k2 >> 22);
+        const int idx = k1 == 0xFFFFFFFFu ? -1 : (int)(e[k1 & 0x3FFFFFu] & 0x3FFFFFu);
         *dist_out = best;
         // :74 (second == INT_MAX: the product is 2.1e9 * ratio in float and cvRound saturates the way lrint does on the host)
         return (best <= ORBM_TH_LOW && best < orb_round_f((float)second * nn_ratio)) ? idx : -1;
@@ -1061,10 +1084,10 @@ __global__ __launch_bounds__(PR_T) void k_init_resolve(const int32_t *__restrict
             if (a_c[i] >= 0) next[i] = atomicExch(&head[a_c[i]], i);
         __syncthreads();
         int changed = 0;
-        for (int i = tid; i < n1; i += PR_T) { // every query reads the OLD claims: the new ones become visible behind a barrier
+        for (int i = wv; i < n1; i += PR_T / G) { // every query reads the OLD claims: the new ones become visible behind a barrier
             int d = 0;
-            n_c[i] = choose(i, &d);
-            n_d[i] = d;
+            const int c = choose(i, &d);
+            if (lane == 0) { n_c[i] = c; n_d[i] = d; }
         }
         __syncthreads();
         for (int i = tid; i < n1; i += PR_T)
@@ -1429,6 +1452,7 @@ struct orbm_ctx {
     PinBuf h_in, h_out;
     int window_on_device = 1;   // ORBM_VAR_WINDOW = 1 keeps the host grid (the parity twin of the device lists)
     int best2_variant = 0;      // ORBM_VAR_BEST2: 0 = fp4, 1 = i8, 2 = valu
+    int init_lanes = 0;         // ORBM_VAR_INIT_LANES: lanes per query of k_init_resolve: 0 = by list length (default), 1, 4, 16, 64
     int best2_resident = 0;     // ORBM_VAR_BEST2_RESIDENT: k_best2_fp4 as a grid of this many workgroups per CU (0 = one per block of queries)
     int n_cus = 256;            // the device's CU count (set at create)
     size_t window_last_total = 0; // candidates the previous window search returned (sizes the first copy-out)
@@ -1470,6 +1494,7 @@ extern "C" int orbm_set_variant(orbm_t *c, int which, int value)
     if (which == ORBM_VAR_BEST2 && value >= 0 && value <= 2) { c->best2_variant = value; return ORBX_OK; }
     if (which == ORBM_VAR_WINDOW && (value == 0 || value == 1)) { c->window_on_device = !value; return ORBX_OK; }
     if (which == ORBM_VAR_BEST2_RESIDENT && value >= 0 && value <= 2) { c->best2_resident = value; return ORBX_OK; }
+    if (which == ORBM_VAR_INIT_LANES && (value == 0 || value == 1 || value == 4 || value == 16 || value == 64)) { c->init_lanes = value; return ORBX_OK; }
     return orbx_set_error(ORBX_E_ARG, "unknown matcher variant switch or value out of range");
 }
 
@@ -2527,8 +2552,8 @@ extern "C" int orbm_search_for_initialization_device(orbm_t *c, float nn_ratio, 
                        d_counts, d_pool, d_total, d_offs);
     M_TRY(orbx_lds_opt_in(reinterpret_cast<const void *>(k_init_resolve), 150 * 1024));
     hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(PR_T), lds, s, d_counts, d_offs, d_pool, (int)std::min(pool_cap, (size_t)INT_MAX), d_total,
-                       n1, n2, (const orbx_kp *)d_kps1, (const orbx_kp *)d_kps2, nn_ratio, check_orientation, ORBM_INIT_MAX_SWEEPS, d_matches12, d_pre,
-                       d_result);
+                       n1, n2, (const orbx_kp *)d_kps1, (const orbx_kp *)d_kps2, nn_ratio, check_orientation, ORBM_INIT_MAX_SWEEPS, c->init_lanes, d_matches12,
+                       d_pre, d_result);
     M_TRY(hipGetLastError());
     return ORBX_OK;
 }

@@ -106,7 +106,7 @@ class MatcherHandle:
     def set_variant(self, name, value):
         """orbm_set_variant: "best2" = "fp4" | "i8" | "valu" (dense best / second-best kernel), "window" = "device" | "host",
         "best2_resident" = 0 | 1 | 2 (k_best2_fp4 as that many workgroups per CU walking the query blocks)."""
-        which = {"best2": 0, "window": 1, "best2_resident": 2}[name]
+        which = {"best2": 0, "window": 1, "best2_resident": 2, "init_lanes": 3}[name]
         val = {"fp4": 0, "i8": 1, "valu": 2, "device": 0, "host": 1}.get(value, value)
         _lib.check(self._L.orbm_set_variant(self._h, which, int(val)))
 

@@ -250,6 +250,15 @@ def test_search_for_initialization_on_the_device(oracle_mod, ori):
         assert n_ref > 50
         if name == "crowded":
             assert res[2] > 2   # the fixed point had chains to follow
+        # ORBM_VAR_INIT_LANES: 1, 4, 16 or 64 lanes share a query's window list in the resolve kernel -- the same answer from each
+        for lanes in (1, 4, 16, 64):
+            m._hd.set_variant("init_lanes", lanes)
+            d["pre"].copy_(up(pre)); d["matches12"].fill_(7)
+            m.SearchForInitializationDevice(d, n1, n2, post.cols, post.rows, window=100, list_cap=1024)
+            res_l = d["result"].cpu().numpy()
+            assert res_l[1] == 0 and res_l[0] == n_ref and res_l[2] == res[2], (name, lanes, res_l)
+            assert np.array_equal(d["matches12"].cpu().numpy(), m_ref) and np.array_equal(d["pre"].cpu().numpy(), pre_ref), (name, lanes)
+        m._hd.set_variant("init_lanes", 0)
         # a pool too small for the lists: reported, matches12 all -1, pre untouched
         d["pre"].copy_(up(pre)); d["matches12"].fill_(7)
         m.SearchForInitializationDevice(d, n1, n2, post.cols, post.rows, window=100, list_cap=2)

@@ -140,20 +140,26 @@ for label, ka, da, kb, db_, lcap in init_cases:
               cell_items=up(np.concatenate([items, np.zeros(1, items.dtype)]).astype(np.int32)), pre=up(pre0),
               matches12=torch.zeros(na, dtype=torch.int32, device=dev), result=torch.zeros(8, dtype=torch.int32, device=dev))
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    tms = []
-    for _ in range(9):
-        di["pre"].copy_(up(pre0))
-        torch.cuda.synchronize()
-        with torch.cuda.stream(ts_i):
-            ev0.record()
-            m9.SearchForInitializationDevice(di, na, nb, post.cols, post.rows, window=100, list_cap=lcap, stream=ts_i.cuda_stream)
-            ev1.record()
-        torch.cuda.synchronize()
-        tms.append(ev0.elapsed_time(ev1))
+    by_lanes = {}
+    for lanes in (0, 1, 4, 16, 64):   # ORBM_VAR_INIT_LANES: lanes that share a query's list; 0 = the kernel's own choice
+        m9._hd.set_variant("init_lanes", lanes)
+        tms = []
+        for _ in range(9):
+            di["pre"].copy_(up(pre0))
+            torch.cuda.synchronize()
+            with torch.cuda.stream(ts_i):
+                ev0.record()
+                m9.SearchForInitializationDevice(di, na, nb, post.cols, post.rows, window=100, list_cap=lcap, stream=ts_i.cuda_stream)
+                ev1.record()
+            torch.cuda.synchronize()
+            tms.append(ev0.elapsed_time(ev1))
+        by_lanes[lanes] = sorted(tms)[4]
+    m9._hd.set_variant("init_lanes", 0)
     r = di["result"].cpu().numpy()
     host_ms = timeit(lambda: m9.SearchForInitialization(ka, da, kb, db_, w, h, pre0.copy(), 100), reps=5)
-    print("SearchForInitialization on the device, %-38s %.3f ms device time (median of 9; %d matches, overflow flag %d, %d sweeps, %d list entries); host entry point %.3f ms"
-          % (label + ":", sorted(tms)[4], r[0], r[1], r[2], r[3], host_ms))
+    print("SearchForInitialization on the device, %-38s %.3f ms device time (median of 9; %d matches, overflow flag %d, %d sweeps, %d list entries); "
+          "with 1 / 4 / 16 / 64 lanes per query %.3f / %.3f / %.3f / %.3f ms; host entry point %.3f ms"
+          % (label + ":", by_lanes[0], r[0], r[1], r[2], r[3], by_lanes[1], by_lanes[4], by_lanes[16], by_lanes[64], host_ms))
 # map-point descriptors: 3000 points x 2..12 observations
 sizes = rng.randint(2, 13, 3000)
 off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
