@@ -6,12 +6,12 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/sweep.jsonl
 : > "$OUT"
 for B in 1 8 64 256 512 1024; do
-  python3 "$ROOT/bench.py" --batch $B --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep >> "$OUT"
+  python3 "$ROOT/bench.py" --batch $B --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs >> "$OUT"
 done
-python3 "$ROOT/bench.py" --batch 512 --width 752 --height 480 --features 1000 --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep >> "$OUT"
-python3 "$ROOT/bench.py" --batch 8 --width 1920 --height 1080 --features 2000 --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep >> "$OUT"
-python3 "$ROOT/bench.py" --config 4 --steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end --no-density-sweep >> "$OUT"
-python3 "$ROOT/bench.py" --batch 128 --width 1920 --height 1080 --features 2000 --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep >> "$OUT"
+python3 "$ROOT/bench.py" --batch 512 --width 752 --height 480 --features 1000 --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs >> "$OUT"
+python3 "$ROOT/bench.py" --batch 8 --width 1920 --height 1080 --features 2000 --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs >> "$OUT"
+python3 "$ROOT/bench.py" --config 4 --steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs >> "$OUT"
+python3 "$ROOT/bench.py" --batch 128 --width 1920 --height 1080 --features 2000 --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs >> "$OUT"
 python3 - "$OUT" <<'PY'
 import json, sys
 for line in open(sys.argv[1]):

@@ -14,7 +14,7 @@ make -C monoorbslam3_amd/csrc -s -j8 prof > $O/make_prof.log 2>&1 && python3 too
 python3 bench.py > $O/final_bench.json 2> $O/final_bench.err || { tail -5 $O/final_bench.err; exit 1; }
 echo "bench done: $(cut -c1-160 $O/final_bench.json)"
 bash tools/kernel_stats.sh > $O/kernel_stats_overlapped.txt 2>&1; echo "kernel stats done"
-( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt2 && rocprofv3 --kernel-trace --output-format csv -d /tmp/kt2 -o r -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end --no-density-sweep > /dev/null 2>&1; python3 $ROOT/tools/step_timeline.py /tmp/kt2 2 > $O/step_timeline.txt 2>&1 ); echo "timeline done"
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt2 && rocprofv3 --kernel-trace --output-format csv -d /tmp/kt2 -o r -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs > /dev/null 2>&1; python3 $ROOT/tools/step_timeline.py /tmp/kt2 2 > $O/step_timeline.txt 2>&1 ); echo "timeline done"
 bash tools/sq_breakdown.sh > $O/sq.log 2>&1; cp gpurun_out/sq_breakdown.txt $O/; echo "sq done"
 bash tools/lds_breakdown.sh > $O/lds.log 2>&1; cp gpurun_out/lds_breakdown.txt $O/; echo "lds done"
 bash tools/batch_sweep.sh > $O/batch_sweep.txt 2> $O/batch_sweep.err; echo "sweep done"

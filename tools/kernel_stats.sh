@@ -3,7 +3,7 @@
 # their streams, so the averages include contention; the minimum is close to the isolated time).
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep "$@" > /dev/null 2>/tmp/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs "$@" > /dev/null 2>/tmp/kt.err
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/kt/**/*kernel_stats.csv", recursive=True)[0]

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 BATCH=${BATCH:-256}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ldsb
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/ldsb -o r -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-density-sweep --batch $BATCH > /dev/null 2> /tmp/ldsb.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/ldsb -o r -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs --batch $BATCH > /dev/null 2> /tmp/ldsb.err
 python3 - <<'PY' | tee "$ROOT/gpurun_out/lds_breakdown.txt"
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

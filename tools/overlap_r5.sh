@@ -5,7 +5,7 @@
 # in TIMELINES.  Output: gpurun_out/overlap_r5/.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/overlap_r5; mkdir -p $O
-COMMON="--no-cpu-baseline --no-end-to-end --no-density-sweep --steps 30 --warmup 5"
+COMMON="--no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs --steps 30 --warmup 5"
 run() { # name, flags
   python3 bench.py $COMMON $2 > $O/b_$1.log 2>&1 || { echo "$1 FAILED"; tail -3 $O/b_$1.log; return; }
   python3 - "$1" $O/b_$1.log <<'PY'

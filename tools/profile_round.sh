@@ -14,13 +14,13 @@ echo "bench done: $(cut -c1-200 "$OUT/bench.json")"
 # (bench.py reads profiles/pmc_traffic.json and profiles/pmc_valu.json of the PREVIOUS collection; after copying this
 #  run's files into profiles/ the next bench line carries them)
 # per-launch tables: one internal stream, so that a "launch" is a whole resident batch
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o r -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o r -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 echo "trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o r -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end --no-density-sweep > /dev/null 2> "$OUT/pmc_fetch.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o r -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs > /dev/null 2> "$OUT/pmc_fetch.err"
 echo "pmc fetch done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o r -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end --no-density-sweep > /dev/null 2> "$OUT/pmc_write.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o r -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs > /dev/null 2> "$OUT/pmc_write.err"
 echo "pmc write done"
-rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_valu" -o r -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end --no-density-sweep > /dev/null 2> "$OUT/pmc_valu.err"
+rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_valu" -o r -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs > /dev/null 2> "$OUT/pmc_valu.err"
 echo "pmc valu done"
 python3 "$ROOT/tools/pmc_traffic.py" "$OUT/pmc_fetch" "$OUT/pmc_write" $BATCH "$OUT/pmc_traffic.json"
 python3 "$ROOT/tools/pmc_valu.py" "$OUT/pmc_valu" $BATCH "$OUT/pmc_valu.json"

@@ -12,7 +12,7 @@ P3="TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum TCP_TCP_TA_DATA_STALL_C
 i=0
 for P in "$P2" "$P3"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --output-format csv -d /tmp/tab/p$i -o r -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-density-sweep --batch 256 > /dev/null 2> /tmp/tab$i.err || { tail -5 /tmp/tab$i.err; exit 1; }
+  rocprofv3 --pmc $P --output-format csv -d /tmp/tab/p$i -o r -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-density-sweep --no-extra-configs --batch 256 > /dev/null 2> /tmp/tab$i.err || { tail -5 /tmp/tab$i.err; exit 1; }
 done
 python3 - <<'PY' | tee "$ROOT/gpurun_out/ta_breakdown.txt"
 import csv, glob, collections
