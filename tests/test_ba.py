@@ -183,6 +183,60 @@ def test_gpu_lm_argument_errors():
         ba.optimize(*unsorted_edges)
 
 
+@pytest.mark.gpu
+def test_gpu_ba_entry_points_lease_their_workspace():
+    """include/orbba.h, "Threads": every host-pointer BA call leases a stream, a device arena and a page-locked staging block from a
+    per-device pool.  A problem without edges (the arena's edge blocks are empty), calls of growing and shrinking size through one
+    workspace (the arena grows, a smaller call then runs inside the larger one), and four host threads calling at once (ctypes releases
+    the GIL: four leases in flight) -- every answer equals the one the same call gives alone."""
+    import threading
+    from monoorbslam3_amd import ba
+    # no edges: H and b are zero, nothing is read or written out of bounds
+    pr, args = _perturbed(3, 10, 1)
+    none = list(args)
+    none[5] = np.zeros(0, np.int32); none[6] = np.zeros(0, np.int32); none[7] = np.zeros((0, 2)); none[8] = np.zeros(0)
+    g = ba.linearize(*none)
+    assert not g["H_pp"].any() and not g["b_p"].any() and not g["H_ll"].any() and not g["b_l"].any() and g["chi2"].size == 0
+    # small, large, small again: the second small call reuses the grown arena and gives the first one's bytes
+    _, small = _perturbed(4, 40, 3)
+    _, large = _perturbed(20, 3000, 5)
+    a = ba.local_bundle_adjustment(*small)
+    big = ba.local_bundle_adjustment(*large)
+    b2 = ba.local_bundle_adjustment(*small)
+    for k in ("pose_R", "pose_t", "points", "chi2", "outlier"):
+        assert np.asarray(a[k]).tobytes() == np.asarray(b2[k]).tobytes(), k
+    assert a["iterations"] == b2["iterations"] and big["iterations"] >= 1
+    lin = ba.linearize(*large)
+    # four threads: two local BAs, a linearisation and a batch of pose optimisations, three rounds each
+    cam, R0, t0, off, P, Z, W = _pose_frames([300, 0, 2, 700], 9)
+    pose_ref = ba.pose_optimize_batch(cam, R0, t0, off, P, Z, W)
+    bad = []
+
+    def run(kind):
+        for _ in range(3):
+            if kind == 0:
+                got = ba.local_bundle_adjustment(*small)
+                ok = all(np.asarray(got[k]).tobytes() == np.asarray(a[k]).tobytes() for k in ("pose_R", "pose_t", "points", "chi2", "outlier"))
+            elif kind == 1:
+                got = ba.local_bundle_adjustment(*large)
+                ok = all(np.asarray(got[k]).tobytes() == np.asarray(big[k]).tobytes() for k in ("pose_R", "pose_t", "points", "chi2", "outlier"))
+            elif kind == 2:
+                got = ba.linearize(*large)
+                ok = all(got[k].tobytes() == lin[k].tobytes() for k in ("chi2", "error", "H_pp", "b_p", "H_ll", "b_l", "H_lp"))
+            else:
+                got = ba.pose_optimize_batch(cam, R0, t0, off, P, Z, W)
+                ok = all(np.asarray(got[k]).tobytes() == np.asarray(pose_ref[k]).tobytes() for k in ("pose_R", "pose_t", "inlier", "n_inliers", "chi2"))
+            if not ok:
+                bad.append(kind)
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad, bad
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Optimize::poseOptimize for a batch of frames (a14b)
 def _pose_frames(sizes, seed, outlier_frac=0.1):
