@@ -8,6 +8,10 @@
 // thread M loops  orbv_transform -> orbm_search_for_triangulation -> orbm_search_fuse -> orbba_local_bundle_adjustment,
 // each on handles of its own (the vocabulary handle is shared, as in the reference).  Every output of every iteration must
 // equal, byte for byte, what the same calls return when one thread runs them alone.
+// Then the same two threads run DEVICE chains, each on a non-blocking stream of its own (what orbx.h asks of a second thread that
+// wants the *_device entry points): T copies a frame up, extracts it and matches it against a resident view (orbx_extract_batch_device
+// -> orbm_best2_device), M computes both bag-of-words records and the triangulation matches (orbv_transform_device x2 ->
+// orbm_search_for_triangulation_device); results equal the single-thread device chains and the host entry points.
 //   two_threads [--iters N]                correctness (exit 0 = all equal)
 //   two_threads --latency N [--own-voc]    per-call latency of T alone and with M running (p50 / p90, microseconds);
 //                                          --own-voc gives each thread its own vocabulary handle (a library older than
@@ -37,6 +41,15 @@
         if (e_ != 0) {                                                                                             \
             std::fprintf(stderr, "%s:%d orbx error %d: %s\n", __FILE__, __LINE__, e_, orbx_last_error());          \
             std::exit(11);                                                                                         \
+        }                                                                                                          \
+    } while (0)
+
+#define HIP_OK(e)                                                                                                  \
+    do {                                                                                                           \
+        hipError_t e_ = (e);                                                                                       \
+        if (e_ != hipSuccess) {                                                                                    \
+            std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));                         \
+            std::exit(10);                                                                                         \
         }                                                                                                          \
     } while (0)
 
@@ -296,6 +309,88 @@ static void pct(std::vector<double> v, double *p50, double *p90)
     *p90 = v[std::min(v.size() - 1, v.size() * 9 / 10)];
 }
 
+
+// ---- device chains, one non-blocking stream per thread
+template <typename T> static T *dmalloc(size_t n) { void *p = nullptr; HIP_OK(hipMalloc(&p, std::max(n, (size_t)1) * sizeof(T))); return (T *)p; }
+template <typename T> static T *hmalloc(size_t n) { void *p = nullptr; HIP_OK(hipHostMalloc(&p, std::max(n, (size_t)1) * sizeof(T), hipHostMallocDefault)); return (T *)p; }
+struct TDev { // thread T: frame up, extract, best / second-best against view a's descriptors
+    hipStream_t s; orbx_t *x; orbm_t *m; int cap, na;
+    uint8_t *h_img, *d_img, *d_desc, *d_desc_a; orbx_kp *d_kp; int32_t *d_n, *d_na, *d_bi; uint16_t *d_bd, *d_sd;
+    orbx_kp *h_kp; uint8_t *h_desc; int32_t *h_n, *h_bi; uint16_t *h_bd, *h_sd;
+    void init(const Scene &S, orbx_t *xh, orbm_t *mh)
+    {
+        HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        x = xh; m = mh; cap = S.cap; na = S.a.n;
+        h_img = hmalloc<uint8_t>((size_t)W * H); memcpy(h_img, S.b.img.data(), (size_t)W * H);
+        d_img = dmalloc<uint8_t>((size_t)W * H); d_kp = dmalloc<orbx_kp>(cap); d_desc = dmalloc<uint8_t>((size_t)cap * 32); d_n = dmalloc<int32_t>(1);
+        d_desc_a = dmalloc<uint8_t>((size_t)na * 32); d_na = dmalloc<int32_t>(1);
+        d_bi = dmalloc<int32_t>(cap); d_bd = dmalloc<uint16_t>(cap); d_sd = dmalloc<uint16_t>(cap);
+        h_kp = hmalloc<orbx_kp>(cap); h_desc = hmalloc<uint8_t>((size_t)cap * 32); h_n = hmalloc<int32_t>(1);
+        h_bi = hmalloc<int32_t>(cap); h_bd = hmalloc<uint16_t>(cap); h_sd = hmalloc<uint16_t>(cap);
+        HIP_OK(hipMemcpy(d_desc_a, S.a.desc.data(), (size_t)na * 32, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_na, &na, 4, hipMemcpyHostToDevice));
+    }
+    void run()
+    {
+        HIP_OK(hipMemcpyAsync(d_img, h_img, (size_t)W * H, hipMemcpyHostToDevice, s));
+        ORB_OK(orbx_extract_batch_device(x, d_img, 1, W, H, W, (size_t)W * H, d_kp, d_desc, cap, d_n, s));
+        ORB_OK(orbm_best2_device(m, 1, d_desc, cap, d_n, cap, d_desc_a, na, d_na, na, nullptr, nullptr, d_bi, d_bd, d_sd, s));
+        HIP_OK(hipMemcpyAsync(h_n, d_n, 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(h_kp, d_kp, sizeof(orbx_kp) * (size_t)cap, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(h_desc, d_desc, (size_t)cap * 32, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(h_bi, d_bi, 4 * (size_t)cap, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(h_bd, d_bd, 2 * (size_t)cap, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(h_sd, d_sd, 2 * (size_t)cap, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
+    struct Out { int n; std::vector<orbx_kp> kp; std::vector<uint8_t> desc; std::vector<int32_t> bi; std::vector<uint16_t> bd, sd; };
+    Out out() const
+    {
+        Out o; o.n = *h_n;
+        o.kp.assign(h_kp, h_kp + o.n); o.desc.assign(h_desc, h_desc + (size_t)o.n * 32);
+        o.bi.assign(h_bi, h_bi + o.n); o.bd.assign(h_bd, h_bd + o.n); o.sd.assign(h_sd, h_sd + o.n);
+        return o;
+    }
+};
+static bool same(const TDev::Out &a, const TDev::Out &b)
+{
+    return a.n == b.n && !memcmp(a.kp.data(), b.kp.data(), sizeof(orbx_kp) * (size_t)a.n) && a.desc == b.desc && a.bi == b.bi && a.bd == b.bd && a.sd == b.sd;
+}
+struct MDev { // thread M: both views' bag of words and the triangulation matches, records resident on the device
+    hipStream_t s; orbv_t *v; orbm_t *m; int n[2], capv;
+    uint8_t *d_desc[2], *d_has[2]; orbx_kp *d_kp[2]; int32_t *d_cnt[2], *d_nw[2], *d_nfv[2], *d_off[2], *d_m12, *d_res, *h_m12, *h_res;
+    uint32_t *d_ids[2], *d_nodes[2], *d_idx[2]; double *d_vals[2];
+    void init(const Scene &S, orbv_t *voc, orbm_t *mh)
+    {
+        HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        v = voc; m = mh; capv = std::max(S.a.n, S.b.n);
+        for (int k = 0; k < 2; ++k) {
+            const View &f = k ? S.b : S.a;
+            const std::vector<uint8_t> &has = k ? S.has_mp_b : S.has_mp_a;
+            n[k] = f.n;
+            d_desc[k] = dmalloc<uint8_t>((size_t)capv * 32); d_kp[k] = dmalloc<orbx_kp>(capv); d_has[k] = dmalloc<uint8_t>(capv); d_cnt[k] = dmalloc<int32_t>(1);
+            d_ids[k] = dmalloc<uint32_t>(capv); d_vals[k] = dmalloc<double>(capv); d_nw[k] = dmalloc<int32_t>(1); d_nodes[k] = dmalloc<uint32_t>(capv);
+            d_off[k] = dmalloc<int32_t>(capv + 1); d_idx[k] = dmalloc<uint32_t>(capv); d_nfv[k] = dmalloc<int32_t>(1);
+            HIP_OK(hipMemcpy(d_desc[k], f.desc.data(), (size_t)f.n * 32, hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(d_kp[k], f.kp.data(), sizeof(orbx_kp) * (size_t)f.n, hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(d_has[k], has.data(), f.n, hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(d_cnt[k], &f.n, 4, hipMemcpyHostToDevice));
+        }
+        d_m12 = dmalloc<int32_t>(capv); d_res = dmalloc<int32_t>(8); h_m12 = hmalloc<int32_t>(capv); h_res = hmalloc<int32_t>(8);
+    }
+    void run()
+    {
+        for (int k = 0; k < 2; ++k)
+            ORB_OK(orbv_transform_device(v, 1, d_desc[k], d_cnt[k], capv, /*levelsup*/ 1, d_ids[k], d_vals[k], d_nw[k], d_nodes[k], d_off[k], d_idx[k],
+                                         d_nfv[k], s));
+        ORB_OK(orbm_search_for_triangulation_device(m, 0, d_desc[0], d_kp[0], d_has[0], n[0], d_nodes[0], d_off[0], d_idx[0], d_nfv[0], d_desc[1],
+                                                    d_kp[1], d_has[1], n[1], d_nodes[1], d_off[1], d_idx[1], d_nfv[1], d_m12, d_res, s));
+        HIP_OK(hipMemcpyAsync(h_m12, d_m12, 4 * (size_t)n[0], hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(h_res, d_res, 32, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
+};
+
 int main(int argc, char **argv)
 {
     int iters = 12, latency = 0;
@@ -375,6 +470,45 @@ int main(int argc, char **argv)
     tm.join();
     std::printf("two threads, %d iterations each: T mismatches %d, M mismatches %d\n", iters, bad_t.load(), bad_m.load());
     if (bad_t.load() || bad_m.load()) return 1;
+
+    // ---- device chains: each thread on a non-blocking stream of its own (M has a vocabulary handle of its own: the device transform uses
+    // the handle's one scratch)
+    orbv_t *voc_dev = make_vocabulary(8, 2);
+    TDev td; MDev md;
+    td.init(S, xh, mt);
+    md.init(S, voc_dev, mm);
+    td.run();
+    const TDev::Out td_ref = td.out();
+    md.run();
+    const std::vector<int32_t> m12_dev(md.h_m12, md.h_m12 + S.a.n);
+    const int tri_dev = md.h_res[0];
+    // ... against the host entry points: the frame extracted on the device is the frame orbx_extract returns, its best / second best are
+    // orbm_best2's, and the device triangulation search is the host one
+    {
+        std::vector<int32_t> bi(t_ref.n); std::vector<uint16_t> bd(t_ref.n), sd(t_ref.n);
+        ORB_OK(orbm_best2(mt, t_ref.desc.data(), t_ref.n, S.a.desc.data(), S.a.n, nullptr, nullptr, bi.data(), bd.data(), sd.data()));
+        const bool ext = td_ref.n == t_ref.n && !memcmp(td_ref.kp.data(), t_ref.kp.data(), sizeof(orbx_kp) * (size_t)t_ref.n) &&
+                         !memcmp(td_ref.desc.data(), t_ref.desc.data(), 32 * (size_t)t_ref.n);
+        if (!ext || bi != td_ref.bi || bd != td_ref.bd || sd != td_ref.sd || md.h_res[1] != 0 || tri_dev != m_ref.n_tri || m12_dev != m_ref.m12) {
+            std::printf("device chains differ from the host entry points (extract %d, triangulation %d against %d, flag %d)\n", (int)ext, tri_dev, m_ref.n_tri,
+                        md.h_res[1]);
+            return 5;
+        }
+    }
+    std::atomic<int> bad_td{0}, bad_md{0};
+    std::thread dt([&] { for (int i = 0; i < iters; ++i) { td.run(); if (!same(td.out(), td_ref)) ++bad_td; } });
+    std::thread dm([&] {
+        for (int i = 0; i < iters; ++i) {
+            md.run();
+            if (md.h_res[0] != tri_dev || md.h_res[1] != 0 || memcmp(md.h_m12, m12_dev.data(), 4 * m12_dev.size())) ++bad_md;
+        }
+    });
+    dt.join();
+    dm.join();
+    std::printf("device chains on two streams, %d iterations each: T mismatches %d, M mismatches %d (best-2 of %d x %d, %d triangulation matches)\n", iters,
+                bad_td.load(), bad_md.load(), td_ref.n, S.a.n, tri_dev);
+    if (bad_td.load() || bad_md.load()) return 6;
+    orbv_destroy(voc_dev);
     orbx_destroy(xh); orbm_destroy(mt); orbm_destroy(mm);
     if (voc_m != voc) orbv_destroy(voc_m);
     orbv_destroy(voc);

@@ -228,7 +228,9 @@ def test_two_host_threads_through_the_c_abi(tmp_path):
     (System.cpp:55; LocalMapping.cpp:45-52, 168, 282, 301) that share one vocabulary.  tests/cpp/two_threads.cpp: thread T loops
     orbx_extract + orbv_transform + orbm_search_by_projection_frame + orbba_pose_optimize_batch, thread M loops orbv_transform +
     orbm_search_for_triangulation + orbm_search_fuse + orbba_local_bundle_adjustment, each on its own handles; every output of
-    every iteration equals the single-thread answer byte for byte."""
+    every iteration equals the single-thread answer byte for byte.  Then both threads run DEVICE chains, each on a non-blocking
+    stream of its own (orbx_extract_batch_device -> orbm_best2_device beside orbv_transform_device x2 ->
+    orbm_search_for_triangulation_device): equal to the single-thread chains and to the host entry points."""
     exe = str(tmp_path / "two_threads")
     lib = os.path.join(ROOT, "monoorbslam3_amd", "lib")
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
