@@ -47,17 +47,26 @@ struct VocLane {
     uint32_t *s_word = nullptr, *s_node = nullptr;
     double *s_w = nullptr;
     size_t s_items = 0;
-    // host-convenience staging
-    void *h_desc = nullptr, *h_bow_ids = nullptr, *h_bow_vals = nullptr, *h_fv_nodes = nullptr, *h_fv_off = nullptr,
-         *h_fv_idx = nullptr, *h_counts = nullptr;
+    // host-pointer staging: ONE device block and its page-locked mirror, laid out for `h_cap` features:
+    // [descriptors 32 B][counts n, n_words, n_fv + pad: 16 B][bow ids 4 B][bow values 8 B][fv nodes 4 B][fv offsets 4 B (+1)][fv indices 4 B]
+    uint8_t *d_blk = nullptr, *h_blk = nullptr;
     size_t h_cap = 0;
+    static size_t al(size_t x) { return (x + 15) & ~(size_t)15; }
+    size_t o_cnt() const { return al(h_cap * 32); }
+    size_t o_ids() const { return o_cnt() + 16; }
+    size_t o_vals() const { return al(o_ids() + h_cap * 4); }
+    size_t o_nodes() const { return o_vals() + h_cap * 8; }
+    size_t o_off() const { return al(o_nodes() + h_cap * 4); }
+    size_t o_idx() const { return al(o_off() + (h_cap + 1) * 4); }
+    size_t bytes() const { return al(o_idx() + h_cap * 4); }
     void release()
     {
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); stream = nullptr; }
-        for (void *p : {(void *)s_word, (void *)s_node, (void *)s_w, h_desc, h_bow_ids, h_bow_vals, h_fv_nodes, h_fv_off, h_fv_idx, h_counts})
+        for (void *p : {(void *)s_word, (void *)s_node, (void *)s_w, (void *)d_blk})
             if (p) (void)hipFree(p);
+        if (h_blk) (void)hipHostFree(h_blk);
         s_word = s_node = nullptr; s_w = nullptr; s_items = 0;
-        h_desc = h_bow_ids = h_bow_vals = h_fv_nodes = h_fv_off = h_fv_idx = h_counts = nullptr; h_cap = 0;
+        d_blk = h_blk = nullptr; h_cap = 0;
     }
 };
 
@@ -570,37 +579,38 @@ extern "C" int orbv_transform(orbv_t *c, const uint8_t *desc, int n, int levelsu
     hipStream_t s = ln.stream;
     if ((size_t)n > ln.h_cap) {
         V_TRY(hipStreamSynchronize(s));
-        for (void **p : {&ln.h_desc, &ln.h_bow_ids, &ln.h_bow_vals, &ln.h_fv_nodes, &ln.h_fv_off, &ln.h_fv_idx, &ln.h_counts})
-            if (*p) { (void)hipFree(*p); *p = nullptr; }
-        ln.h_cap = 0;
-        const size_t g = (size_t)n + n / 2 + 64;
-        V_TRY(hipMalloc(&ln.h_desc, g * 32));
-        V_TRY(hipMalloc(&ln.h_bow_ids, g * 4));
-        V_TRY(hipMalloc(&ln.h_bow_vals, g * 8));
-        V_TRY(hipMalloc(&ln.h_fv_nodes, g * 4));
-        V_TRY(hipMalloc(&ln.h_fv_off, (g + 1) * 4));
-        V_TRY(hipMalloc(&ln.h_fv_idx, g * 4));
-        V_TRY(hipMalloc(&ln.h_counts, 12));
-        ln.h_cap = g;
+        if (ln.d_blk) { (void)hipFree(ln.d_blk); ln.d_blk = nullptr; }
+        if (ln.h_blk) { (void)hipHostFree(ln.h_blk); ln.h_blk = nullptr; }
+        ln.h_cap = (size_t)n + n / 2 + 64;
+        const size_t nb = ln.bytes();
+        hipError_t e = hipMalloc((void **)&ln.d_blk, nb);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&ln.h_blk, nb, hipHostMallocDefault);
+        if (e != hipSuccess) { ln.h_cap = 0; V_TRY(e); }
     }
-    int32_t *cnt = (int32_t *)ln.h_counts; // [0] n, [1] n_words, [2] n_fv
-    const int32_t n32 = n;
-    V_TRY(hipMemcpyAsync(ln.h_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-    V_TRY(hipMemcpyAsync(cnt, &n32, 4, hipMemcpyHostToDevice, s));
-    int rc = transform_enqueue(c, ln, 1, (const uint8_t *)ln.h_desc, cnt, n, levelsup, (uint32_t *)ln.h_bow_ids,
-                               (double *)ln.h_bow_vals, cnt + 1, (uint32_t *)ln.h_fv_nodes, (int32_t *)ln.h_fv_off,
-                               (uint32_t *)ln.h_fv_idx, cnt + 2, s);
+    // one copy up (descriptors + the count), the two kernels, one copy down (counts and the five arrays at their capacity), ONE wait:
+    // the arrays then go to the caller from page-locked memory (was two waits and eight copies, five of them to pageable memory)
+    uint8_t *d = ln.d_blk, *h = ln.h_blk;
+    memcpy(h, desc, (size_t)n * 32);
+    int32_t *hc = reinterpret_cast<int32_t *>(h + ln.o_cnt());
+    hc[0] = n; hc[1] = 0; hc[2] = 0; hc[3] = 0;
+    V_TRY(hipMemcpyAsync(d, h, ln.o_ids(), hipMemcpyHostToDevice, s));
+    int32_t *cnt = reinterpret_cast<int32_t *>(d + ln.o_cnt()); // [0] n, [1] n_words, [2] n_fv
+    int rc = transform_enqueue(c, ln, 1, d, cnt, n, levelsup, reinterpret_cast<uint32_t *>(d + ln.o_ids()), reinterpret_cast<double *>(d + ln.o_vals()),
+                               cnt + 1, reinterpret_cast<uint32_t *>(d + ln.o_nodes()), reinterpret_cast<int32_t *>(d + ln.o_off()),
+                               reinterpret_cast<uint32_t *>(d + ln.o_idx()), cnt + 2, s);
     if (rc) return rc;
-    int32_t back[3];
-    V_TRY(hipMemcpyAsync(back, cnt, 12, hipMemcpyDeviceToHost, s));
+    // (the arrays are laid out for h_cap features; only the first n -- n + 1 offsets -- of each can hold anything)
+    const size_t down_end = ln.o_idx() + (size_t)n * 4;
+    V_TRY(hipMemcpyAsync(h + ln.o_cnt(), d + ln.o_cnt(), down_end - ln.o_cnt(), hipMemcpyDeviceToHost, s));
     V_TRY(hipStreamSynchronize(s));
-    *n_words = back[1];
-    *n_fv = back[2];
-    V_TRY(hipMemcpyAsync(bow_ids, ln.h_bow_ids, (size_t)back[1] * 4, hipMemcpyDeviceToHost, s));
-    V_TRY(hipMemcpyAsync(bow_vals, ln.h_bow_vals, (size_t)back[1] * 8, hipMemcpyDeviceToHost, s));
-    V_TRY(hipMemcpyAsync(fv_nodes, ln.h_fv_nodes, (size_t)back[2] * 4, hipMemcpyDeviceToHost, s));
-    V_TRY(hipMemcpyAsync(fv_off, ln.h_fv_off, (size_t)(back[2] + 1) * 4, hipMemcpyDeviceToHost, s));
-    V_TRY(hipMemcpyAsync(fv_idx, ln.h_fv_idx, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    V_TRY(hipStreamSynchronize(s));
+    const int nw = hc[1], nf = hc[2];
+    if (nw < 0 || nw > n || nf < 0 || nf > n) return orbx_set_error(ORBX_E_NO_DEVICE, "orbv_transform: counts out of range");
+    *n_words = nw;
+    *n_fv = nf;
+    memcpy(bow_ids, h + ln.o_ids(), (size_t)nw * 4);
+    memcpy(bow_vals, h + ln.o_vals(), (size_t)nw * 8);
+    memcpy(fv_nodes, h + ln.o_nodes(), (size_t)nf * 4);
+    memcpy(fv_off, h + ln.o_off(), (size_t)(nf + 1) * 4);
+    memcpy(fv_idx, h + ln.o_idx(), (size_t)n * 4);
     return ORBX_OK;
 }
