@@ -326,6 +326,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-match", action="store_true", help="time extraction only")
+    ap.add_argument("--clock-warmup-steps", type=int, default=150,
+                    help="untimed steps run before the --warmup steps so that the device's clocks are at their sustained level (0 = none)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the extra (untimed) keys config3 (2000 x 2000 Hamming best-2 / SearchByBow) and config5 (local BA 20 x 3000)")
     ap.add_argument("--no-density-sweep", action="store_true",
@@ -563,6 +565,13 @@ def main():
         torch.cuda.synchronize()
         return t_local
 
+    # Steady-state clocks before anything is timed: a device that sat idle while the inputs were built ramps its clocks over tens of
+    # milliseconds of load, and W = 3-5 warm-up steps are 7-11 ms of it -- the first timed steps then run slow (20 timed steps:
+    # 2.168 ms per step behind 3 warm-up steps, 2.141 behind 50; a 3000-step run sustains 2.12: profiles/r06_steps_sweep.txt).  A fixed
+    # number of untimed steps (the same on every rank: the N > 1 step holds a collective), then the W warm-up steps of the contract.
+    for _ in range(args.clock_warmup_steps):
+        step()
+    sync()
     for _ in range(args.warmup):
         step()
     sync()
@@ -908,6 +917,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "clock_warmup_steps": args.clock_warmup_steps,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
